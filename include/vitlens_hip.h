@@ -1,0 +1,130 @@
+/* vitlens_hip.h — C ABI of libvitlens_hip.so (MI355X / gfx950).
+ *
+ * The reference (TencentARC/ViT-Lens) has NO native layer: its hot path is stock torch.nn
+ * modules.  The drop-in boundary is therefore the Python module surface
+ * (open_clip.TriCLIP.encode_*, open_clip.loss.*, mm_vit_lens.ViTLens.encode); this C ABI
+ * sits directly under that surface and is what a maintainer's ctypes stub binds (see
+ * INTEGRATION.md).  Each entry point names the reference call it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed for the duration of the call; nothing is
+ *     retained or freed; workspaces are supplied by the caller
+ *   - all matrices are row-major; "bf16" is a 16-bit brain-float bit pattern (uint16_t)
+ *   - every function is stream-ordered and non-blocking on `stream` (a hipStream_t)
+ *   - return value: 0 on success, non-zero on failure; vl_last_error() gives the message
+ *   - no exceptions cross the ABI; no global mutable state except the last-error string
+ */
+#ifndef VITLENS_HIP_H
+#define VITLENS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+/* epilogues of vl_gemm_bf16 */
+#define VL_EPI_BF16 0     /* out bf16[M,N]   = act(alpha*acc + bias)                     */
+#define VL_EPI_F32 1      /* out f32 [M,N]   = alpha*acc + bias                          */
+#define VL_EPI_RES_F32 2  /* out f32 [M,N]   = res f32 + alpha*acc + bias (in place ok)  */
+#define VL_EPI_RES_BF16 3 /* out bf16[M,N]   = res bf16 + alpha*acc + bias               */
+#define VL_EPI_GEGLU 5    /* out bf16[M,N/2] = a*gelu(gate), W rows interleaved (a,gate) */
+#define VL_ACT_NONE 0
+#define VL_ACT_GELU 1     /* exact-erf GELU (nn.GELU default)                            */
+
+/* dtype tags for mixed-dtype entry points */
+#define VL_F32 0
+#define VL_BF16 1
+
+const char* vl_last_error(void);
+int vl_version(void);
+
+/* C[M,N] = A[M,K] · W[N,K]^T with fused epilogue.  A, W bf16.  K % 64 == 0, N % 4 == 0.
+ * cfg: -1 auto | 0: 256x256 tile LDS-DMA | 1: 128x128 LDS-DMA | 2/3: same, register staging.
+ * Replaces nn.Linear / out_proj / mlp.c_fc(+GELU) / mlp.c_proj(+residual)
+ * (open_clip/transformer.py:226-234,268-271), Perceiver to_q/to_kv/to_out/FeedForward
+ * (open_clip/perceiver.py:85-123), pooled @ proj (transformer.py:786-787) and
+ * logit_scale * x @ y.T (open_clip/loss.py:131-136). */
+int vl_gemm_bf16(const void* A, const void* W, const float* bias, void* out, const void* res,
+                 int M, int N, int K, int lda, int ldw, int ldo, float alpha, int epi, int act,
+                 int cfg, hipStream_t stream);
+
+/* Packed in-projection of nn.MultiheadAttention (transformer.py:215,252) with the head split
+ * fused into the epilogue: A[B*L,K] · Win[3*H*dh,K]^T + bias ->
+ *   q [B,H,L,dh] (pre-multiplied by qscale), k [B,H,L,dh], vt [B,H,dh,Lp] (V transposed,
+ *   key index contiguous, rows padded to Lp >= L; pad columns are never written). dh % 8 == 0. */
+int vl_gemm_qkv_bf16(const void* A, const void* Win, const float* bias, void* q, void* k, void* vt,
+                     int B, int L, int H, int dh, int Lp, int K, int lda, float qscale, int cfg,
+                     hipStream_t stream);
+
+int vl_device_info(int device, char* arch, int arch_len, int* cus, int* clock_khz, long* hbm_bytes);
+
+/* Fused attention forward: softmax(q k^T [+ causal mask]) v without materialising the scores.
+ * q [B,H,Lq,dh] (pre-scaled by softmax_scale*log2e), k [B,H,Lk,dh], vt [B,H,dh,Lkp];
+ * out [B,Lq,H*dh] bf16 (token-major, ready for the out-projection); lse [B,H,Lq] optional
+ * (natural-log LSE of the scaled scores, kept for the backward pass).  dh in {32, 64}.
+ * Replaces F.multi_head_attention_forward (transformer.py:241-252, causal mask :870-876) and
+ * the Perceiver einsum attention (perceiver.py:128-145). */
+int vl_attn_fwd_bf16(const void* q, const void* k, const void* vt, void* out, float* lse,
+                     int B, int H, int Lq, int Lk, int Lkp, int dh, int causal, hipStream_t stream);
+
+/* LayerNorm over the last dim (eps inside sqrt, biased variance): y = (x-mean)*rstd*w + b.
+ * Source row for output row r is  r*row_mul + row_index[r]  when row_index != NULL (EOT gather,
+ * model.py:539; cls pooling uses row_index == NULL with x_row_stride = (T+1)*D), else r.
+ * Replaces LayerNorm/LayerNormFp32 (transformer.py:17-34) and PreNorm (perceiver.py:67-82). */
+int vl_layernorm_fwd(const void* x, int x_dtype, long x_row_stride, const int64_t* row_index, long row_mul,
+                     const float* w, const float* b, void* y, int y_dtype, long y_row_stride,
+                     float* mean, float* rstd, int rows, int D, float eps, hipStream_t stream);
+
+/* [cls ; tokens] + positional_embedding (+ adapter pos on rows 1..T) -> ln_pre, one pass.
+ * tokens [B,T,D]; y [B,T+1,D].  Replaces transformer.py:756-772 (+ :734-745 for pos2). */
+int vl_assemble_ln_pre(const void* tokens, int tok_dtype, const float* cls, const float* pos, const float* pos2,
+                       const float* w, const float* b, void* y, int y_dtype, int B, int T, int D, float eps,
+                       hipStream_t stream);
+
+/* F.normalize(dim=-1, eps): y f32 and/or bf16 copy; norms[rows] optional (model.py:522-540). */
+int vl_l2_normalize(const float* x, float* y, void* y_bf16, float* norms, int rows, int D, float eps,
+                    hipStream_t stream);
+int vl_l2_normalize_bwd(const float* f, const float* df, const float* norms, float* dx, int rows, int D, float eps,
+                        hipStream_t stream);
+
+/* Patch extraction for Conv2d(bias=False, padding=0) as a GEMM operand: x [N,C,H,W] f32 ->
+ * patches bf16 [N*gh*gw, Kp], column order (c,i,j), zero padded to Kp.  transpose_hw=1 reads the
+ * stored tensor as [N,C,W,H] (AST_tokenizer.py:46-47).  Token order is row-major (gh, gw)
+ * exactly as conv -> reshape(N,C,-1).permute(0,2,1) (transformer.py:674-676). */
+int vl_im2col_bf16(const float* x, void* patches, int N, int C, int H, int W, int kh, int kw, int sh, int sw,
+                   int Kp, int transpose_hw, hipStream_t stream);
+
+/* out[b,l,:] = token_embedding[ids[b,l]] + positional_embedding[l]   (model.py:531-533) */
+int vl_text_embed(const int64_t* ids, const float* tok_emb, const float* pos, void* out, int out_dtype,
+                  int B, int L, int D, int vocab, hipStream_t stream);
+
+int vl_cast_f32_bf16(const float* x, void* y, long n, hipStream_t stream);
+/* y[r,:] = x[r,:] + table[r % T,:]   (x_vada["x"] + x_vada["pos"], transformer.py:743-745) */
+int vl_add_rows(const void* x, int x_dtype, const float* table, void* y, int y_dtype, long rows, int T, int D,
+                hipStream_t stream);
+/* out[c,r] bf16 = in[r,c]; columns r in [R, ldo) zero-filled (operand prep for gradient GEMMs) */
+int vl_transpose_to_bf16(const void* in, int in_dtype, long ldi, int R, int C, void* out, long ldo, hipStream_t stream);
+
+/* InfoNCE pieces over logits f32 [R,C] (row r's positive is column r+label_off):
+ *   vl_ce_stats      row_lse[R], col_lse[C], diag[R]; col_ws = 2*ceil(R/64)*C floats of workspace
+ *   vl_ce_loss_accum *loss += w_row*mean(row_lse-diag) + w_col*mean(col_lse[r+off]-diag)
+ *   vl_ce_grad       G[R,ldg] / GT[C,ldgt] bf16 = dLoss/dlogits (and transpose), *dscale += <G,logits>/scale
+ * Replaces F.cross_entropy(logits_per_x)+F.cross_entropy(logits_per_y) and autograd thereof
+ * (loss.py:158-163, 300-306, 377-383). */
+int vl_ce_stats(const float* logits, long ld, int R, int C, int label_off, float* row_lse, float* col_lse,
+                float* diag, float* col_ws, hipStream_t stream);
+int vl_ce_loss_accum(const float* row_lse, const float* col_lse, const float* diag, int R, int C, int label_off,
+                     float w_row, float w_col, float* loss_inout, hipStream_t stream);
+int vl_ce_grad(const float* logits, long ld, int R, int C, int label_off, const float* row_lse, const float* col_lse,
+               float w_row, float w_col, void* G, long ldg, void* GT, long ldgt, float logit_scale,
+               float* dscale_inout, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITLENS_HIP_H */

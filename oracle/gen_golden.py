@@ -23,14 +23,14 @@ OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 
 TINY = {
     "embed_dim": 32,
-    "vision_cfg": {"image_size": 32, "layers": 2, "width": 64, "patch_size": 8, "head_width": 16},
-    "text_cfg": {"context_length": 16, "vocab_size": 96, "width": 32, "heads": 2, "layers": 2},
+    "vision_cfg": {"image_size": 32, "layers": 2, "width": 64, "patch_size": 8, "head_width": 32},
+    "text_cfg": {"context_length": 16, "vocab_size": 96, "width": 64, "heads": 2, "layers": 2},
 }
 
 
 def tiny_args(modality):
-    common = dict(perceiver_num_latents=16, perceiver_latent_dim=64, perceiver_latent_heads=4,
-                  perceiver_latent_dim_head=16, perceiver_cross_dim_head=16, perceiver_cross_heads=1)
+    common = dict(perceiver_num_latents=16, perceiver_latent_dim=64, perceiver_latent_heads=2,
+                  perceiver_latent_dim_head=32, perceiver_cross_dim_head=32, perceiver_cross_heads=1)
     if modality == "depth":
         return ref_loader.lens_args("depth", **common)
     if modality == "audio":
@@ -39,7 +39,7 @@ def tiny_args(modality):
                                     perceiver_depth=2, perceiver_self_per_cross_attn=2, **common)
     if modality == "pc":
         return ref_loader.lens_args("pc", pc_num_group=16, pc_group_size=8, pc_encoder_dims=32,
-                                    pc_trans_dim=24, pc_npoints=256, perceiver_input_chan=24,
+                                    pc_trans_dim=64, pc_npoints=256, perceiver_input_chan=64,
                                     perceiver_depth=2, perceiver_self_per_cross_attn=1,
                                     pc_tokenizer="pointbert", pc_in_channel=3, pc_radius=0.2, **common)
     raise ValueError(modality)

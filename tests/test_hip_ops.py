@@ -1,0 +1,249 @@
+"""GPU parity of each HIP kernel (through the C ABI) against a plain fp32 PyTorch restatement of
+the same op evaluated on the bf16-rounded operands.  Tolerances are stated per test."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from vitlens_hip import ops
+    return ops
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def maxerr(a, b):
+    return float((a.float().cpu() - b.float().cpu()).abs().max())
+
+
+def relerr(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 200, 128), (1000, 1028, 1024), (65, 32, 64), (514, 3072, 1024)])
+def test_gemm_f32_out(cfg, M, N, K):
+    """Transpose-detecting (asymmetric) operands; fp32 accumulate => rel err <= 1e-5 vs fp32 matmul of
+    the same bf16 operands (only summation order differs)."""
+    ops = _ops()
+    a = rnd(M, K, seed=1).bfloat16().cuda(); w = rnd(N, K, seed=2).bfloat16().cuda()
+    bias = rnd(N, seed=3).cuda()
+    out = ops.gemm(a, w, bias, epi=ops.EPI_F32, alpha=0.5, cfg=cfg)
+    ref = 0.5 * (a.float().cpu() @ w.float().cpu().t()) + bias.cpu()
+    assert out.shape == (M, N)
+    assert relerr(out, ref) < 1e-5, (relerr(out, ref), maxerr(out, ref))
+
+
+@pytest.mark.parametrize("cfg", [0, 1])
+def test_gemm_identity_asymmetric(cfg):
+    """A = I  =>  C == W^T exactly (catches row/col swaps and fragment-layout errors bit-exactly)."""
+    ops = _ops()
+    K = 256
+    a = torch.eye(K).bfloat16().cuda()
+    w = (torch.arange(320 * K).reshape(320, K) % 251 - 125).float().bfloat16().cuda()
+    out = ops.gemm(a, w, None, epi=ops.EPI_F32, cfg=cfg)
+    assert torch.equal(out.cpu(), w.float().cpu().t())
+
+
+@pytest.mark.parametrize("cfg", [0, 1])
+def test_gemm_epilogues(cfg):
+    ops = _ops()
+    M, N, K = 520, 384, 192
+    a = rnd(M, K, seed=4).bfloat16().cuda(); w = rnd(N, K, seed=5, scale=0.1).bfloat16().cuda()
+    bias = rnd(N, seed=6).cuda()
+    acc = a.float().cpu() @ w.float().cpu().t() + bias.cpu()
+    # bf16 + GELU(erf): one bf16 rounding of the result => 2^-8 relative
+    out = ops.gemm(a, w, bias, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg)
+    ref = torch.nn.functional.gelu(acc)
+    assert maxerr(out, ref) < 1e-2 and relerr(out, ref) < 4e-3
+    # fp32 residual, in place
+    res = rnd(M, N, seed=7).cuda(); res0 = res.clone().cpu()
+    ops.gemm(a, w, bias, out=res, res=res, epi=ops.EPI_RES_F32, cfg=cfg)
+    assert relerr(res, res0 + acc) < 1e-5
+    # bf16 residual
+    resb = rnd(M, N, seed=8).bfloat16().cuda(); resb0 = resb.float().cpu()
+    ops.gemm(a, w, bias, out=resb, res=resb, epi=ops.EPI_RES_BF16, cfg=cfg)
+    assert relerr(resb, resb0 + acc) < 4e-3
+    # GEGLU with interleaved (a, gate) rows
+    out = ops.gemm(a, w, bias, epi=ops.EPI_GEGLU, cfg=cfg)
+    ref = acc[:, 0::2] * torch.nn.functional.gelu(acc[:, 1::2])
+    assert out.shape == (M, N // 2) and relerr(out, ref) < 4e-3
+
+
+def test_gelu_erf_accuracy():
+    """The A&S erf used in the epilogue: |gelu_hip - gelu_exact| <= 1e-6 before bf16 rounding; checked
+    through the f32 path by feeding x through an identity GEMM is not possible (GELU is bf16-out only),
+    so bound the bf16 result by half an ulp + 1e-6."""
+    ops = _ops()
+    K = 64
+    x = torch.linspace(-8, 8, 64 * 64).reshape(64, 64)
+    a = x.bfloat16().cuda()
+    w = torch.eye(K).bfloat16().cuda()
+    out = ops.gemm(a, w, None, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=1).float().cpu()
+    ref = torch.nn.functional.gelu(a.float().cpu())
+    ulp = ref.abs() * 2.0 ** -8 + 1e-6
+    assert bool(((out - ref).abs() <= ulp).all())
+
+
+@pytest.mark.parametrize("B,L,H,dh", [(2, 257, 16, 64), (3, 77, 12, 64), (2, 17, 2, 32), (1, 600, 1, 64)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_qkv_and_attention(B, L, H, dh, causal):
+    """in_proj GEMM + head split + fused attention vs explicit softmax(QK^T/sqrt(d)+mask)V in fp32 on the
+    bf16-rounded q/k/v.  P is rounded to bf16 before P·V (flash-attention practice) => abs err <= 2e-2·max|v|."""
+    ops = _ops()
+    D = H * dh
+    x = rnd(B * L, D, seed=9).bfloat16().cuda()
+    w = rnd(3 * D, D, seed=10, scale=D ** -0.5).bfloat16().cuda()
+    bias = rnd(3 * D, seed=11, scale=0.1).cuda()
+    Lp = (L + 7) // 8 * 8
+    q = torch.empty(B, H, L, dh, dtype=torch.bfloat16, device="cuda"); k = torch.empty_like(q)
+    vt = torch.full((B, H, dh, Lp), float("nan"), dtype=torch.bfloat16, device="cuda")  # poison the pad
+    ops.gemm_qkv(x, w, bias, q, k, vt, B, L, H, dh)
+    qkv = x.float().cpu() @ w.float().cpu().t() + bias.cpu()
+    qr, kr, vr = [t.reshape(B, L, H, dh).permute(0, 2, 1, 3) for t in qkv.split(D, dim=-1)]
+    scale = dh ** -0.5 * ops.LOG2E
+    assert relerr(q, qr * scale) < 4e-3
+    assert relerr(k, kr) < 4e-3
+    assert relerr(vt[..., :L].transpose(-1, -2), vr) < 4e-3
+    out = torch.empty(B * L, D, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B, H, L, device="cuda")
+    ops.attn_fwd(q, k, vt, out, lse=lse, causal=causal)
+    qf, kf, vf = q.float().cpu() / ops.LOG2E, k.float().cpu(), vt[..., :L].float().cpu().transpose(-1, -2)
+    s = qf @ kf.transpose(-1, -2)
+    if causal:
+        s = s + torch.full((L, L), float("-inf")).triu_(1)
+    ref = torch.softmax(s, -1) @ vf
+    ref = ref.permute(0, 2, 1, 3).reshape(B * L, D)
+    assert torch.isfinite(out.float()).all()
+    assert maxerr(out, ref) < 2e-2 * float(vf.abs().max()), maxerr(out, ref)
+    assert relerr(out, ref) < 1e-2
+    assert maxerr(lse, torch.logsumexp(s, -1)) < 1e-3
+
+
+@pytest.mark.parametrize("D", [1024, 768, 512, 384, 64, 24])
+@pytest.mark.parametrize("in_dt", [torch.float32, torch.bfloat16])
+def test_layernorm(D, in_dt):
+    ops = _ops()
+    rows = 37
+    x = (rnd(rows, D, seed=12) * 3 + 1).to(in_dt).cuda()
+    w = (1 + rnd(D, seed=13, scale=0.1)).cuda(); b = rnd(D, seed=14, scale=0.1).cuda()
+    ref = torch.nn.functional.layer_norm(x.float().cpu(), (D,), w.cpu(), b.cpu(), 1e-5)
+    y = torch.empty(rows, D, dtype=torch.float32, device="cuda")
+    mean = torch.empty(rows, device="cuda"); rstd = torch.empty(rows, device="cuda")
+    ops.layernorm(x, w, b, y, rows, D, mean=mean, rstd=rstd)
+    assert maxerr(y, ref) < 2e-5
+    assert maxerr(mean, x.float().cpu().mean(-1)) < 1e-5
+    yb = torch.empty(rows, D, dtype=torch.bfloat16, device="cuda")
+    ops.layernorm(x, w, b, yb, rows, D)
+    assert relerr(yb, ref) < 4e-3
+
+
+def test_layernorm_gather_and_stride():
+    ops = _ops()
+    B, L, D = 5, 9, 256
+    x = rnd(B * L, D, seed=15).cuda()
+    w = torch.ones(D).cuda(); b = torch.zeros(D).cuda()
+    idx = torch.tensor([3, 0, 8, 5, 1]).cuda()
+    y = torch.empty(B, D, device="cuda")
+    ops.layernorm(x, w, b, y, B, D, x_row_stride=D, row_index=idx, row_mul=L)
+    xr = x.cpu().reshape(B, L, D)[torch.arange(B), idx.cpu()]
+    assert maxerr(y, torch.nn.functional.layer_norm(xr, (D,))) < 2e-5
+    ops.layernorm(x, w, b, y, B, D, x_row_stride=L * D)      # cls pooling: row b*L
+    assert maxerr(y, torch.nn.functional.layer_norm(x.cpu().reshape(B, L, D)[:, 0], (D,))) < 2e-5
+
+
+@pytest.mark.parametrize("D", [1024, 64])
+def test_assemble_ln_pre(D):
+    ops = _ops()
+    B, T = 3, 16
+    tok = rnd(B * T, D, seed=16).bfloat16().cuda()
+    cls = rnd(D, seed=17).cuda(); pos = rnd(T + 1, D, seed=18).cuda(); pos2 = rnd(T, D, seed=19).cuda()
+    w = (1 + rnd(D, seed=20, scale=0.1)).cuda(); b = rnd(D, seed=21, scale=0.1).cuda()
+    for p2 in (None, pos2):
+        y = torch.empty(B * (T + 1), D, device="cuda")
+        ops.assemble_ln_pre(tok, cls, pos, p2, w, b, y, B, T, D)
+        t = tok.float().cpu().reshape(B, T, D)
+        if p2 is not None:
+            t = t + pos2.cpu()
+        x = torch.cat([cls.cpu().expand(B, 1, D), t], 1) + pos.cpu()
+        ref = torch.nn.functional.layer_norm(x, (D,), w.cpu(), b.cpu(), 1e-5).reshape(-1, D)
+        assert maxerr(y, ref) < 3e-5
+
+
+def test_im2col_token_order_exact():
+    """Patch -> token indexing must be bit-exact (values are integers representable in bf16)."""
+    ops = _ops()
+    N, Cc, H, W, p = 2, 3, 28, 28, 14
+    x = (torch.arange(N * Cc * H * W) % 200 - 100).float().reshape(N, Cc, H, W)
+    cols, gh, gw = ops.im2col(x.cuda(), p, p, p, p, 640)
+    ref = torch.nn.functional.unfold(x, (p, p), stride=p).transpose(1, 2).reshape(N * gh * gw, -1)
+    assert torch.equal(cols[:, :588].float().cpu(), ref)
+    assert float(cols[:, 588:].abs().max()) == 0.0
+    # AST: stored [N, T, F], conv input [N,1,F,T], 8x8 kernel stride 5 (overlapping)
+    xs = (torch.arange(2 * 33 * 24) % 120 - 60).float().reshape(2, 33, 24)
+    cols, gh, gw = ops.im2col(xs.unsqueeze(1).cuda(), 8, 8, 5, 5, 64, transpose_hw=True)
+    ref = torch.nn.functional.unfold(xs.unsqueeze(1).transpose(2, 3), (8, 8), stride=5).transpose(1, 2).reshape(-1, 64)
+    assert (gh, gw) == (4, 6)
+    assert torch.equal(cols.float().cpu(), ref)
+
+
+def test_text_embed_and_l2norm():
+    ops = _ops()
+    V, D, B, L = 50, 64, 3, 7
+    emb = rnd(V, D, seed=22).cuda(); pos = rnd(L, D, seed=23).cuda()
+    ids = torch.randint(0, V, (B, L), generator=torch.Generator().manual_seed(1)).cuda()
+    out = torch.empty(B * L, D, device="cuda")
+    ops.text_embed(ids, emb, pos, out)
+    ref = (emb.cpu()[ids.cpu()] + pos.cpu()).reshape(-1, D)
+    assert torch.equal(out.cpu(), ref)
+    x = rnd(9, 768, seed=24).cuda()
+    nrm = torch.empty(9, device="cuda"); yb = torch.empty(9, 768, dtype=torch.bfloat16, device="cuda")
+    y = ops.l2_normalize(x, out_bf16=yb, norms=nrm)
+    assert maxerr(y, torch.nn.functional.normalize(x.cpu(), dim=-1)) < 1e-6
+    assert maxerr(nrm, x.cpu().norm(dim=-1)) < 1e-4
+    df = rnd(9, 768, seed=25).cuda()
+    dx = ops.l2_normalize_bwd(y, df, nrm)
+    xr = x.cpu().clone().requires_grad_(True)
+    (torch.nn.functional.normalize(xr, dim=-1) * df.cpu()).sum().backward()
+    assert maxerr(dx, xr.grad) < 1e-6
+
+
+@pytest.mark.parametrize("R,Cc,off", [(64, 64, 0), (100, 100, 0), (48, 192, 96), (1024, 1024, 0)])
+def test_infonce_pieces(R, Cc, off):
+    """row/col LSE, loss and dL/dlogits vs autograd of F.cross_entropy (fp32)."""
+    ops = _ops()
+    lg = (rnd(R, Cc, seed=26) * 4).cuda()
+    square = (R == Cc)
+    row_lse, col_lse, diag = ops.ce_stats(lg, off, want_cols=square)
+    l = lg.cpu().clone().requires_grad_(True)
+    lab = torch.arange(R) + off
+    loss_ref = torch.nn.functional.cross_entropy(l, lab) * 0.5
+    if square:
+        loss_ref = loss_ref + torch.nn.functional.cross_entropy(l.t(), lab) * 0.5
+    loss_ref.backward()
+    loss = torch.zeros(1, device="cuda")
+    ops.ce_loss_accum(loss, row_lse, col_lse, diag, R, Cc, off, 0.5, 0.5)
+    assert abs(float(loss) - float(loss_ref)) < 1e-4
+    dscale = torch.zeros(1, device="cuda")
+    G, GT = ops.ce_grad(lg, row_lse, col_lse, off, 0.5, 0.5, 2.0, dscale)
+    assert relerr(G[:, :Cc], l.grad) < 5e-3
+    assert relerr(GT[:, :R], l.grad.t()) < 5e-3
+    assert float(G[:, Cc:].abs().max() if G.shape[1] > Cc else 0) == 0.0
+    ds_ref = float((l.grad * l.detach()).sum() / 2.0)
+    assert abs(float(dscale) - ds_ref) < 1e-3 * max(1.0, abs(ds_ref))
+
+
+def test_transpose_to_bf16():
+    ops = _ops()
+    x = rnd(70, 45, seed=27).cuda()
+    t = ops.transpose_to_bf16(x, ldo=128)
+    assert t.shape == (45, 128)
+    assert torch.equal(t[:, :70].cpu(), x.cpu().t().bfloat16())
+    assert float(t[:, 70:].abs().max()) == 0.0

@@ -1,0 +1,24 @@
+#!/bin/bash
+# One GPU-box visit: parity tests, micro-benchmarks, bench line, rocprof summary.  Logs -> gpurun_out/
+set +e
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+echo "== rocminfo ==" > gpurun_out/env.log
+rocminfo 2>/dev/null | grep -E "Marketing Name|gfx|Compute Unit|Max Clock" | head -12 >> gpurun_out/env.log
+nproc >> gpurun_out/env.log; lscpu | grep -E "Model name|^CPU\(s\)" >> gpurun_out/env.log
+echo "== pytest gpu ==" 
+timeout 900 python -m pytest tests -m gpu -q -n 4 -p no:cacheprovider 2>&1 | tail -80 > gpurun_out/pytest_gpu.log
+tail -40 gpurun_out/pytest_gpu.log
+echo "== kernel bench =="
+timeout 600 python tools/kernel_bench.py ${KB_ARGS:---quick} > gpurun_out/kernel_bench.log 2>&1
+tail -40 gpurun_out/kernel_bench.log
+echo "== bench =="
+timeout 600 python bench.py --steps 5 --warmup 2 --detail gpurun_out/bench_detail.json > gpurun_out/bench.log 2>&1
+tail -3 gpurun_out/bench.log
+echo "== rocprof =="
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1
+cd $GRAFT_REPO_ROOT
+find gpurun_out/prof -name "*stats*" | head; 
+for f in $(find gpurun_out/prof -name "*kernel_stats*.csv" | head -1); do head -30 $f; done
+# keep only the small summaries
+find gpurun_out/prof -name "*kernel_trace*" -size +20M -delete

@@ -1,0 +1,81 @@
+#!/usr/bin/env python
+"""Per-kernel micro-benchmarks on the GPU box (HIP-event timing, interleaved variants, random data).
+Writes gpurun_out/kernel_bench.json.  Usage: python tools/kernel_bench.py [--quick]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "vit-lens_amd"))
+import torch  # noqa: E402
+from vitlens_hip import ops  # noqa: E402
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def main():
+    quick = "--quick" in sys.argv
+    res = {"device": ops.device_info(0), "gemm": [], "attn": [], "rows": []}
+    T = 257 * 256
+    shapes = [("qkv", T, 3072, 1024), ("out", T, 1024, 1024), ("fc", T, 4096, 1024), ("proj", T, 1024, 4096),
+              ("sq4k", 4096, 4096, 4096), ("sq8k", 8192, 8192, 8192)]
+    for name, M, N, K in shapes:
+        a = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
+        bias = torch.randn(N, device="cuda")
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        resf = torch.randn(M, N, device="cuda")
+        for cfg in (0, 1, 2, 3):
+            for epi, act, label in ((ops.EPI_BF16, 0, "bf16"), (ops.EPI_BF16, 1, "bf16+gelu"), (ops.EPI_RES_F32, 0, "res_f32")):
+                if quick and (cfg > 1 or label == "bf16+gelu" and name not in ("fc",)):
+                    continue
+                if label == "res_f32":
+                    fn = lambda: ops.gemm(a, w, bias, out=resf, res=resf, epi=epi, cfg=cfg)
+                else:
+                    fn = lambda: ops.gemm(a, w, bias, out=out, epi=epi, act=act, cfg=cfg)
+                med, mn = timeit(fn)
+                tf = 2.0 * M * N * K / (med * 1e-3) / 1e12
+                res["gemm"].append({"shape": name, "M": M, "N": N, "K": K, "cfg": cfg, "epi": label, "ms": med, "min_ms": mn, "tflops": tf})
+                print(f"gemm {name:5s} cfg{cfg} {label:10s} {med:8.3f} ms  {tf:7.1f} TF/s", flush=True)
+        del a, w, out, resf
+    # qkv + attention at the bench shape
+    B, L, H, dh = 256, 257, 16, 64
+    D = H * dh
+    x = torch.randn(B * L, D, device="cuda").bfloat16(); w = (torch.randn(3 * D, D, device="cuda") * D ** -0.5).bfloat16()
+    bias = torch.randn(3 * D, device="cuda")
+    q = torch.empty(B, H, L, dh, device="cuda", dtype=torch.bfloat16); k = torch.empty_like(q)
+    vt = torch.zeros(B, H, dh, 264, device="cuda", dtype=torch.bfloat16)
+    o = torch.empty(B * L, D, device="cuda", dtype=torch.bfloat16)
+    for cfg in (0, 1):
+        med, mn = timeit(lambda: ops.gemm_qkv(x, w, bias, q, k, vt, B, L, H, dh, cfg=cfg))
+        print(f"qkv-scatter cfg{cfg} {med:8.3f} ms {2.0 * B * L * 3 * D * D / med / 1e9:7.1f} TF/s", flush=True)
+        res["gemm"].append({"shape": "qkv_scatter", "cfg": cfg, "ms": med, "tflops": 2.0 * B * L * 3 * D * D / med / 1e9})
+    med, mn = timeit(lambda: ops.attn_fwd(q, k, vt, o))
+    fl = 4.0 * B * H * L * L * dh
+    print(f"attn fwd {med:8.3f} ms {fl / med / 1e9:7.1f} TF/s", flush=True)
+    res["attn"].append({"B": B, "L": L, "H": H, "dh": dh, "ms": med, "tflops": fl / med / 1e9})
+    # layernorm
+    for dt, nm in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        xr = torch.randn(B * L, D, device="cuda").to(dt)
+        wln = torch.ones(D, device="cuda"); bln = torch.zeros(D, device="cuda")
+        med, mn = timeit(lambda: ops.layernorm(xr, wln, bln, o, B * L, D))
+        gb = (xr.numel() * xr.element_size() + o.numel() * 2) / 1e9
+        print(f"layernorm {nm} {med:8.3f} ms {gb / med * 1e3:7.1f} GB/s", flush=True)
+        res["rows"].append({"op": "layernorm_" + nm, "ms": med, "gbps": gb / med * 1e3})
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "kernel_bench.json"), "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,223 @@
+// InfoNCE (CLIP contrastive) loss pieces on gfx950.
+//
+// Replaces F.cross_entropy over rows and columns of `logit_scale * x @ y.T` and its autograd
+// (open_clip/loss.py:129-136,158-163,300-306,377-383).  The logits matrix is produced once
+// by vl_gemm_bf16 (fp32 out); these kernels read it ONCE for the row statistics, once for the
+// column statistics and once to emit the gradient matrix G = dL/dlogits (bf16) together with
+// its transpose, so the two feature-gradient GEMMs run as plain NT GEMMs.
+//   labels: row r <-> column (r + label_off)     (label_off = rank*b under --local-loss)
+#include "vl_common.h"
+#include "vitlens_hip.h"
+
+namespace {
+
+// one wave per row: online (max, sum) -> lse[r]; diag[r] = logits[r, r+off]
+__global__ void __launch_bounds__(256) row_lse_kernel(const float* lg, long ld, int R, int C, int off,
+                                                      float* lse, float* diag) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float* row = lg + (long)r * ld;
+  float m = -INFINITY, s = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float v = row[c];
+    const float mn = fmaxf(m, v);
+    s = s * __expf(m - mn) + __expf(v - mn);
+    m = mn;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+    const float mn = fmaxf(m, m2);
+    const float a = (m == -INFINITY) ? 0.f : s * __expf(m - mn);
+    const float b = (m2 == -INFINITY) ? 0.f : s2 * __expf(m2 - mn);
+    s = a + b; m = mn;
+  }
+  if (lane == 0) {
+    lse[r] = m + __logf(s);
+    if (diag) { const int c = r + off; diag[r] = (c >= 0 && c < C) ? row[c] : 0.f; }
+  }
+}
+
+// column partials over a chunk of 64 rows: thread per column (coalesced)
+__global__ void __launch_bounds__(256) col_part_kernel(const float* lg, long ld, int R, int C,
+                                                       float* pm, float* ps) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int r0 = blockIdx.y * 64, r1 = min(R, r0 + 64);
+  float m = -INFINITY, s = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const float v = lg[(long)r * ld + c];
+    const float mn = fmaxf(m, v);
+    s = s * __expf(m - mn) + __expf(v - mn);
+    m = mn;
+  }
+  pm[(long)blockIdx.y * C + c] = m; ps[(long)blockIdx.y * C + c] = s;
+}
+__global__ void __launch_bounds__(256) col_comb_kernel(const float* pm, const float* ps, int nchunk, int C, float* lse) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float m = -INFINITY, s = 0.f;
+  for (int k = 0; k < nchunk; ++k) {
+    const float m2 = pm[(long)k * C + c], s2 = ps[(long)k * C + c];
+    const float mn = fmaxf(m, m2);
+    const float a = (m == -INFINITY) ? 0.f : s * __expf(m - mn);
+    s = a + s2 * __expf(m2 - mn); m = mn;
+  }
+  lse[c] = m + __logf(s);
+}
+
+// loss_out[0] += w_row * mean_r(row_lse[r] - diag[r]) + w_col * mean_r(col_lse[r+off] - diag[r])
+__global__ void __launch_bounds__(256) ce_reduce_kernel(const float* row_lse, const float* col_lse, const float* diag,
+                                                        int R, int C, int off, float w_row, float w_col, float* loss_out) {
+  float a = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) {
+    float v = 0.f;
+    if (row_lse) v += w_row * (row_lse[r] - diag[r]);
+    const int c = r + off;
+    if (col_lse && c >= 0 && c < C) v += w_col * (col_lse[c] - diag[r]);
+    a += v;
+  }
+  __shared__ float sh[4];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss_out, (sh[0] + sh[1] + sh[2] + sh[3]) / (float)R);
+}
+
+// G[r,c] = w_row/R * (softmax_row - onehot) + w_col/R * (softmax_col - onehot); also G^T; dscale += sum(G*l)/scale
+__global__ void __launch_bounds__(256) grad_kernel(const float* lg, long ld, int R, int C, int off,
+                                                   const float* row_lse, const float* col_lse, float w_row, float w_col,
+                                                   bf16_t* G, long ldg, bf16_t* GT, long ldgt, float inv_scale, float* dscale) {
+  __shared__ float tile[32][33];
+  __shared__ float red[4];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const float invR = 1.0f / (float)R;
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + k * 8, c = c0 + tx;
+    float g = 0.f;
+    if (r < R && c < C) {
+      const float l = lg[(long)r * ld + c];
+      const float hot = (c == r + off) ? 1.f : 0.f;
+      if (row_lse) g += w_row * invR * (__expf(l - row_lse[r]) - hot);
+      if (col_lse) g += w_col * invR * (__expf(l - col_lse[c]) - hot);
+      acc = fmaf(g, l, acc);
+    }
+    tile[ty + k * 8][tx] = g;
+    if (G && r < R && c < ldg) G[(long)r * ldg + c] = f2bf(g);   // pad columns [C, ldg) get zeros
+  }
+  __syncthreads();
+  if (GT) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + ty + k * 8, r = r0 + tx;
+      if (c < C && r < ldgt) GT[(long)c * ldgt + r] = f2bf(r < R ? tile[tx][ty + k * 8] : 0.f);
+    }
+  }
+  if (dscale) {
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dscale, (red[0] + red[1] + red[2] + red[3]) * inv_scale);
+  }
+}
+
+// backward of F.normalize: dx = (df - f * <f, df>) / max(||x||, eps)  (f = normalised feature)
+__global__ void __launch_bounds__(256) l2norm_bwd_kernel(const float* f, const float* df, const float* nrm, float* dx,
+                                                         int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* fr = f + (long)row * D; const float* dr = df + (long)row * D;
+  float s = 0.f;
+  for (int e = lane; e < D; e += 64) s = fmaf(fr[e], dr[e], s);
+  s = wave_sum(s);
+  const float inv = 1.0f / fmaxf(nrm[row], eps);
+  for (int e = lane; e < D; e += 64) dx[(long)row * D + e] = (dr[e] - fr[e] * s) * inv;
+}
+
+// out[c, r] (bf16, ld) = in[r, c] (f32 or bf16) ; pads columns r in [R, ld) with zeros
+template <typename TIN>
+__global__ void __launch_bounds__(256) transpose_bf16_kernel(const TIN* in, long ldi, int R, int C, bf16_t* out, long ldo) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + k * 8, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < C) {
+      if constexpr (sizeof(TIN) == 4) v = ((const float*)in)[(long)r * ldi + c];
+      else v = bf2f(((const bf16_t*)in)[(long)r * ldi + c]);
+    }
+    tile[ty + k * 8][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + k * 8, r = r0 + tx;
+    if (c < C && r < ldo) out[(long)c * ldo + r] = f2bf(tile[tx][ty + k * 8]);
+  }
+}
+
+}  // namespace
+
+extern "C" int vl_set_error(const char* msg);
+#define VL_HIP_OK(e) do { hipError_t _e = (e); if (_e != hipSuccess) return vl_set_error(hipGetErrorString(_e)); } while (0)
+
+extern "C" int vl_ce_stats(const float* logits, long ld, int R, int C, int label_off, float* row_lse, float* col_lse,
+                           float* diag, float* col_ws, hipStream_t stream) {
+  if (R <= 0 || C <= 0) return vl_set_error("vl_ce_stats: empty problem");
+  if (row_lse || diag) {
+    if (!row_lse) return vl_set_error("vl_ce_stats: diag requires row_lse");
+    hipLaunchKernelGGL(row_lse_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, logits, ld, R, C, label_off, row_lse, diag);
+  }
+  if (col_lse) {
+    if (!col_ws) return vl_set_error("vl_ce_stats: col_lse needs a workspace of 2*ceil(R/64)*C floats");
+    const int nch = (R + 63) / 64;
+    float* pm = col_ws; float* ps = col_ws + (long)nch * C;
+    hipLaunchKernelGGL(col_part_kernel, dim3((C + 255) / 256, nch), dim3(256), 0, stream, logits, ld, R, C, pm, ps);
+    hipLaunchKernelGGL(col_comb_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, pm, ps, nch, C, col_lse);
+  }
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vl_ce_loss_accum(const float* row_lse, const float* col_lse, const float* diag, int R, int C, int label_off,
+                                float w_row, float w_col, float* loss_inout, hipStream_t stream) {
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, stream, row_lse, col_lse, diag, R, C, label_off, w_row, w_col, loss_inout);
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vl_ce_grad(const float* logits, long ld, int R, int C, int label_off, const float* row_lse, const float* col_lse,
+                          float w_row, float w_col, void* G, long ldg, void* GT, long ldgt, float logit_scale,
+                          float* dscale_inout, hipStream_t stream) {
+  if (R <= 0 || C <= 0) return vl_set_error("vl_ce_grad: empty problem");
+  const int gc = (int)(((G && ldg > C ? ldg : C) + 31) / 32), gr = (int)(((GT && ldgt > R ? ldgt : R) + 31) / 32);
+  hipLaunchKernelGGL(grad_kernel, dim3(gc, gr), dim3(256), 0, stream, logits, ld, R, C, label_off, row_lse, col_lse, w_row, w_col,
+                     (bf16_t*)G, ldg, (bf16_t*)GT, ldgt, 1.0f / logit_scale, dscale_inout);
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vl_l2_normalize_bwd(const float* f, const float* df, const float* norms, float* dx, int rows, int D, float eps,
+                                   hipStream_t stream) {
+  if (rows <= 0) return vl_set_error("vl_l2_normalize_bwd: empty problem");
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, f, df, norms, dx, rows, D, eps);
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vl_transpose_to_bf16(const void* in, int in_dtype, long ldi, int R, int C, void* out, long ldo, hipStream_t stream) {
+  if (R <= 0 || C <= 0) return vl_set_error("vl_transpose_to_bf16: empty problem");
+  if (ldo < R) return vl_set_error("vl_transpose_to_bf16: ldo < R");
+  const dim3 g((C + 31) / 32, (int)((ldo + 31) / 32));
+  if (in_dtype == VL_F32) hipLaunchKernelGGL(transpose_bf16_kernel<float>, g, dim3(256), 0, stream, (const float*)in, ldi, R, C, (bf16_t*)out, ldo);
+  else hipLaunchKernelGGL(transpose_bf16_kernel<bf16_t>, g, dim3(256), 0, stream, (const bf16_t*)in, ldi, R, C, (bf16_t*)out, ldo);
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}

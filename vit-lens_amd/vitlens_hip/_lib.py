@@ -1,0 +1,64 @@
+"""ctypes binding of libvitlens_hip.so (the C ABI declared in include/vitlens_hip.h)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class LibraryNotBuilt(ImportError):
+    pass
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "libvitlens_hip.so")
+
+
+P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+# name -> argtypes (all functions return int status unless listed in _RET)
+SIGNATURES = {
+    "vl_version": [],
+    "vl_device_info": [I, C.c_char_p, I, C.POINTER(I), C.POINTER(I), C.POINTER(L)],
+    "vl_gemm_bf16": [P, P, P, P, P, I, I, I, I, I, I, F, I, I, I, P],
+    "vl_gemm_qkv_bf16": [P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P],
+    "vl_attn_fwd_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "vl_layernorm_fwd": [P, I, L, P, L, P, P, P, I, L, P, P, I, I, F, P],
+    "vl_assemble_ln_pre": [P, I, P, P, P, P, P, P, I, I, I, I, F, P],
+    "vl_l2_normalize": [P, P, P, P, I, I, F, P],
+    "vl_l2_normalize_bwd": [P, P, P, P, I, I, F, P],
+    "vl_im2col_bf16": [P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "vl_text_embed": [P, P, P, P, I, I, I, I, I, P],
+    "vl_cast_f32_bf16": [P, P, L, P],
+    "vl_add_rows": [P, I, P, P, I, L, I, I, P],
+    "vl_transpose_to_bf16": [P, I, L, I, I, P, L, P],
+    "vl_ce_stats": [P, L, I, I, I, P, P, P, P, P],
+    "vl_ce_loss_accum": [P, P, P, I, I, I, F, F, P, P],
+    "vl_ce_grad": [P, L, I, I, I, P, P, F, F, P, L, P, L, F, P, P],
+}
+
+
+def load_library():
+    """Load the shared library or fail loudly (there is no fallback path)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise LibraryNotBuilt(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C vit-lens_amd/csrc` (hipcc --offload-arch=gfx950). No CPU/eager fallback exists.")
+    lib = C.CDLL(path)
+    lib.vl_last_error.restype = C.c_char_p
+    lib.vl_last_error.argtypes = []
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.argtypes = args
+        fn.restype = I
+    _LIB = lib
+    return lib
+
+
+def check(status: int):
+    if status != 0:
+        raise RuntimeError("libvitlens_hip: " + load_library().vl_last_error().decode())

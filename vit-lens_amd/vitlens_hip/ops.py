@@ -1,0 +1,198 @@
+"""Tensor-level wrappers over the C ABI.  Every function enqueues HIP kernels on the current
+torch stream and returns immediately.  Inputs must live on a GPU: there is no CPU fallback."""
+import ctypes as C
+import math
+
+import torch
+
+from ._lib import load_library, check
+
+F32, BF16 = 0, 1
+EPI_BF16, EPI_F32, EPI_RES_F32, EPI_RES_BF16, EPI_GEGLU = 0, 1, 2, 3, 5
+ACT_NONE, ACT_GELU = 0, 1
+LOG2E = 1.4426950408889634
+
+_lib = load_library()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("vitlens_hip ops need GPU tensors (no CPU fallback)")
+    return C.c_void_p(t.data_ptr())
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _chk2d(t, name, dtype=None):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: need a row-major 2-D tensor, got shape {tuple(t.shape)} strides {t.stride()}")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def gemm(a, w, bias=None, out=None, res=None, epi=EPI_BF16, act=ACT_NONE, alpha=1.0, cfg=-1):
+    """out = epilogue(a @ w.T).  a [M,K] bf16, w [N,K] bf16."""
+    _chk2d(a, "a", torch.bfloat16); _chk2d(w, "w", torch.bfloat16)
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"gemm: K mismatch {a.shape} vs {w.shape}")
+    if out is None:
+        n_out = N // 2 if epi == EPI_GEGLU else N
+        odt = torch.float32 if epi in (EPI_F32, EPI_RES_F32) else torch.bfloat16
+        out = torch.empty(M, n_out, device=a.device, dtype=odt)
+    _chk2d(out, "out")
+    if res is not None:
+        _chk2d(res, "res")
+        if res.stride(0) != out.stride(0) or res.dtype != out.dtype:
+            raise ValueError("gemm: residual must share out's row stride and dtype")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N):
+        raise ValueError("gemm: bias must be f32 [N]")
+    check(_lib.vl_gemm_bf16(_p(a), _p(w), _p(bias), _p(out), _p(res), M, N, K, a.stride(0), w.stride(0),
+                            out.stride(0), float(alpha), epi, act, cfg, _stream()))
+    return out
+
+
+def gemm_qkv(a, w, bias, q, k, vt, B, L, H, dh, softmax_scale=None, cfg=-1):
+    """Packed MHA in-projection with head split: fills q,k [B,H,L,dh] and vt [B,H,dh,Lp]."""
+    _chk2d(a, "a", torch.bfloat16); _chk2d(w, "w", torch.bfloat16)
+    if a.shape[0] != B * L or w.shape[0] != 3 * H * dh or w.stride(0) != w.shape[1]:
+        raise ValueError("gemm_qkv: shape mismatch")
+    Lp = vt.shape[-1]
+    scale = (dh ** -0.5 if softmax_scale is None else softmax_scale) * LOG2E
+    check(_lib.vl_gemm_qkv_bf16(_p(a), _p(w), _p(bias), _p(q), _p(k), _p(vt), B, L, H, dh, Lp, a.shape[1],
+                                a.stride(0), float(scale), cfg, _stream()))
+
+
+def attn_fwd(q, k, vt, out, lse=None, causal=False):
+    """q [B,H,Lq,dh] (pre-scaled), k [B,H,Lk,dh], vt [B,H,dh,Lkp] -> out [B*Lq, H*dh] bf16."""
+    B, H, Lq, dh = q.shape
+    Lk = k.shape[2]
+    Lkp = vt.shape[3]
+    check(_lib.vl_attn_fwd_bf16(_p(q), _p(k), _p(vt), _p(out), _p(lse), B, H, Lq, Lk, Lkp, dh,
+                                1 if causal else 0, _stream()))
+    return out
+
+
+def layernorm(x, w, b, out, rows, D, x_row_stride=None, row_index=None, row_mul=0, mean=None, rstd=None,
+              eps=1e-5):
+    xs = D if x_row_stride is None else x_row_stride
+    check(_lib.vl_layernorm_fwd(_p(x), _dt(x), xs, _p(row_index), row_mul, _p(w), _p(b), _p(out), _dt(out),
+                                out.stride(-2) if out.dim() >= 2 else D, _p(mean), _p(rstd), rows, D,
+                                float(eps), _stream()))
+    return out
+
+
+def assemble_ln_pre(tokens, cls, pos, pos2, w, b, out, B, T, D, eps=1e-5):
+    check(_lib.vl_assemble_ln_pre(_p(tokens), _dt(tokens), _p(cls), _p(pos), _p(pos2), _p(w), _p(b), _p(out),
+                                  _dt(out), B, T, D, float(eps), _stream()))
+    return out
+
+
+def l2_normalize(x, out=None, out_bf16=None, norms=None, eps=1e-12):
+    _chk2d(x, "x", torch.float32)
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.vl_l2_normalize(_p(x), _p(out), _p(out_bf16), _p(norms), x.shape[0], x.shape[1], float(eps),
+                               _stream()))
+    return out
+
+
+def l2_normalize_bwd(f, df, norms, eps=1e-12):
+    dx = torch.empty_like(f)
+    check(_lib.vl_l2_normalize_bwd(_p(f), _p(df), _p(norms), _p(dx), f.shape[0], f.shape[1], float(eps),
+                                   _stream()))
+    return dx
+
+
+def im2col(x, kh, kw, sh, sw, Kp, transpose_hw=False, out=None):
+    """x [N,C,H,W] f32 (or [N,C,W,H] stored when transpose_hw) -> bf16 [N*gh*gw, Kp]."""
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("im2col: need contiguous f32 input")
+    N, Cc = x.shape[0], x.shape[1]
+    H, W = (x.shape[3], x.shape[2]) if transpose_hw else (x.shape[2], x.shape[3])
+    gh, gw = (H - kh) // sh + 1, (W - kw) // sw + 1
+    if out is None:
+        out = torch.empty(N * gh * gw, Kp, device=x.device, dtype=torch.bfloat16)
+    check(_lib.vl_im2col_bf16(_p(x), _p(out), N, Cc, H, W, kh, kw, sh, sw, Kp, 1 if transpose_hw else 0,
+                              _stream()))
+    return out, gh, gw
+
+
+def text_embed(ids, tok_emb, pos, out):
+    B, L = ids.shape
+    check(_lib.vl_text_embed(_p(ids), _p(tok_emb), _p(pos), _p(out), _dt(out), B, L, tok_emb.shape[1],
+                             tok_emb.shape[0], _stream()))
+    return out
+
+
+def cast_bf16(x, out=None):
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    check(_lib.vl_cast_f32_bf16(_p(x), _p(out), x.numel(), _stream()))
+    return out
+
+
+def add_rows(x, table, out, rows, T, D):
+    check(_lib.vl_add_rows(_p(x), _dt(x), _p(table), _p(out), _dt(out), rows, T, D, _stream()))
+    return out
+
+
+def transpose_to_bf16(x, ldo=None, out=None):
+    """x [R,C] (f32|bf16, row-major) -> bf16 [C, ldo] with zero-filled tail columns."""
+    _chk2d(x, "x")
+    R, Cc = x.shape
+    ldo = R if ldo is None else ldo
+    if out is None:
+        out = torch.empty(Cc, ldo, device=x.device, dtype=torch.bfloat16)
+    check(_lib.vl_transpose_to_bf16(_p(x), _dt(x), x.stride(0), R, Cc, _p(out), ldo, _stream()))
+    return out
+
+
+def ce_stats(logits, label_off=0, want_cols=True):
+    _chk2d(logits, "logits", torch.float32)
+    R, Cc = logits.shape
+    dev = logits.device
+    row_lse = torch.empty(R, device=dev, dtype=torch.float32)
+    diag = torch.empty(R, device=dev, dtype=torch.float32)
+    col_lse = torch.empty(Cc, device=dev, dtype=torch.float32) if want_cols else None
+    ws = torch.empty(2 * ((R + 63) // 64) * Cc, device=dev, dtype=torch.float32) if want_cols else None
+    check(_lib.vl_ce_stats(_p(logits), logits.stride(0), R, Cc, label_off, _p(row_lse), _p(col_lse), _p(diag),
+                           _p(ws), _stream()))
+    return row_lse, col_lse, diag
+
+
+def ce_loss_accum(loss, row_lse, col_lse, diag, R, Cc, label_off, w_row, w_col):
+    check(_lib.vl_ce_loss_accum(_p(row_lse), _p(col_lse), _p(diag), R, Cc, label_off, float(w_row), float(w_col),
+                                _p(loss), _stream()))
+
+
+def ce_grad(logits, row_lse, col_lse, label_off, w_row, w_col, logit_scale, dscale, need_g=True, need_gt=True):
+    R, Cc = logits.shape
+    dev = logits.device
+    ldg = (Cc + 63) // 64 * 64
+    ldgt = (R + 63) // 64 * 64
+    G = torch.empty(R, ldg, device=dev, dtype=torch.bfloat16) if need_g else None
+    GT = torch.empty(Cc, ldgt, device=dev, dtype=torch.bfloat16) if need_gt else None
+    check(_lib.vl_ce_grad(_p(logits), logits.stride(0), R, Cc, label_off, _p(row_lse), _p(col_lse), float(w_row),
+                          float(w_col), _p(G), ldg, _p(GT), ldgt, float(logit_scale), _p(dscale), _stream()))
+    return G, GT
+
+
+def device_info(device=0):
+    arch = C.create_string_buffer(64)
+    cus, clk, mem = C.c_int(), C.c_int(), C.c_long()
+    check(_lib.vl_device_info(device, arch, 64, C.byref(cus), C.byref(clk), C.byref(mem)))
+    return {"arch": arch.value.decode(), "cus": cus.value, "clock_khz": clk.value, "hbm_bytes": mem.value}
