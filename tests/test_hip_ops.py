@@ -62,7 +62,7 @@ def test_gemm_epilogues(cfg):
     # bf16 + GELU(erf): one bf16 rounding of the result => 2^-8 relative
     out = ops.gemm(a, w, bias, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg)
     ref = torch.nn.functional.gelu(acc)
-    assert maxerr(out, ref) < 1e-2 and relerr(out, ref) < 4e-3
+    assert bool(((out.float().cpu() - ref).abs() <= ref.abs() * 2.0 ** -8 + 1e-3).all()) and relerr(out, ref) < 4e-3
     # fp32 residual, in place
     res = rnd(M, N, seed=7).cuda(); res0 = res.clone().cpu()
     ops.gemm(a, w, bias, out=res, res=res, epi=ops.EPI_RES_F32, cfg=cfg)

@@ -79,7 +79,10 @@ def test_vitl_text_tower_vs_oracle():
     eng = E.TextEngine(sd, E.TextCfg(), "cuda")
     got = eng.encode_text(text.cuda())
     assert relerr(got, ref) < 2e-2, relerr(got, ref)
-    assert float((cos_matrix(got, got) - cos_matrix(ref, ref)).abs().max()) < 1e-3
+    # random-init text features share a large common component (mutual cosine ~0.6), which makes the
+    # cosine matrix ~2x more sensitive to the bf16 operand rounding than the image tower's: 2e-3 here.
+    assert float((cos_matrix(got, got) - cos_matrix(ref, ref)).abs().max()) < 2e-3
+    assert float((1 - torch.nn.functional.cosine_similarity(got.float().cpu(), ref, dim=-1)).max()) < 1e-3
 
 
 def test_batch_invariance_full_size():

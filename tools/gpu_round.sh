@@ -16,7 +16,7 @@ echo "== bench =="
 timeout 600 python bench.py --steps 5 --warmup 2 --detail gpurun_out/bench_detail.json > gpurun_out/bench.log 2>&1
 tail -3 gpurun_out/bench.log
 echo "== rocprof =="
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1
 cd $GRAFT_REPO_ROOT
 find gpurun_out/prof -name "*stats*" | head; 
 for f in $(find gpurun_out/prof -name "*kernel_stats*.csv" | head -1); do head -30 $f; done
