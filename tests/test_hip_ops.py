@@ -27,7 +27,7 @@ def relerr(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, -1])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 200, 128), (1000, 1028, 1024), (65, 32, 64), (514, 3072, 1024)])
 def test_gemm_f32_out(cfg, M, N, K):
     """Transpose-detecting (asymmetric) operands; fp32 accumulate => rel err <= 1e-5 vs fp32 matmul of
@@ -41,7 +41,25 @@ def test_gemm_f32_out(cfg, M, N, K):
     assert relerr(out, ref) < 1e-5, (relerr(out, ref), maxerr(out, ref))
 
 
-@pytest.mark.parametrize("cfg", [0, 1])
+@pytest.mark.parametrize("cfg", [4, 5, -1])
+def test_gemm_persistent_many_tiles_and_row_split(cfg):
+    """Persistent kernels: several tiles per workgroup, tile switch inside the flattened k-loop, and (auto)
+    the split into a CU-balanced persistent launch + a 128x128 remainder launch on the last rows."""
+    ops = _ops()
+    M, N, K = 256 * 64 + 300, 1024, 192
+    a = rnd(M, K, seed=31).bfloat16().cuda(); w = rnd(N, K, seed=32, scale=0.1).bfloat16().cuda()
+    bias = rnd(N, seed=33).cuda()
+    ref = a.float().cpu() @ w.float().cpu().t() + bias.cpu()
+    out = ops.gemm(a, w, bias, epi=ops.EPI_F32, cfg=cfg)
+    assert relerr(out, ref) < 1e-5, relerr(out, ref)
+    res = rnd(M, N, seed=34).cuda(); res0 = res.clone().cpu()
+    ops.gemm(a, w, bias, out=res, res=res, epi=ops.EPI_RES_F32, cfg=cfg)
+    assert relerr(res, res0 + ref) < 1e-5
+    outb = ops.gemm(a, w, bias, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg)
+    assert relerr(outb, torch.nn.functional.gelu(ref)) < 4e-3
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 4, 5])
 def test_gemm_identity_asymmetric(cfg):
     """A = I  =>  C == W^T exactly (catches row/col swaps and fragment-layout errors bit-exactly)."""
     ops = _ops()
@@ -92,7 +110,7 @@ def test_gelu_erf_accuracy():
     assert bool(((out - ref).abs() <= ulp).all())
 
 
-@pytest.mark.parametrize("B,L,H,dh", [(2, 257, 16, 64), (3, 77, 12, 64), (2, 17, 2, 32), (1, 600, 1, 64)])
+@pytest.mark.parametrize("B,L,H,dh", [(2, 257, 16, 64), (3, 77, 12, 64), (2, 17, 2, 32), (1, 600, 1, 64), (65, 257, 16, 64)])
 @pytest.mark.parametrize("causal", [False, True])
 def test_qkv_and_attention(B, L, H, dh, causal):
     """in_proj GEMM + head split + fused attention vs explicit softmax(QK^T/sqrt(d)+mask)V in fp32 on the

@@ -20,5 +20,8 @@ cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $
 cd $GRAFT_REPO_ROOT
 find gpurun_out/prof -name "*stats*" | head; 
 for f in $(find gpurun_out/prof -name "*kernel_stats*.csv" | head -1); do head -30 $f; done
+echo "== pmc =="
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc -o gemm -- python $GRAFT_REPO_ROOT/tools/gemm_pmc.py > $GRAFT_REPO_ROOT/gpurun_out/pmc.log 2>&1
+cd $GRAFT_REPO_ROOT; ls gpurun_out/pmc | head
 # keep only the small summaries
 find gpurun_out/prof -name "*kernel_trace*" -size +20M -delete

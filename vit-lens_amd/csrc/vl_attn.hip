@@ -31,7 +31,7 @@ struct AttnP {
 };
 
 template <int DH>
-__global__ void __launch_bounds__(1024) attn_fwd_kernel(const AttnP p) {
+__global__ void __launch_bounds__(576, 5) attn_fwd_kernel(const AttnP p) {
   constexpr int RB = DH * 2;          // K row bytes in LDS
   constexpr int CH = RB / 16;         // 16-byte chunks per row
   constexpr int RSH = (DH == 64) ? 1 : 2;  // rows per 256-B bank row = 2^RSH
@@ -76,31 +76,55 @@ __global__ void __launch_bounds__(1024) attn_fwd_kernel(const AttnP p) {
   for (int kc0 = 0; kc0 < p.Lk; kc0 += KC) {
     if (p.causal && kc0 > blk_q_hi) break;   // uniform across the workgroup
     __syncthreads();
-    // ---- stage K chunk (zero rows past Lk) ----
-    for (int i = tid; i < KC * CH; i += nthr) {
-      const int row = i / CH, c = i % CH;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (kc0 + row < p.Lk) v = *(const u32x4*)(Kg + (size_t)(kc0 + row) * DH + c * 8);
-      *(u32x4*)(sK + row * RB + ((c ^ ((row >> RSH) & (CH - 1))) * 16)) = v;
-    }
-    // ---- stage V^T chunk (zero keys past Lk) ----
-    for (int i = tid; i < DH * (KC / 8); i += nthr) {
-      const int d = i / (KC / 8), kp = i % (KC / 8);
-      const int key = kc0 + kp * 8;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (key + 8 <= p.Lkp) v = *(const u32x4*)(Vg + (size_t)d * p.Lkp + key);
-      if (key + 8 > p.Lk) {  // boundary / pad piece: clear keys >= Lk (pad columns are uninitialised)
+    // ---- stage K chunk + V^T chunk: issue 4+4 independent 16-byte loads per thread, then store ----
+    // (one load->store at a time exposes the full memory latency 8x per workgroup)
+    constexpr int NPK = KC * CH, NPV = DH * (KC / 8);
+    for (int base = 0; base < NPK; base += 4 * nthr) {
+      u32x4 kv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          unsigned int w = v[e];
-          if (key + 2 * e >= p.Lk) w &= 0xffff0000u;
-          if (key + 2 * e + 1 >= p.Lk) w &= 0x0000ffffu;
-          v[e] = w;
-        }
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * nthr + tid;
+        const int row = i / CH, c = i % CH;
+        kv[u] = u32x4{0u, 0u, 0u, 0u};
+        if (i < NPK && kc0 + row < p.Lk) kv[u] = *(const u32x4*)(Kg + (size_t)(kc0 + row) * DH + c * 8);
       }
-      u32x2* dst = (u32x2*)(sV + d * VS + kp * 8);
-      u32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
-      dst[0] = lo; dst[1] = hi;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * nthr + tid;
+        const int row = i / CH, c = i % CH;
+        if (i < NPK) *(u32x4*)(sK + row * RB + ((c ^ ((row >> RSH) & (CH - 1))) * 16)) = kv[u];
+      }
+    }
+    for (int base = 0; base < NPV; base += 4 * nthr) {
+      u32x4 vv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * nthr + tid;
+        const int d = i / (KC / 8), kp = i % (KC / 8);
+        const int key = kc0 + kp * 8;
+        vv[u] = u32x4{0u, 0u, 0u, 0u};
+        if (i < NPV && key + 8 <= p.Lkp) vv[u] = *(const u32x4*)(Vg + (size_t)d * p.Lkp + key);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * nthr + tid;
+        if (i >= NPV) continue;
+        const int d = i / (KC / 8), kp = i % (KC / 8);
+        const int key = kc0 + kp * 8;
+        u32x4 v = vv[u];
+        if (key + 8 > p.Lk) {  // boundary / pad piece: clear keys >= Lk (pad columns are uninitialised)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            unsigned int w = v[e];
+            if (key + 2 * e >= p.Lk) w &= 0xffff0000u;
+            if (key + 2 * e + 1 >= p.Lk) w &= 0x0000ffffu;
+            v[e] = w;
+          }
+        }
+        u32x2* dst = (u32x2*)(sV + d * VS + kp * 8);
+        u32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+        dst[0] = lo; dst[1] = hi;
+      }
     }
     __syncthreads();
     if (!wave_active) continue;

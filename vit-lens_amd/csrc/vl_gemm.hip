@@ -40,6 +40,7 @@ struct GemmP {
   bf16_t *q, *k, *vt;
   int L, H, dh, Lp;
   float qscale;
+  int m_off;         // absolute row of local row 0 (QKV scatter of a row-split launch)
 };
 
 template <int BM, int BN>
@@ -55,6 +56,81 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int xcd = bid & 7, idx = bid >> 3;
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + idx;
+}
+
+// ---- epilogue: lane owns row m = mrow0 + 32*i + fr, columns n = ncol0 + 32*j + 8*q + 4*fg + {0..3} ----
+template <int EPI, int MT, int NTL>
+__device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL], int mrow0, int ncol0, int fr, int fg) {
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = mrow0 + i * 32 + fr;
+    if (m >= p.M) continue;
+    [[maybe_unused]] int qb = 0, ql = 0;
+    if constexpr (EPI == EPI_QKV) { const int ma = m + p.m_off; qb = ma / p.L; ql = ma - qb * p.L; }
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = ncol0 + j * 32 + q * 8 + fg * 4;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e] * p.alpha;
+        if (p.bias) {
+          const f32x4 b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += b[e];
+        }
+        if constexpr (EPI == EPI_BF16) {
+          if (p.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+          }
+          u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+          *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
+        } else if constexpr (EPI == EPI_F32) {
+          f32x4 o = {v[0], v[1], v[2], v[3]};
+          *(f32x4*)((float*)p.out + (size_t)m * p.ldo + n) = o;
+        } else if constexpr (EPI == EPI_RES_F32) {
+          const f32x4 r = *(const f32x4*)((const float*)p.res + (size_t)m * p.ldo + n);
+          f32x4 o = {v[0] + r[0], v[1] + r[1], v[2] + r[2], v[3] + r[3]};
+          *(f32x4*)((float*)p.out + (size_t)m * p.ldo + n) = o;
+        } else if constexpr (EPI == EPI_RES_BF16) {
+          const u32x2 r = *(const u32x2*)((const bf16_t*)p.res + (size_t)m * p.ldo + n);
+          v[0] += bf2f((bf16_t)(r[0] & 0xffff)); v[1] += bf2f((bf16_t)(r[0] >> 16));
+          v[2] += bf2f((bf16_t)(r[1] & 0xffff)); v[3] += bf2f((bf16_t)(r[1] >> 16));
+          u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+          *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
+        } else if constexpr (EPI == EPI_QKV) {
+          // head-dim % 8 == 0: (which, head) are wave-uniform for the 8-column group -> SALU divides
+          const int nu = ncol0 + j * 32 + q * 8;
+          const int D = p.H * p.dh;
+          const int which = nu / D;
+          const int c = nu - which * D;
+          const int h = c / p.dh, d = c - h * p.dh + fg * 4;
+          const size_t bh = (size_t)qb * p.H + h;
+          if (which == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= p.qscale;
+            u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+            *(u32x2*)(p.q + (bh * p.L + ql) * p.dh + d) = o;
+          } else if (which == 1) {
+            u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+            *(u32x2*)(p.k + (bh * p.L + ql) * p.dh + d) = o;
+          } else {
+            bf16_t* dst = p.vt + (bh * p.dh + d) * p.Lp + ql;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(size_t)e * p.Lp] = f2bf(v[e]);
+          }
+        } else if constexpr (EPI == EPI_GEGLU) {
+          // interleaved rows: (a_j, gate_j, a_j+1, gate_j+1)
+          const float o0 = v[0] * gelu_erf(v[1]);
+          const float o1 = v[2] * gelu_erf(v[3]);
+          *(unsigned int*)((bf16_t*)p.out + (size_t)m * p.ldo + (n >> 1)) = pack2bf(o0, o1);
+        }
+      }
+    }
+  }
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool DMA>
@@ -168,77 +244,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns row m = ..+fr, columns n = nb + 8*q + 4*fg + {0..3} ---------------
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = m0 + wave_m * WTM + i * 32 + fr;
-    if (m >= p.M) continue;
-    [[maybe_unused]] int qb = 0, ql = 0;
-    if constexpr (EPI == EPI_QKV) { qb = m / p.L; ql = m - qb * p.L; }
-#pragma unroll
-    for (int j = 0; j < NTL; ++j) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wave_n * WTN + j * 32 + q * 8 + fg * 4;
-        if (n >= p.N) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e] * p.alpha;
-        if (p.bias) {
-          const f32x4 b = *(const f32x4*)(p.bias + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += b[e];
-        }
-        if constexpr (EPI == EPI_BF16) {
-          if (p.act == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-          }
-          u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-          *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
-        } else if constexpr (EPI == EPI_F32) {
-          f32x4 o = {v[0], v[1], v[2], v[3]};
-          *(f32x4*)((float*)p.out + (size_t)m * p.ldo + n) = o;
-        } else if constexpr (EPI == EPI_RES_F32) {
-          const f32x4 r = *(const f32x4*)((const float*)p.res + (size_t)m * p.ldo + n);
-          f32x4 o = {v[0] + r[0], v[1] + r[1], v[2] + r[2], v[3] + r[3]};
-          *(f32x4*)((float*)p.out + (size_t)m * p.ldo + n) = o;
-        } else if constexpr (EPI == EPI_RES_BF16) {
-          const u32x2 r = *(const u32x2*)((const bf16_t*)p.res + (size_t)m * p.ldo + n);
-          v[0] += bf2f((bf16_t)(r[0] & 0xffff)); v[1] += bf2f((bf16_t)(r[0] >> 16));
-          v[2] += bf2f((bf16_t)(r[1] & 0xffff)); v[3] += bf2f((bf16_t)(r[1] >> 16));
-          u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-          *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
-        } else if constexpr (EPI == EPI_QKV) {
-          // head-dim % 8 == 0: (which, head) are wave-uniform for the 8-column group -> SALU divides
-          const int nu = n0 + wave_n * WTN + j * 32 + q * 8;
-          const int D = p.H * p.dh;
-          const int which = nu / D;
-          const int c = nu - which * D;
-          const int h = c / p.dh, d = c - h * p.dh + fg * 4;
-          const size_t bh = (size_t)qb * p.H + h;
-          if (which == 0) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= p.qscale;
-            u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-            *(u32x2*)(p.q + (bh * p.L + ql) * p.dh + d) = o;
-          } else if (which == 1) {
-            u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-            *(u32x2*)(p.k + (bh * p.L + ql) * p.dh + d) = o;
-          } else {
-            bf16_t* dst = p.vt + (bh * p.dh + d) * p.Lp + ql;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) dst[(size_t)e * p.Lp] = f2bf(v[e]);
-          }
-        } else if constexpr (EPI == EPI_GEGLU) {
-          // interleaved rows: (a_j, gate_j, a_j+1, gate_j+1)
-          const float o0 = v[0] * gelu_erf(v[1]);
-          const float o1 = v[2] * gelu_erf(v[3]);
-          *(unsigned int*)((bf16_t*)p.out + (size_t)m * p.ldo + (n >> 1)) = pack2bf(o0, o1);
-        }
-      }
-    }
-  }
+  store_tile<EPI, MT, NTL>(p, acc, m0 + wave_m * WTM, n0 + wave_n * WTN, fr, fg);
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, bool DMA>
@@ -257,9 +263,345 @@ hipError_t launch(const GemmP& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Persistent variant: one workgroup per CU walks its list of output tiles; the (tile, k-step)
+// sequence is flattened so the LDS-DMA of step s+1 -- including the FIRST k-slab of the next tile
+// -- is always in flight while step s computes and while a finished tile is being stored.
+// MFMA operand fragments are double-buffered in registers across the four 16-wide k-substeps.
+// Tile order: groups of GN consecutive N-tiles, M fastest inside a group, and each XCD owns a
+// contiguous run of G/8 tiles per round -> the 4 weight slabs of a group stay resident in that
+// XCD's L2 across rounds while activation tiles stream through once per group.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+__global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
+    gemm_nt_persist_kernel(const GemmP p) {
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int MT = WTM / 32, NTL = WTN / 32;
+  constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW);
+  constexpr int GN = 4;
+  using S = Smem<BM, BN>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int ntiles = tiles_m * tiles_n;
+  const int G = gridDim.x;                                   // multiple of 8
+  const int slot = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  if (slot >= ntiles) return;
+  const int my_tiles = (ntiles - slot + G - 1) / G;
+  const int nk = p.K >> 6;
+  const int total = my_tiles * nk;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wid % WAVES_M, wave_n = wid / WAVES_M;
+  const int srow = lane >> 3, pch = lane & 7;
+  const int fr = lane & 31, fg = lane >> 5;
+  const int fsw = (fr >> 1) & 7;
+
+  auto tile_origin = [&](int ti, int& m0, int& n0) {
+    const int v = ti * G + slot;
+    const int gsz = GN * tiles_m;
+    const int gid = v / gsz, rem = v - gid * gsz;
+    const int first_n = gid * GN;
+    const int gn = min(tiles_n - first_n, GN);
+    const int tm = rem / gn;
+    m0 = tm * BM; n0 = (first_n + (rem - tm * gn)) * BN;
+  };
+
+  const bf16_t* gA[AI]; const bf16_t* gB[BI];
+  auto set_sources = [&](int m0, int n0) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int row = (i * NW + wid) * 8 + srow;
+      int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
+      gA[i] = p.A + (size_t)gm * p.lda + (pch ^ ((row >> 1) & 7)) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int row = (i * NW + wid) * 8 + srow;
+      int gn_ = n0 + row; gn_ = gn_ < p.N ? gn_ : p.N - 1;
+      gB[i] = p.W + (size_t)gn_ * p.ldw + (pch ^ ((row >> 1) & 7)) * 8;
+    }
+  };
+  auto stage_dma = [&](int kt, int buf) {
+    unsigned char* sA = smem + buf * S::STAGE;
+    unsigned char* sB = sA + S::A_BYTES;
+    const int k0 = kt << 6;
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA[i] + k0),
+                                       (__attribute__((address_space(3))) void*)(sA + (i * NW + wid) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB[i] + k0),
+                                       (__attribute__((address_space(3))) void*)(sB + (i * NW + wid) * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[MT][NTL];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int cur_m0, cur_n0;
+  tile_origin(0, cur_m0, cur_n0);
+  set_sources(cur_m0, cur_n0);
+  stage_dma(0, 0);
+  __syncthreads();
+
+  int kt = 0, ti = 0;
+  for (int s = 0; s < total; ++s) {
+    const int buf = s & 1;
+    // ---- issue the DMA of step s+1 (possibly the first k-slab of the next tile) ----
+    if (s + 1 < total) {
+      if (kt + 1 == nk) {
+        int nm0, nn0;
+        tile_origin(ti + 1, nm0, nn0);
+        set_sources(nm0, nn0);
+        stage_dma(0, buf ^ 1);
+      } else {
+        stage_dma(kt + 1, buf ^ 1);
+      }
+    }
+    // ---- 4 k-substeps with register double-buffered fragments ----
+    const unsigned char* sA = smem + buf * S::STAGE + (wave_m * WTM + fr) * 128;
+    const unsigned char* sB = smem + buf * S::STAGE + S::A_BYTES + (wave_n * WTN + fr) * 128;
+    bf16x8 af[2][MT], wf[2][NTL];
+    {
+      const int off = ((0 * 2 + fg) ^ fsw) * 16;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[0][i] = *(const bf16x8*)(sA + i * 32 * 128 + off);
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) wf[0][j] = *(const bf16x8*)(sB + j * 32 * 128 + off);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int c = kk & 1;
+      if (kk < 3) {
+        const int off = (((kk + 1) * 2 + fg) ^ fsw) * 16;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[c ^ 1][i] = *(const bf16x8*)(sA + i * 32 * 128 + off);
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) wf[c ^ 1][j] = *(const bf16x8*)(sB + j * 32 * 128 + off);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][j], af[c][i], acc[i][j], 0, 0, 0);
+    }
+    // ---- tile finished: store and reset (the next tile's first slab is already in flight) ----
+    if (kt + 1 == nk) {
+      store_tile<EPI, MT, NTL>(p, acc, cur_m0 + wave_m * WTM, cur_n0 + wave_n * WTN, fr, fg);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      kt = 0; ++ti;
+      if (s + 1 < total) tile_origin(ti, cur_m0, cur_n0);
+    } else {
+      ++kt;
+    }
+    __syncthreads();
+  }
+}
+
+
+// Persistent kernel, hand-scheduled k-step: the 8 LDS-DMA instructions of the next step and the 6
+// fragment reads of the next 16-wide k-substep are issued ahead of the MFMAs of the current
+// substep (sched_barrier fences pin the phases), so neither DMA issue cost nor ds_read latency sits
+// in front of the matrix pipe.  The k-step body is one branch-free basic block: source pointers of
+// the step after next are prepared at the end of the previous step, and the last step of a
+// workgroup re-issues a harmless reload instead of branching around the DMA.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+__global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
+    gemm_nt_persist2_kernel(const GemmP p) {
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int MT = WTM / 32, NTL = WTN / 32;
+  constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW);
+  static_assert(AI == 4 && BI == 4 && MT == 4 && NTL == 2, "schedule written for the 256x256 / 8-wave tile");
+  constexpr int GN = 4;
+  using S = Smem<BM, BN>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int ntiles = tiles_m * tiles_n;
+  const int G = gridDim.x;
+  const int slot = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  if (slot >= ntiles) return;
+  const int my_tiles = (ntiles - slot + G - 1) / G;
+  const int nk = p.K >> 6;
+  const int total = my_tiles * nk;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wid % WAVES_M, wave_n = wid / WAVES_M;
+  const int srow = lane >> 3, pch = lane & 7;
+  const int fr = lane & 31, fg = lane >> 5;
+  const int fsw = (fr >> 1) & 7;
+
+  auto tile_origin = [&](int ti, int& m0, int& n0) {
+    const int v = ti * G + slot;
+    const int gsz = GN * tiles_m;
+    const int gid = v / gsz, rem = v - gid * gsz;
+    const int first_n = gid * GN;
+    const int gn = min(tiles_n - first_n, GN);
+    const int tm = rem / gn;
+    m0 = tm * BM; n0 = (first_n + (rem - tm * gn)) * BN;
+  };
+  // src[0..3] = A row groups, src[4..7] = W row groups; pointers already include the k offset
+  const bf16_t* src[8];
+  auto set_sources = [&](int m0, int n0, int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (i * NW + wid) * 8 + srow;
+      const int sw = (pch ^ ((row >> 1) & 7)) * 8;
+      int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
+      int gn_ = n0 + row; gn_ = gn_ < p.N ? gn_ : p.N - 1;
+      src[i] = p.A + (size_t)gm * p.lda + sw + k0;
+      src[4 + i] = p.W + (size_t)gn_ * p.ldw + sw + k0;
+    }
+  };
+  auto dma = [&](int i, unsigned char* stage_base) {
+    unsigned char* dst = stage_base + (i < 4 ? 0 : S::A_BYTES) + ((i & 3) * NW + wid) * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+
+  f32x16 acc[MT][NTL];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int cur_m0, cur_n0, nxt_m0, nxt_n0;
+  tile_origin(0, cur_m0, cur_n0);
+  nxt_m0 = cur_m0; nxt_n0 = cur_n0;
+  set_sources(cur_m0, cur_n0, 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma(i, smem);
+  // sources for the DMA issued during step 0 (= data of step 1)
+  int kt = 0, ti = 0;          // position of the step being computed
+  int lkt = 0, lti = 0;        // position of the step whose data the in-loop DMA loads (s+1)
+  auto advance_load = [&]() {
+    ++lkt;
+    if (lkt == nk) { lkt = 0; ++lti; if (lti < my_tiles) tile_origin(lti, nxt_m0, nxt_n0); else { lti = my_tiles - 1; } }
+    set_sources(nxt_m0, nxt_n0, lkt << 6);
+  };
+  advance_load();
+  __syncthreads();
+
+  for (int s = 0; s < total; ++s) {
+    unsigned char* cur = smem + (s & 1) * S::STAGE;
+    unsigned char* oth = smem + ((s & 1) ^ 1) * S::STAGE;
+    const unsigned char* sA = cur + (wave_m * WTM + fr) * 128;
+    const unsigned char* sB = cur + S::A_BYTES + (wave_n * WTN + fr) * 128;
+    bf16x8 af[2][MT], wf[2][NTL];
+    auto ldfrag = [&](int kk, int c) {
+      const int off = ((kk * 2 + fg) ^ fsw) * 16;
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) wf[c][j] = *(const bf16x8*)(sB + j * 32 * 128 + off);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[c][i] = *(const bf16x8*)(sA + i * 32 * 128 + off);
+    };
+    auto mma = [&](int c) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][j], af[c][i], acc[i][j], 0, 0, 0);
+    };
+    // phase fences: nothing moves across, so each phase ISSUES the next phase's fragment reads (and
+    // half of the next step's DMA) ahead of its own MFMAs and the waits land one phase later.
+    ldfrag(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    dma(0, oth); dma(1, oth); dma(2, oth); dma(3, oth);
+    ldfrag(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0);
+    __builtin_amdgcn_sched_barrier(0);
+    dma(4, oth); dma(5, oth); dma(6, oth); dma(7, oth);
+    ldfrag(2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1);
+    __builtin_amdgcn_sched_barrier(0);
+    ldfrag(3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1);
+    __builtin_amdgcn_sched_barrier(0);
+
+    if (kt + 1 == nk) {
+      store_tile<EPI, MT, NTL>(p, acc, cur_m0 + wave_m * WTM, cur_n0 + wave_n * WTN, fr, fg);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      kt = 0; ++ti;
+      if (ti < my_tiles) tile_origin(ti, cur_m0, cur_n0);
+    } else {
+      ++kt;
+    }
+    advance_load();     // pointers for the DMA of the next iteration (data of step s+2)
+    __syncthreads();
+  }
+}
+
+static int g_num_cus = 0;
+static int num_cus() {
+  if (g_num_cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    g_num_cus = n;
+  }
+  return g_num_cus;
+}
+
+static int g_persist_variant = 2;   // 1 = plain persistent loop, 2 = hand-scheduled k-step
+extern "C" int vl_gemm_set_persist_variant(int v) { g_persist_variant = (v == 1) ? 1 : 2; return 0; }
+
+template <int EPI, int VAR>
+hipError_t launch_persist_v(const GemmP& p, hipStream_t s) {
+  using S = Smem<256, 256>;
+  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  auto kern = (VAR == 1) ? gemm_nt_persist_kernel<256, 256, 2, 4, EPI> : gemm_nt_persist2_kernel<256, 256, 2, 4, EPI>;
+  constexpr int smem = 2 * S::STAGE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  int G = num_cus() & ~7;
+  if (tiles < G) G = (tiles + 7) & ~7;
+  hipLaunchKernelGGL(kern, dim3(G), dim3(512), smem, s, p);
+  return hipGetLastError();
+}
+template <int EPI>
+hipError_t launch_persist(const GemmP& p, hipStream_t s) {
+  return g_persist_variant == 1 ? launch_persist_v<EPI, 1>(p, s) : launch_persist_v<EPI, 2>(p, s);
+}
+
 template <int EPI>
 hipError_t dispatch(const GemmP& p, int cfg, hipStream_t s) {
   // cfg bit0: 0 = 256x256 tile (8 waves), 1 = 128x128 tile (4 waves); bit1: 1 = register staging
+  if (cfg == 4) return launch_persist_v<EPI, 1>(p, s);
+  if (cfg == 5) return launch_persist_v<EPI, 2>(p, s);
   switch (cfg & 3) {
     case 0: return launch<256, 256, 2, 4, EPI, true>(p, s);
     case 1: return launch<128, 128, 2, 2, EPI, true>(p, s);
@@ -272,11 +614,32 @@ hipError_t dispatch(const GemmP& p, int cfg, hipStream_t s) {
 
 extern "C" int vl_set_error(const char* msg);
 
-static int auto_cfg(int M, int N, int cfg) {
-  if (cfg >= 0) return cfg;
-  // big tiles only when they still fill the chip a few times over
-  const long big_tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
-  return big_tiles >= 512 ? 0 : 1;
+static int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+// cfg >= 0: run exactly that kernel configuration.
+// cfg == -1 (auto): problems smaller than one wave of 256x256 tiles use 128x128 tiles; larger ones run
+// the persistent 256x256 kernel on the largest row range whose tile count is a multiple of the CU count
+// (every CU gets the same number of tiles -> no tail round) and the few remaining rows on 128x128 tiles.
+template <int EPI>
+static hipError_t run_gemm(const GemmP& p, int cfg, hipStream_t s) {
+  if (cfg >= 0) return dispatch<EPI>(p, cfg, s);
+  const int G = num_cus() & ~7;
+  const int tiles_n = (p.N + 255) / 256, full_m = p.M / 256;
+  if ((long)full_m * tiles_n < G) return dispatch<EPI>(p, 1, s);
+  const int step = G / gcd_i(G, tiles_n);
+  const int main_m = (full_m / step) * step;
+  if (main_m == 0) return dispatch<EPI>(p, 4, s);
+  const int rows_main = main_m * 256;
+  GemmP pm = p; pm.M = rows_main;
+  hipError_t e = launch_persist<EPI>(pm, s);
+  if (e != hipSuccess || rows_main == p.M) return e;
+  GemmP pr = p;
+  pr.M = p.M - rows_main; pr.m_off = p.m_off + rows_main;
+  pr.A = p.A + (size_t)rows_main * p.lda;
+  constexpr size_t osz = (EPI == EPI_F32 || EPI == EPI_RES_F32) ? 4 : 2;
+  if (p.out) pr.out = (unsigned char*)p.out + (size_t)rows_main * p.ldo * osz;
+  if (p.res) pr.res = (const unsigned char*)p.res + (size_t)rows_main * p.ldo * osz;
+  return dispatch<EPI>(pr, 1, s);
 }
 
 #define VL_CHECK_ARG(c, msg) do { if (!(c)) return vl_set_error(msg); } while (0)
@@ -292,14 +655,13 @@ extern "C" int vl_gemm_bf16(const void* A, const void* W, const float* bias, voi
   GemmP p{};
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = bias; p.out = out; p.res = res;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.alpha = alpha; p.act = act;
-  cfg = auto_cfg(M, N, cfg);
   hipError_t e;
   switch (epi) {
-    case VL_EPI_BF16: e = dispatch<EPI_BF16>(p, cfg, stream); break;
-    case VL_EPI_F32: e = dispatch<EPI_F32>(p, cfg, stream); break;
-    case VL_EPI_RES_F32: VL_CHECK_ARG(res, "vl_gemm_bf16: residual missing"); e = dispatch<EPI_RES_F32>(p, cfg, stream); break;
-    case VL_EPI_RES_BF16: VL_CHECK_ARG(res, "vl_gemm_bf16: residual missing"); e = dispatch<EPI_RES_BF16>(p, cfg, stream); break;
-    case VL_EPI_GEGLU: e = dispatch<EPI_GEGLU>(p, cfg, stream); break;
+    case VL_EPI_BF16: e = run_gemm<EPI_BF16>(p, cfg, stream); break;
+    case VL_EPI_F32: e = run_gemm<EPI_F32>(p, cfg, stream); break;
+    case VL_EPI_RES_F32: VL_CHECK_ARG(res, "vl_gemm_bf16: residual missing"); e = run_gemm<EPI_RES_F32>(p, cfg, stream); break;
+    case VL_EPI_RES_BF16: VL_CHECK_ARG(res, "vl_gemm_bf16: residual missing"); e = run_gemm<EPI_RES_BF16>(p, cfg, stream); break;
+    case VL_EPI_GEGLU: e = run_gemm<EPI_GEGLU>(p, cfg, stream); break;
     default: return vl_set_error("vl_gemm_bf16: unknown epilogue");
   }
   if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
@@ -317,8 +679,7 @@ extern "C" int vl_gemm_qkv_bf16(const void* A, const void* W, const float* bias,
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = bias;
   p.M = B * L; p.N = 3 * H * dh; p.K = K; p.lda = lda; p.ldw = K; p.ldo = 0; p.alpha = 1.f;
   p.q = (bf16_t*)q; p.k = (bf16_t*)k; p.vt = (bf16_t*)vt; p.L = L; p.H = H; p.dh = dh; p.Lp = Lp; p.qscale = qscale;
-  cfg = auto_cfg(p.M, p.N, cfg);
-  hipError_t e = dispatch<EPI_QKV>(p, cfg, stream);
+  hipError_t e = run_gemm<EPI_QKV>(p, cfg, stream);
   if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
   return 0;
 }
