@@ -54,12 +54,15 @@ int vl_gemm_bf16(const void* A, const void* W, const float* bias, void* out, con
                  int cfg, hipStream_t stream);
 
 /* Packed in-projection of nn.MultiheadAttention (transformer.py:215,252) with the head split
- * fused into the epilogue: A[B*L,K] · Win[3*H*dh,K]^T + bias ->
+ * fused into the epilogue: A[B*L,K] · Win[count*H*dh,K]^T + bias ->
  *   q [B,H,L,dh] (pre-multiplied by qscale), k [B,H,L,dh], vt [B,H,dh,Lp] (V transposed,
- *   key index contiguous, rows padded to Lp >= L; pad columns are never written). dh % 8 == 0. */
+ *   key index contiguous, rows padded to Lp >= L; pad columns are never written). dh % 8 == 0.
+ * (first,count) select which of (q,k,v) the rows of Win produce: (0,3) packed in_proj_weight /
+ * [to_q;to_kv]; (0,1) Perceiver to_q; (1,2) Perceiver to_kv (perceiver.py:115-116,124-126). */
 int vl_gemm_qkv_bf16(const void* A, const void* Win, const float* bias, void* q, void* k, void* vt,
-                     int B, int L, int H, int dh, int Lp, int K, int lda, float qscale, int cfg,
-                     hipStream_t stream);
+                     int B, int L, int H, int dh, int Lp, int K, int lda, float qscale, int first,
+                     int count, int cfg, hipStream_t stream);
+int vl_gemm_set_persist_variant(int v);
 
 int vl_device_info(int device, char* arch, int arch_len, int* cus, int* clock_khz, long* hbm_bytes);
 

@@ -30,7 +30,7 @@ TINY = {
 
 def tiny_args(modality):
     common = dict(perceiver_num_latents=16, perceiver_latent_dim=64, perceiver_latent_heads=2,
-                  perceiver_latent_dim_head=32, perceiver_cross_dim_head=32, perceiver_cross_heads=1)
+                  perceiver_latent_dim_head=32, perceiver_cross_dim_head=64, perceiver_cross_heads=1)
     if modality == "depth":
         return ref_loader.lens_args("depth", **common)
     if modality == "audio":
@@ -38,7 +38,7 @@ def tiny_args(modality):
                                     audio_fstride=6, audio_tstride=6, perceiver_input_chan=64,
                                     perceiver_depth=2, perceiver_self_per_cross_attn=2, **common)
     if modality == "pc":
-        return ref_loader.lens_args("pc", pc_num_group=16, pc_group_size=8, pc_encoder_dims=32,
+        return ref_loader.lens_args("pc", pc_num_group=16, pc_group_size=8, pc_encoder_dims=64,
                                     pc_trans_dim=64, pc_npoints=256, perceiver_input_chan=64,
                                     perceiver_depth=2, perceiver_self_per_cross_attn=1,
                                     pc_tokenizer="pointbert", pc_in_channel=3, pc_radius=0.2, **common)

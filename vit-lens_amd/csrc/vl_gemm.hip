@@ -39,6 +39,7 @@ struct GemmP {
   // QKV scatter
   bf16_t *q, *k, *vt;
   int L, H, dh, Lp;
+  int which0;        // first part produced by this GEMM: 0 = q, 1 = k, 2 = v
   float qscale;
   int m_off;         // absolute row of local row 0 (QKV scatter of a row-split launch)
 };
@@ -105,8 +106,9 @@ __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL
           // head-dim % 8 == 0: (which, head) are wave-uniform for the 8-column group -> SALU divides
           const int nu = ncol0 + j * 32 + q * 8;
           const int D = p.H * p.dh;
-          const int which = nu / D;
-          const int c = nu - which * D;
+          const int wq = nu / D;
+          const int c = nu - wq * D;
+          const int which = wq + p.which0;
           const int h = c / p.dh, d = c - h * p.dh + fg * 4;
           const size_t bh = (size_t)qb * p.H + h;
           if (which == 0) {
@@ -669,15 +671,16 @@ extern "C" int vl_gemm_bf16(const void* A, const void* W, const float* bias, voi
 }
 
 extern "C" int vl_gemm_qkv_bf16(const void* A, const void* W, const float* bias, void* q, void* k, void* vt,
-                                int B, int L, int H, int dh, int Lp, int K, int lda, float qscale, int cfg,
-                                hipStream_t stream) {
+                                int B, int L, int H, int dh, int Lp, int K, int lda, float qscale, int first,
+                                int count, int cfg, hipStream_t stream) {
+  VL_CHECK_ARG(first >= 0 && count >= 1 && first + count <= 3, "vl_gemm_qkv_bf16: bad (first, count)");
   VL_CHECK_ARG(B > 0 && L > 0 && H > 0, "vl_gemm_qkv_bf16: empty problem");
   VL_CHECK_ARG((K & 63) == 0, "vl_gemm_qkv_bf16: K must be a multiple of 64");
   VL_CHECK_ARG((dh & 7) == 0, "vl_gemm_qkv_bf16: head dim must be a multiple of 8");
   VL_CHECK_ARG(Lp >= L, "vl_gemm_qkv_bf16: Lp < L");
   GemmP p{};
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = bias;
-  p.M = B * L; p.N = 3 * H * dh; p.K = K; p.lda = lda; p.ldw = K; p.ldo = 0; p.alpha = 1.f;
+  p.M = B * L; p.N = count * H * dh; p.K = K; p.which0 = first; p.lda = lda; p.ldw = K; p.ldo = 0; p.alpha = 1.f;
   p.q = (bf16_t*)q; p.k = (bf16_t*)k; p.vt = (bf16_t*)vt; p.L = L; p.H = H; p.dh = dh; p.Lp = Lp; p.qscale = qscale;
   hipError_t e = run_gemm<EPI_QKV>(p, cfg, stream);
   if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));

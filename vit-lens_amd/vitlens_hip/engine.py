@@ -177,3 +177,183 @@ class TextEngine:
         ops.layernorm(ws.x, self.ln_final[0], self.ln_final[1], pooled, B, D, x_row_stride=D, row_index=eot, row_mul=L)
         f = ops.gemm(pooled, self.projT, None, epi=ops.EPI_F32, cfg=self.gemm_cfg)
         return ops.l2_normalize(f) if normalize else f
+
+
+# ------------------------------------------------------------------------------------------------
+# The "Lens": modality tokenizer + Perceiver resampler in front of the frozen ViT
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class LensCfg:
+    """Mirror of the exp_args fields VisionTransformer.forward reads (module_cfg.py:37-92)."""
+    modality: str = "depth"            # depth | audio | pc | image
+    perceiver_identity: bool = True    # perceiver.py:370-371
+    depth: int = 2
+    self_per_cross: int = 3
+    num_latents: int = 256
+    latent_dim: int = 1024
+    input_chan: int = 1024
+    cross_heads: int = 1
+    cross_dim_head: int = 64
+    latent_heads: int = 16
+    latent_dim_head: int = 64
+    audio_fstride: int = 10
+    audio_tstride: int = 10
+    audio_mel_bins: int = 128
+    audio_target_length: int = 512
+    pc_num_group: int = 512
+    pc_group_size: int = 32
+    pc_encoder_dims: int = 256
+    pc_trans_dim: int = 384
+    use_orig_pos: bool = True
+    disable_adapter_pos: bool = False
+
+
+def _interleave_geglu(w: torch.Tensor, b: torch.Tensor):
+    """Linear(D, 8D) rows [a(0..4D) ; gate(4D..8D)] -> interleaved (a_j, gate_j) so the GEGLU epilogue
+    finds both halves of a pair in one lane (perceiver.py:85-89 `x, gates = x.chunk(2, dim=-1)`)."""
+    half = w.shape[0] // 2
+    wi = torch.stack([w[:half], w[half:]], dim=1).reshape(w.shape[0], w.shape[1])
+    bi = torch.stack([b[:half], b[half:]], dim=1).reshape(-1)
+    return wi, bi
+
+
+def prep_lens_attn(sd, p, device, packed_self: bool):
+    bf = torch.bfloat16
+    d = {"to_out_w": _dev(sd[p + "to_out.weight"], device, bf), "to_out_b": _dev(sd[p + "to_out.bias"], device)}
+    if packed_self:
+        d["qkv_w"] = _dev(torch.cat([sd[p + "to_q.weight"], sd[p + "to_kv.weight"]], 0), device, bf)
+    else:
+        d["q_w"] = _dev(sd[p + "to_q.weight"], device, bf)
+        d["kv_w"] = _dev(sd[p + "to_kv.weight"], device, bf)
+    return d
+
+
+def prep_lens_ff(sd, p, device):
+    w0, b0 = _interleave_geglu(sd[p + "net.0.weight"].detach().float(), sd[p + "net.0.bias"].detach().float())
+    return {"w0": _dev(w0, device, torch.bfloat16), "b0": _dev(b0, device),
+            "w2": _dev(sd[p + "net.2.weight"], device, torch.bfloat16), "b2": _dev(sd[p + "net.2.bias"], device)}
+
+
+class PerceiverEngine:
+    """Perceiver.forward(return_embeddings=True) (open_clip/perceiver.py:289-328), fourier_encode_data=False."""
+
+    def __init__(self, sd, prefix: str, cfg: LensCfg, device, gemm_cfg=-1):
+        self.cfg, self.device, self.gemm_cfg = cfg, torch.device(device), gemm_cfg
+        self.latents = _dev(sd[prefix + "latents"], device)
+        ln = lambda q: (_dev(sd[q + ".weight"], device), _dev(sd[q + ".bias"], device))
+        self.layers = []
+        for i in range(cfg.depth):
+            q = f"{prefix}layers.{i}."
+            lay = {"x_norm": ln(q + "0.norm"), "x_norm_ctx": ln(q + "0.norm_context"),
+                   "x_attn": prep_lens_attn(sd, q + "0.fn.", device, False),
+                   "x_ff_norm": ln(q + "1.norm"), "x_ff": prep_lens_ff(sd, q + "1.fn.", device), "selfs": []}
+            for j in range(cfg.self_per_cross):
+                r = f"{q}2.{j}."
+                lay["selfs"].append({"norm": ln(r + "0.norm"), "attn": prep_lens_attn(sd, r + "0.fn.", device, True),
+                                     "ff_norm": ln(r + "1.norm"), "ff": prep_lens_ff(sd, r + "1.fn.", device)})
+            self.layers.append(lay)
+        self._ws = {}
+
+    def _workspace(self, B, Tc):
+        key = (B, Tc)
+        if key in self._ws:
+            return self._ws[key]
+        c, dev, bf = self.cfg, self.device, torch.bfloat16
+        n, D = c.num_latents, c.latent_dim
+        f = lambda *s, dt=bf: torch.empty(*s, device=dev, dtype=dt)
+        ws = {
+            "x": f(B * n, D, dt=torch.float32), "h": f(B * n, D), "ctx": f(B * Tc, c.input_chan),
+            "xq": f(B, c.cross_heads, n, c.cross_dim_head), "xk": f(B, c.cross_heads, Tc, c.cross_dim_head),
+            "xvt": torch.zeros(B, c.cross_heads, c.cross_dim_head, (Tc + 7) // 8 * 8, device=dev, dtype=bf),
+            "xa": f(B * n, c.cross_heads * c.cross_dim_head),
+            "sq": f(B, c.latent_heads, n, c.latent_dim_head), "sk": f(B, c.latent_heads, n, c.latent_dim_head),
+            "svt": torch.zeros(B, c.latent_heads, c.latent_dim_head, (n + 7) // 8 * 8, device=dev, dtype=bf),
+            "sa": f(B * n, c.latent_heads * c.latent_dim_head), "hid": f(B * n, 4 * D),
+        }
+        self._ws[key] = ws
+        return ws
+
+    def _ff(self, ws, norm, ff, rows, D):
+        ops.layernorm(ws["x"], norm[0], norm[1], ws["h"], rows, D)
+        ops.gemm(ws["h"], ff["w0"], ff["b0"], out=ws["hid"], epi=ops.EPI_GEGLU, cfg=self.gemm_cfg)
+        ops.gemm(ws["hid"], ff["w2"], ff["b2"], out=ws["x"], res=ws["x"], epi=ops.EPI_RES_F32, cfg=self.gemm_cfg)
+
+    def forward(self, data: torch.Tensor, B: int) -> torch.Tensor:
+        """data [B*Tc, C] (bf16|f32) -> latents [B*n, D] f32 (view of an internal workspace)."""
+        c = self.cfg
+        Tc, n, D = data.shape[0] // B, c.num_latents, c.latent_dim
+        ws = self._workspace(B, Tc)
+        ws["x"].view(B, n, D).copy_(self.latents)          # repeat(latents, 'n d -> b n d')
+        rows = B * n
+        for lay in self.layers:
+            a = lay["x_attn"]
+            ops.layernorm(ws["x"], lay["x_norm"][0], lay["x_norm"][1], ws["h"], rows, D)
+            ops.layernorm(data, lay["x_norm_ctx"][0], lay["x_norm_ctx"][1], ws["ctx"], B * Tc, c.input_chan)
+            ops.gemm_qkv(ws["h"], a["q_w"], None, ws["xq"], None, None, B, n, c.cross_heads, c.cross_dim_head,
+                         first=0, count=1, cfg=self.gemm_cfg)
+            ops.gemm_qkv(ws["ctx"], a["kv_w"], None, None, ws["xk"], ws["xvt"], B, Tc, c.cross_heads, c.cross_dim_head,
+                         first=1, count=2, cfg=self.gemm_cfg)
+            ops.attn_fwd(ws["xq"], ws["xk"], ws["xvt"], ws["xa"])
+            ops.gemm(ws["xa"], a["to_out_w"], a["to_out_b"], out=ws["x"], res=ws["x"], epi=ops.EPI_RES_F32, cfg=self.gemm_cfg)
+            self._ff(ws, lay["x_ff_norm"], lay["x_ff"], rows, D)
+            for sl in lay["selfs"]:
+                a = sl["attn"]
+                ops.layernorm(ws["x"], sl["norm"][0], sl["norm"][1], ws["h"], rows, D)
+                ops.gemm_qkv(ws["h"], a["qkv_w"], None, ws["sq"], ws["sk"], ws["svt"], B, n, c.latent_heads,
+                             c.latent_dim_head, cfg=self.gemm_cfg)
+                ops.attn_fwd(ws["sq"], ws["sk"], ws["svt"], ws["sa"])
+                ops.gemm(ws["sa"], a["to_out_w"], a["to_out_b"], out=ws["x"], res=ws["x"], epi=ops.EPI_RES_F32, cfg=self.gemm_cfg)
+                self._ff(ws, sl["ff_norm"], sl["ff"], rows, D)
+        return ws["x"]
+
+
+class LensEngine:
+    """`visual.` tower of TriCLIP for a non-image modality: visual_adapter -> (+pos) -> Perceiver -> ViT trunk
+    (VisionTransformer.forward, open_clip/transformer.py:723-792)."""
+
+    def __init__(self, sd, prefix: str, tower: TowerCfg, lens: LensCfg, device, res_dtype=torch.float32, gemm_cfg=-1):
+        self.tower, self.lens, self.device, self.gemm_cfg = tower, lens, torch.device(device), gemm_cfg
+        self.vit = VitEngine(sd, prefix, tower, device, res_dtype=res_dtype, gemm_cfg=gemm_cfg)
+        a = prefix + "visual_adapter."
+        self.adapter_pos = None
+        if lens.modality in ("depth", "audio"):
+            self.conv_w = conv_weight_as_gemm(sd[a + "conv1.weight"], device)
+            pos = sd[a + "pos_emb"].detach().float()
+            self.adapter_pos = _dev(pos * (0.0 if lens.disable_adapter_pos else 1.0), device)
+        elif lens.modality == "pc":
+            from .points import PointTokenizerEngine
+            self.points = PointTokenizerEngine(sd, a, lens, device, gemm_cfg=gemm_cfg)
+        else:
+            raise NotImplementedError(lens.modality)
+        self.perceiver = None if lens.perceiver_identity else PerceiverEngine(sd, prefix + "perceiver.", lens, device, gemm_cfg)
+
+    def tokens(self, x: torch.Tensor):
+        """-> (tokens [B*T, C] bf16, pos table [T, C] f32 or per-sample pos [B*T, C], B)."""
+        L = self.lens
+        p = self.tower.patch
+        if L.modality == "depth":       # DepthTokenizer.py:35-60
+            cols, gh, gw = ops.im2col(x.contiguous().float(), p, p, p, p, self.conv_w.shape[1])
+            return ops.gemm(cols, self.conv_w, None, epi=ops.EPI_BF16, cfg=self.gemm_cfg), self.adapter_pos
+        if L.modality == "audio":       # AST_tokenizer.py:44-57: [N,T,F] -> conv over [N,1,F,T]
+            cols, gh, gw = ops.im2col(x.contiguous().float().unsqueeze(1), p, p, L.audio_fstride, L.audio_tstride,
+                                      self.conv_w.shape[1], transpose_hw=True)
+            return ops.gemm(cols, self.conv_w, None, epi=ops.EPI_BF16, cfg=self.gemm_cfg), self.adapter_pos
+        raise NotImplementedError(L.modality)
+
+    def encode(self, x: torch.Tensor, normalize: bool = False, **kw) -> torch.Tensor:
+        B = x.shape[0]
+        if self.lens.modality == "pc":
+            tok = self.points.forward(x, **kw)                 # already x + pos, [B*G, C] bf16
+            lat = self.perceiver.forward(tok, B)
+            f = self.vit.trunk(lat, B, use_orig_pos=self.lens.use_orig_pos)
+        else:
+            tok, pos = self.tokens(x)
+            if self.perceiver is None:
+                f = self.vit.trunk(tok, B, pos2=pos, use_orig_pos=self.lens.use_orig_pos)
+            else:
+                T = tok.shape[0] // B
+                xin = torch.empty_like(tok)
+                ops.add_rows(tok, pos, xin, tok.shape[0], T, tok.shape[1])
+                lat = self.perceiver.forward(xin, B)
+                f = self.vit.trunk(lat, B, use_orig_pos=self.lens.use_orig_pos)
+        return ops.l2_normalize(f) if normalize else f

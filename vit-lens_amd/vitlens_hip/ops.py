@@ -65,15 +65,16 @@ def gemm(a, w, bias=None, out=None, res=None, epi=EPI_BF16, act=ACT_NONE, alpha=
     return out
 
 
-def gemm_qkv(a, w, bias, q, k, vt, B, L, H, dh, softmax_scale=None, cfg=-1):
-    """Packed MHA in-projection with head split: fills q,k [B,H,L,dh] and vt [B,H,dh,Lp]."""
+def gemm_qkv(a, w, bias, q, k, vt, B, L, H, dh, softmax_scale=None, cfg=-1, first=0, count=3):
+    """Packed MHA in-projection with head split: fills q,k [B,H,L,dh] and vt [B,H,dh,Lp].
+    (first, count) = which of (q,k,v) the rows of w produce."""
     _chk2d(a, "a", torch.bfloat16); _chk2d(w, "w", torch.bfloat16)
-    if a.shape[0] != B * L or w.shape[0] != 3 * H * dh or w.stride(0) != w.shape[1]:
+    if a.shape[0] != B * L or w.shape[0] != count * H * dh or w.stride(0) != w.shape[1]:
         raise ValueError("gemm_qkv: shape mismatch")
-    Lp = vt.shape[-1]
+    Lp = vt.shape[-1] if vt is not None else (L + 7) // 8 * 8
     scale = (dh ** -0.5 if softmax_scale is None else softmax_scale) * LOG2E
     check(_lib.vl_gemm_qkv_bf16(_p(a), _p(w), _p(bias), _p(q), _p(k), _p(vt), B, L, H, dh, Lp, a.shape[1],
-                                a.stride(0), float(scale), cfg, _stream()))
+                                a.stride(0), float(scale), first, count, cfg, _stream()))
 
 
 def attn_fwd(q, k, vt, out, lse=None, causal=False):
