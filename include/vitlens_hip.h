@@ -33,6 +33,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define VL_EPI_RES_F32 2  /* out f32 [M,N]   = res f32 + alpha*acc + bias (in place ok)  */
 #define VL_EPI_RES_BF16 3 /* out bf16[M,N]   = res bf16 + alpha*acc + bias               */
 #define VL_EPI_GEGLU 5    /* out bf16[M,N/2] = a*gelu(gate), W rows interleaved (a,gate) */
+#define VL_EPI_DGELU 6    /* out bf16[M,N]   = alpha*acc * gelu'(res bf16[M,N])  (dX through GELU) */
 #define VL_ACT_NONE 0
 #define VL_ACT_GELU 1     /* exact-erf GELU (nn.GELU default)                            */
 
@@ -63,6 +64,15 @@ int vl_gemm_qkv_bf16(const void* A, const void* Win, const float* bias, void* q,
                      int B, int L, int H, int dh, int Lp, int K, int lda, float qscale, int first,
                      int count, int cfg, hipStream_t stream);
 int vl_gemm_set_persist_variant(int v);
+/* vl_gemm_bf16 + `out2`: with VL_EPI_BF16/VL_ACT_GELU also stores the pre-activation (bf16) for the backward. */
+int vl_gemm_bf16_ex(const void* A, const void* W, const float* bias, void* out, const void* res, void* out2,
+                    int M, int N, int K, int lda, int ldw, int ldo, float alpha, int epi, int act,
+                    int cfg, hipStream_t stream);
+/* vl_gemm_qkv_bf16 + optional extra layouts kept for the attention backward:
+ * qt,kt [B,H,dh,Lp] (transposed q/k), v [B,H,L,dh] (row-major v).  Any output pointer may be NULL. */
+int vl_gemm_qkv_bf16_ex(const void* A, const void* Win, const float* bias, void* q, void* k, void* vt,
+                        void* qt, void* kt, void* v, int B, int L, int H, int dh, int Lp, int K, int lda,
+                        float qscale, int first, int count, int cfg, hipStream_t stream);
 
 int vl_device_info(int device, char* arch, int arch_len, int* cus, int* clock_khz, long* hbm_bytes);
 
@@ -84,10 +94,11 @@ int vl_layernorm_fwd(const void* x, int x_dtype, long x_row_stride, const int64_
                      float* mean, float* rstd, int rows, int D, float eps, hipStream_t stream);
 
 /* [cls ; tokens] + positional_embedding (+ adapter pos on rows 1..T) -> ln_pre, one pass.
- * tokens [B,T,D]; y [B,T+1,D].  Replaces transformer.py:756-772 (+ :734-745 for pos2). */
+ * tokens [B,T,D]; y [B,T+1,D].  Optional (training): xpre f32 [B,T+1,D] = the un-normalised rows,
+ * mean/rstd [B*(T+1)].  Replaces transformer.py:756-772 (+ :734-745 for pos2). */
 int vl_assemble_ln_pre(const void* tokens, int tok_dtype, const float* cls, const float* pos, const float* pos2,
-                       const float* w, const float* b, void* y, int y_dtype, int B, int T, int D, float eps,
-                       hipStream_t stream);
+                       const float* w, const float* b, void* y, int y_dtype, float* xpre, float* mean, float* rstd,
+                       int B, int T, int D, float eps, hipStream_t stream);
 
 /* F.normalize(dim=-1, eps): y f32 and/or bf16 copy; norms[rows] optional (model.py:522-540). */
 int vl_l2_normalize(const float* x, float* y, void* y_bf16, float* norms, int rows, int D, float eps,
@@ -126,6 +137,36 @@ int vl_ce_loss_accum(const float* row_lse, const float* col_lse, const float* di
 int vl_ce_grad(const float* logits, long ld, int R, int C, int label_off, const float* row_lse, const float* col_lse,
                float w_row, float w_col, void* G, long ldg, void* GT, long ldgt, float logit_scale,
                float* dscale_inout, hipStream_t stream);
+
+/* ---- backward / optimizer (trainable towers; autograd of the ops above) ---------------------- */
+/* dx = dLN(dy) + dres (optional); outputs f32 `dx` and/or a bf16 copy `dx_bf16` (next GEMM operand). */
+int vl_layernorm_bwd(const void* dy, int dy_dtype, long dy_stride, const void* x, int x_dtype, long x_stride,
+                     const float* mean, const float* rstd, const float* w, const float* dres, float* dx,
+                     void* dx_bf16, long dx_stride, int rows, int D, hipStream_t stream);
+/* dw[j] += sum_r dy*xhat ; db[j] += sum_r dy   (accumulating; zero the buffers first) */
+int vl_layernorm_bwd_params(const void* dy, int dy_dtype, long dy_stride, const void* x, int x_dtype, long x_stride,
+                            const float* mean, const float* rstd, float* dw, float* db, int rows, int D,
+                            hipStream_t stream);
+/* out[j] += scale * sum_r a[r,j]  (bias gradients) */
+int vl_colsum(const void* a, int a_dtype, long lda, float* out, int rows, int cols, float scale, hipStream_t stream);
+int vl_gelu_bf16(const void* u, void* y, long n, hipStream_t stream);
+/* delta[b,h,l] = sum_d dO[b,h,l,d] * O[b*L+l, h*dh+d] */
+int vl_attn_delta(const void* dO, const void* o, float* delta, int B, int H, int L, int dh, hipStream_t stream);
+/* Attention backward (see csrc/vl_attn_bwd.hip): dq/dk/dv are token-major bf16 destinations with row
+ * strides ld_dq / ld_dkv, already offset to their column block; scale = softmax scale. */
+int vl_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* qt, const void* kt,
+                     const void* dO, const void* dOt, const float* lse, const float* delta,
+                     void* dq, void* dk, void* dv, long ld_dq, long ld_dkv,
+                     int B, int H, int Lq, int Lk, int Lqp, int Lkp, int dh, int causal, float scale,
+                     hipStream_t stream);
+/* torch.optim.AdamW step on one tensor (grad is multiplied by grad_scale first); step counts from 1. */
+int vl_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, float grad_scale, hipStream_t stream);
+int vl_clamp_scalar(float* p, float lo, float hi, hipStream_t stream);
+int vl_axpy_f32(float* y, const float* x, float alpha, long n, hipStream_t stream);
+/* out[t,:] += sum_b x[b*batch_stride_rows + row_offset + t, :]   (positional-embedding gradients) */
+int vl_batch_rowsum(const float* x, float* out, int B, int T, int D, long batch_stride_rows, long row_offset,
+                    hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,7 @@ enum Epi : int {
   EPI_RES_BF16 = 3,  // out bf16 = res bf16 + acc + bias
   EPI_QKV = 4,    // scatter to q[B,H,L,dh], k[B,H,L,dh], vt[B,H,dh,Lp]
   EPI_GEGLU = 5,  // rows interleaved (a_j, gate_j): out bf16[M, N/2] = a * gelu(gate)
+  EPI_DGELU = 6,  // out bf16 = acc * gelu'(aux[m,n])   (backward through GELU fused into the dX GEMM)
 };
 
 struct GemmP {
@@ -31,13 +32,15 @@ struct GemmP {
   const bf16_t* W;   // [N, K]
   const float* bias; // [N] or null
   void* out;
-  const void* res;
+  const void* res;   // residual (EPI_RES_*) or pre-activation u (EPI_DGELU), same shape/stride as out
+  void* out2;        // EPI_BF16 + act: optional copy of the PRE-activation values (saved for backward)
   int M, N, K;
   int lda, ldw, ldo; // row strides in elements
   float alpha;
   int act;           // 0 none, 1 gelu(erf)
   // QKV scatter
   bf16_t *q, *k, *vt;
+  bf16_t *qt, *kt, *v;   // optional extra layouts for the attention backward (transposed q/k, row-major v)
   int L, H, dh, Lp;
   int which0;        // first part produced by this GEMM: 0 = q, 1 = k, 2 = v
   float qscale;
@@ -84,6 +87,10 @@ __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL
         }
         if constexpr (EPI == EPI_BF16) {
           if (p.act == 1) {
+            if (p.out2) {
+              u32x2 o2; o2[0] = pack2bf(v[0], v[1]); o2[1] = pack2bf(v[2], v[3]);
+              *(u32x2*)((bf16_t*)p.out2 + (size_t)m * p.ldo + n) = o2;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
           }
@@ -102,6 +109,12 @@ __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL
           v[2] += bf2f((bf16_t)(r[1] & 0xffff)); v[3] += bf2f((bf16_t)(r[1] >> 16));
           u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
           *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
+        } else if constexpr (EPI == EPI_DGELU) {
+          const u32x2 r = *(const u32x2*)((const bf16_t*)p.res + (size_t)m * p.ldo + n);
+          v[0] *= gelu_erf_grad(bf2f((bf16_t)(r[0] & 0xffff))); v[1] *= gelu_erf_grad(bf2f((bf16_t)(r[0] >> 16)));
+          v[2] *= gelu_erf_grad(bf2f((bf16_t)(r[1] & 0xffff))); v[3] *= gelu_erf_grad(bf2f((bf16_t)(r[1] >> 16)));
+          u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+          *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
         } else if constexpr (EPI == EPI_QKV) {
           // head-dim % 8 == 0: (which, head) are wave-uniform for the 8-column group -> SALU divides
           const int nu = ncol0 + j * 32 + q * 8;
@@ -115,14 +128,30 @@ __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= p.qscale;
             u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-            *(u32x2*)(p.q + (bh * p.L + ql) * p.dh + d) = o;
+            if (p.q) *(u32x2*)(p.q + (bh * p.L + ql) * p.dh + d) = o;
+            if (p.qt) {
+              bf16_t* dst = p.qt + (bh * p.dh + d) * p.Lp + ql;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dst[(size_t)e * p.Lp] = f2bf(v[e]);
+            }
           } else if (which == 1) {
             u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-            *(u32x2*)(p.k + (bh * p.L + ql) * p.dh + d) = o;
-          } else {
-            bf16_t* dst = p.vt + (bh * p.dh + d) * p.Lp + ql;
+            if (p.k) *(u32x2*)(p.k + (bh * p.L + ql) * p.dh + d) = o;
+            if (p.kt) {
+              bf16_t* dst = p.kt + (bh * p.dh + d) * p.Lp + ql;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dst[(size_t)e * p.Lp] = f2bf(v[e]);
+              for (int e = 0; e < 4; ++e) dst[(size_t)e * p.Lp] = f2bf(v[e]);
+            }
+          } else {
+            if (p.vt) {
+              bf16_t* dst = p.vt + (bh * p.dh + d) * p.Lp + ql;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dst[(size_t)e * p.Lp] = f2bf(v[e]);
+            }
+            if (p.v) {
+              u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+              *(u32x2*)(p.v + (bh * p.L + ql) * p.dh + d) = o;
+            }
           }
         } else if constexpr (EPI == EPI_GEGLU) {
           // interleaved rows: (a_j, gate_j, a_j+1, gate_j+1)
@@ -646,16 +675,25 @@ static hipError_t run_gemm(const GemmP& p, int cfg, hipStream_t s) {
 
 #define VL_CHECK_ARG(c, msg) do { if (!(c)) return vl_set_error(msg); } while (0)
 
+extern "C" int vl_gemm_bf16_ex(const void* A, const void* W, const float* bias, void* out, const void* res, void* out2,
+                               int M, int N, int K, int lda, int ldw, int ldo, float alpha, int epi, int act,
+                               int cfg, hipStream_t stream);
 extern "C" int vl_gemm_bf16(const void* A, const void* W, const float* bias, void* out, const void* res,
                             int M, int N, int K, int lda, int ldw, int ldo, float alpha, int epi, int act,
                             int cfg, hipStream_t stream) {
+  return vl_gemm_bf16_ex(A, W, bias, out, res, nullptr, M, N, K, lda, ldw, ldo, alpha, epi, act, cfg, stream);
+}
+
+extern "C" int vl_gemm_bf16_ex(const void* A, const void* W, const float* bias, void* out, const void* res, void* out2,
+                               int M, int N, int K, int lda, int ldw, int ldo, float alpha, int epi, int act,
+                               int cfg, hipStream_t stream) {
   VL_CHECK_ARG(M > 0 && N > 0 && K > 0, "vl_gemm_bf16: empty problem");
   VL_CHECK_ARG((K & 63) == 0, "vl_gemm_bf16: K must be a multiple of 64");
   VL_CHECK_ARG((N & 3) == 0, "vl_gemm_bf16: N must be a multiple of 4");
   VL_CHECK_ARG((lda & 7) == 0 && (ldw & 7) == 0, "vl_gemm_bf16: lda/ldw must be multiples of 8");
   VL_CHECK_ARG((ldo & 3) == 0, "vl_gemm_bf16: ldo must be a multiple of 4");
   GemmP p{};
-  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = bias; p.out = out; p.res = res;
+  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = bias; p.out = out; p.res = res; p.out2 = out2;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.alpha = alpha; p.act = act;
   hipError_t e;
   switch (epi) {
@@ -664,15 +702,26 @@ extern "C" int vl_gemm_bf16(const void* A, const void* W, const float* bias, voi
     case VL_EPI_RES_F32: VL_CHECK_ARG(res, "vl_gemm_bf16: residual missing"); e = run_gemm<EPI_RES_F32>(p, cfg, stream); break;
     case VL_EPI_RES_BF16: VL_CHECK_ARG(res, "vl_gemm_bf16: residual missing"); e = run_gemm<EPI_RES_BF16>(p, cfg, stream); break;
     case VL_EPI_GEGLU: e = run_gemm<EPI_GEGLU>(p, cfg, stream); break;
+    case VL_EPI_DGELU: VL_CHECK_ARG(res, "vl_gemm_bf16: pre-activation tensor missing"); e = run_gemm<EPI_DGELU>(p, cfg, stream); break;
     default: return vl_set_error("vl_gemm_bf16: unknown epilogue");
   }
   if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
   return 0;
 }
 
+extern "C" int vl_gemm_qkv_bf16_ex(const void* A, const void* W, const float* bias, void* q, void* k, void* vt,
+                                   void* qt, void* kt, void* v, int B, int L, int H, int dh, int Lp, int K, int lda,
+                                   float qscale, int first, int count, int cfg, hipStream_t stream);
 extern "C" int vl_gemm_qkv_bf16(const void* A, const void* W, const float* bias, void* q, void* k, void* vt,
                                 int B, int L, int H, int dh, int Lp, int K, int lda, float qscale, int first,
                                 int count, int cfg, hipStream_t stream) {
+  return vl_gemm_qkv_bf16_ex(A, W, bias, q, k, vt, nullptr, nullptr, nullptr, B, L, H, dh, Lp, K, lda, qscale, first, count,
+                             cfg, stream);
+}
+
+extern "C" int vl_gemm_qkv_bf16_ex(const void* A, const void* W, const float* bias, void* q, void* k, void* vt,
+                                   void* qt, void* kt, void* v, int B, int L, int H, int dh, int Lp, int K, int lda,
+                                   float qscale, int first, int count, int cfg, hipStream_t stream) {
   VL_CHECK_ARG(first >= 0 && count >= 1 && first + count <= 3, "vl_gemm_qkv_bf16: bad (first, count)");
   VL_CHECK_ARG(B > 0 && L > 0 && H > 0, "vl_gemm_qkv_bf16: empty problem");
   VL_CHECK_ARG((K & 63) == 0, "vl_gemm_qkv_bf16: K must be a multiple of 64");
@@ -681,7 +730,7 @@ extern "C" int vl_gemm_qkv_bf16(const void* A, const void* W, const float* bias,
   GemmP p{};
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = bias;
   p.M = B * L; p.N = count * H * dh; p.K = K; p.which0 = first; p.lda = lda; p.ldw = K; p.ldo = 0; p.alpha = 1.f;
-  p.q = (bf16_t*)q; p.k = (bf16_t*)k; p.vt = (bf16_t*)vt; p.L = L; p.H = H; p.dh = dh; p.Lp = Lp; p.qscale = qscale;
+  p.q = (bf16_t*)q; p.k = (bf16_t*)k; p.vt = (bf16_t*)vt; p.qt = (bf16_t*)qt; p.kt = (bf16_t*)kt; p.v = (bf16_t*)v; p.L = L; p.H = H; p.dh = dh; p.Lp = Lp; p.qscale = qscale;
   hipError_t e = run_gemm<EPI_QKV>(p, cfg, stream);
   if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
   return 0;

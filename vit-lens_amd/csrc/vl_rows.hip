@@ -83,6 +83,12 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const LnP p) {
         }
       }
     }
+    if constexpr (MODE == 1) {
+      if (p.y2) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) store4((float*)p.y2 + (long)row * D + c * 256 + lane * 4, v[c]);
+      }
+    }
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
@@ -120,7 +126,11 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const LnP p) {
     for (int e = lane; e < D; e += 64) { const float d = fetch(e) - mu; q = fmaf(d, d, q); }
     const float rs = rsqrtf(wave_sum(q) * invD + p.eps);
     if (p.mean && lane == 0) { p.mean[row] = mu; p.rstd[row] = rs; }
-    for (int e = lane; e < D; e += 64) store1(y + e, fmaf((fetch(e) - mu) * rs, p.w[e], p.b[e]));
+    for (int e = lane; e < D; e += 64) {
+      const float t = fetch(e);
+      if constexpr (MODE == 1) { if (p.y2) ((float*)p.y2)[(long)row * D + e] = t; }
+      store1(y + e, fmaf((t - mu) * rs, p.w[e], p.b[e]));
+    }
   }
 }
 
@@ -242,11 +252,11 @@ extern "C" int vl_layernorm_fwd(const void* x, int x_dtype, long x_row_stride, c
 }
 
 extern "C" int vl_assemble_ln_pre(const void* tokens, int tok_dtype, const float* cls, const float* pos, const float* pos2,
-                                  const float* w, const float* b, void* y, int y_dtype, int B, int T, int D, float eps,
-                                  hipStream_t stream) {
+                                  const float* w, const float* b, void* y, int y_dtype, float* xpre, float* mean, float* rstd,
+                                  int B, int T, int D, float eps, hipStream_t stream) {
   if (B <= 0 || T <= 0 || D <= 0) return vl_set_error("vl_assemble_ln_pre: empty problem");
   LnP p{}; p.x = tokens; p.xs = D; p.w = w; p.b = b; p.y = y; p.ys = D; p.rows = B * (T + 1); p.D = D; p.eps = eps;
-  p.cls = cls; p.pos = pos; p.pos2 = pos2; p.T = T;
+  p.cls = cls; p.pos = pos; p.pos2 = pos2; p.T = T; p.y2 = xpre; p.mean = mean; p.rstd = rstd;
   VL_HIP_OK(ln_dispatch<1>(p, tok_dtype, y_dtype, stream));
   return 0;
 }

@@ -25,7 +25,7 @@ SIGNATURES = {
     "vl_gemm_set_persist_variant": [I],
     "vl_attn_fwd_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, P],
     "vl_layernorm_fwd": [P, I, L, P, L, P, P, P, I, L, P, P, I, I, F, P],
-    "vl_assemble_ln_pre": [P, I, P, P, P, P, P, P, I, I, I, I, F, P],
+    "vl_assemble_ln_pre": [P, I, P, P, P, P, P, P, I, P, P, P, I, I, I, F, P],
     "vl_l2_normalize": [P, P, P, P, I, I, F, P],
     "vl_l2_normalize_bwd": [P, P, P, P, I, I, F, P],
     "vl_im2col_bf16": [P, P, I, I, I, I, I, I, I, I, I, I, P],
@@ -36,6 +36,18 @@ SIGNATURES = {
     "vl_ce_stats": [P, L, I, I, I, P, P, P, P, P],
     "vl_ce_loss_accum": [P, P, P, I, I, I, F, F, P, P],
     "vl_ce_grad": [P, L, I, I, I, P, P, F, F, P, L, P, L, F, P, P],
+    "vl_gemm_bf16_ex": [P, P, P, P, P, P, I, I, I, I, I, I, F, I, I, I, P],
+    "vl_gemm_qkv_bf16_ex": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, I, I, P],
+    "vl_layernorm_bwd": [P, I, L, P, I, L, P, P, P, P, P, P, L, I, I, P],
+    "vl_layernorm_bwd_params": [P, I, L, P, I, L, P, P, P, P, I, I, P],
+    "vl_colsum": [P, I, L, P, I, I, F, P],
+    "vl_gelu_bf16": [P, P, L, P],
+    "vl_attn_delta": [P, P, P, I, I, I, I, P],
+    "vl_attn_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, I, I, I, I, I, F, P],
+    "vl_adamw_step": [P, P, P, P, L, F, F, F, F, F, I, F, P],
+    "vl_clamp_scalar": [P, F, F, P],
+    "vl_axpy_f32": [P, P, F, L, P],
+    "vl_batch_rowsum": [P, P, I, I, I, L, L, P],
 }
 
 

@@ -8,7 +8,7 @@ import torch
 from ._lib import load_library, check
 
 F32, BF16 = 0, 1
-EPI_BF16, EPI_F32, EPI_RES_F32, EPI_RES_BF16, EPI_GEGLU = 0, 1, 2, 3, 5
+EPI_BF16, EPI_F32, EPI_RES_F32, EPI_RES_BF16, EPI_GEGLU, EPI_DGELU = 0, 1, 2, 3, 5, 6
 ACT_NONE, ACT_GELU = 0, 1
 LOG2E = 1.4426950408889634
 
@@ -42,8 +42,8 @@ def _chk2d(t, name, dtype=None):
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
 
 
-def gemm(a, w, bias=None, out=None, res=None, epi=EPI_BF16, act=ACT_NONE, alpha=1.0, cfg=-1):
-    """out = epilogue(a @ w.T).  a [M,K] bf16, w [N,K] bf16."""
+def gemm(a, w, bias=None, out=None, res=None, epi=EPI_BF16, act=ACT_NONE, alpha=1.0, cfg=-1, out2=None):
+    """out = epilogue(a @ w.T).  a [M,K] bf16, w [N,K] bf16.  out2: optional pre-activation copy (bf16)."""
     _chk2d(a, "a", torch.bfloat16); _chk2d(w, "w", torch.bfloat16)
     M, K = a.shape
     N = w.shape[0]
@@ -60,21 +60,25 @@ def gemm(a, w, bias=None, out=None, res=None, epi=EPI_BF16, act=ACT_NONE, alpha=
             raise ValueError("gemm: residual must share out's row stride and dtype")
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N):
         raise ValueError("gemm: bias must be f32 [N]")
-    check(_lib.vl_gemm_bf16(_p(a), _p(w), _p(bias), _p(out), _p(res), M, N, K, a.stride(0), w.stride(0),
-                            out.stride(0), float(alpha), epi, act, cfg, _stream()))
+    if out2 is not None and (out2.stride(0) != out.stride(0) or out2.dtype != torch.bfloat16):
+        raise ValueError("gemm: out2 must be bf16 with out's row stride")
+    check(_lib.vl_gemm_bf16_ex(_p(a), _p(w), _p(bias), _p(out), _p(res), _p(out2), M, N, K, a.stride(0), w.stride(0),
+                               out.stride(0), float(alpha), epi, act, cfg, _stream()))
     return out
 
 
-def gemm_qkv(a, w, bias, q, k, vt, B, L, H, dh, softmax_scale=None, cfg=-1, first=0, count=3):
+def gemm_qkv(a, w, bias, q, k, vt, B, L, H, dh, softmax_scale=None, cfg=-1, first=0, count=3, qt=None, kt=None,
+             v=None, raw_scale=None):
     """Packed MHA in-projection with head split: fills q,k [B,H,L,dh] and vt [B,H,dh,Lp].
     (first, count) = which of (q,k,v) the rows of w produce."""
     _chk2d(a, "a", torch.bfloat16); _chk2d(w, "w", torch.bfloat16)
     if a.shape[0] != B * L or w.shape[0] != count * H * dh or w.stride(0) != w.shape[1]:
         raise ValueError("gemm_qkv: shape mismatch")
-    Lp = vt.shape[-1] if vt is not None else (L + 7) // 8 * 8
-    scale = (dh ** -0.5 if softmax_scale is None else softmax_scale) * LOG2E
-    check(_lib.vl_gemm_qkv_bf16(_p(a), _p(w), _p(bias), _p(q), _p(k), _p(vt), B, L, H, dh, Lp, a.shape[1],
-                                a.stride(0), float(scale), first, count, cfg, _stream()))
+    tt = next((t for t in (vt, qt, kt) if t is not None), None)
+    Lp = tt.shape[-1] if tt is not None else (L + 7) // 8 * 8
+    scale = (dh ** -0.5 if softmax_scale is None else softmax_scale) * LOG2E if raw_scale is None else raw_scale
+    check(_lib.vl_gemm_qkv_bf16_ex(_p(a), _p(w), _p(bias), _p(q), _p(k), _p(vt), _p(qt), _p(kt), _p(v), B, L, H, dh, Lp,
+                                   a.shape[1], a.stride(0), float(scale), first, count, cfg, _stream()))
 
 
 def attn_fwd(q, k, vt, out, lse=None, causal=False):
@@ -96,9 +100,9 @@ def layernorm(x, w, b, out, rows, D, x_row_stride=None, row_index=None, row_mul=
     return out
 
 
-def assemble_ln_pre(tokens, cls, pos, pos2, w, b, out, B, T, D, eps=1e-5):
+def assemble_ln_pre(tokens, cls, pos, pos2, w, b, out, B, T, D, eps=1e-5, xpre=None, mean=None, rstd=None):
     check(_lib.vl_assemble_ln_pre(_p(tokens), _dt(tokens), _p(cls), _p(pos), _p(pos2), _p(w), _p(b), _p(out),
-                                  _dt(out), B, T, D, float(eps), _stream()))
+                                  _dt(out), _p(xpre), _p(mean), _p(rstd), B, T, D, float(eps), _stream()))
     return out
 
 
@@ -197,3 +201,62 @@ def device_info(device=0):
     cus, clk, mem = C.c_int(), C.c_int(), C.c_long()
     check(_lib.vl_device_info(device, arch, 64, C.byref(cus), C.byref(clk), C.byref(mem)))
     return {"arch": arch.value.decode(), "cus": cus.value, "clock_khz": clk.value, "hbm_bytes": mem.value}
+
+
+# ------------------------------------------------------------------------------------------------ backward
+def layernorm_bwd(dy, x, mean, rstd, w, rows, D, dres=None, dx=None, dx_bf16=None, x_row_stride=None,
+                  dy_row_stride=None, dx_row_stride=None):
+    check(_lib.vl_layernorm_bwd(_p(dy), _dt(dy), D if dy_row_stride is None else dy_row_stride, _p(x), _dt(x),
+                                D if x_row_stride is None else x_row_stride, _p(mean), _p(rstd), _p(w), _p(dres),
+                                _p(dx), _p(dx_bf16), D if dx_row_stride is None else dx_row_stride, rows, D, _stream()))
+
+
+def layernorm_bwd_params(dy, x, mean, rstd, dw, db, rows, D, x_row_stride=None, dy_row_stride=None):
+    check(_lib.vl_layernorm_bwd_params(_p(dy), _dt(dy), D if dy_row_stride is None else dy_row_stride, _p(x), _dt(x),
+                                       D if x_row_stride is None else x_row_stride, _p(mean), _p(rstd), _p(dw), _p(db),
+                                       rows, D, _stream()))
+
+
+def colsum(a, out, scale=1.0):
+    _chk2d(a, "a")
+    check(_lib.vl_colsum(_p(a), _dt(a), a.stride(0), _p(out), a.shape[0], a.shape[1], float(scale), _stream()))
+
+
+def gelu_bf16(u, out):
+    check(_lib.vl_gelu_bf16(_p(u), _p(out), u.numel(), _stream()))
+    return out
+
+
+def attn_delta(dO, o, delta):
+    B, H, L, dh = dO.shape
+    check(_lib.vl_attn_delta(_p(dO), _p(o), _p(delta), B, H, L, dh, _stream()))
+    return delta
+
+
+def attn_bwd(q, k, v, qt, kt, dO, dOt, lse, delta, dq, dk, dv, ld_dq, ld_dkv, causal=False, softmax_scale=None):
+    B, H, Lq, dh = q.shape
+    Lk = k.shape[2]
+    scale = dh ** -0.5 if softmax_scale is None else softmax_scale
+    check(_lib.vl_attn_bwd_bf16(_p(q), _p(k), _p(v), _p(qt), _p(kt), _p(dO), _p(dOt), _p(lse), _p(delta), _p(dq), _p(dk),
+                                _p(dv), ld_dq, ld_dkv, B, H, Lq, Lk, qt.shape[3], kt.shape[3], dh, 1 if causal else 0,
+                                float(scale), _stream()))
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    for t in (p, g, m, v):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("adamw_step: contiguous f32 tensors required")
+    check(_lib.vl_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                             float(weight_decay), int(step), float(grad_scale), _stream()))
+
+
+def clamp_scalar(p, lo, hi):
+    check(_lib.vl_clamp_scalar(_p(p), float(lo), float(hi), _stream()))
+
+
+def axpy(y, x, alpha=1.0):
+    check(_lib.vl_axpy_f32(_p(y), _p(x), float(alpha), y.numel(), _stream()))
+
+
+def batch_rowsum(x, out, B, T, D, batch_stride_rows, row_offset):
+    check(_lib.vl_batch_rowsum(_p(x), _p(out), B, T, D, batch_stride_rows, row_offset, _stream()))
