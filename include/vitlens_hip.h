@@ -130,6 +130,8 @@ int vl_transpose_to_bf16(const void* in, int in_dtype, long ldi, int R, int C, v
  *   vl_ce_grad       G[R,ldg] / GT[C,ldgt] bf16 = dLoss/dlogits (and transpose), *dscale += <G,logits>/scale
  * Replaces F.cross_entropy(logits_per_x)+F.cross_entropy(logits_per_y) and autograd thereof
  * (loss.py:158-163, 300-306, 377-383). */
+/* f32 [rows,D] -> bf16 [rows,3D] hi/lo split (pattern 0: hi|lo|hi, 1: hi|hi|lo) for near-fp32 logits */
+int vl_split_bf16x3(const float* x, void* out, long rows, int D, int pattern, hipStream_t stream);
 int vl_ce_stats(const float* logits, long ld, int R, int C, int label_off, float* row_lse, float* col_lse,
                 float* diag, float* col_ws, hipStream_t stream);
 int vl_ce_loss_accum(const float* row_lse, const float* col_lse, const float* diag, int R, int C, int label_off,

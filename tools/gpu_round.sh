@@ -10,17 +10,20 @@ echo "== pytest gpu =="
 timeout 900 python -m pytest tests -m gpu -q -n 4 -p no:cacheprovider 2>&1 | tail -80 > gpurun_out/pytest_gpu.log
 tail -40 gpurun_out/pytest_gpu.log
 echo "== kernel bench =="
-timeout 600 python tools/kernel_bench.py ${KB_ARGS:---quick} > gpurun_out/kernel_bench.log 2>&1
-tail -40 gpurun_out/kernel_bench.log
+if [ -z "$SKIP_KB" ]; then timeout 600 python tools/kernel_bench.py ${KB_ARGS:---quick} > gpurun_out/kernel_bench.log 2>&1; tail -40 gpurun_out/kernel_bench.log; fi
 echo "== bench =="
 timeout 600 python bench.py --steps 5 --warmup 2 --detail gpurun_out/bench_detail.json > gpurun_out/bench.log 2>&1
 tail -3 gpurun_out/bench.log
+echo "== bench c3 =="
+timeout 900 python bench.py --workload c3 --batch ${C3_BATCH:-1024} --steps 3 --warmup 1 --detail gpurun_out/bench_c3_detail.json > gpurun_out/bench_c3.log 2>&1
+tail -3 gpurun_out/bench_c3.log | cut -c1-1800
 echo "== rocprof =="
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1
 cd $GRAFT_REPO_ROOT
 find gpurun_out/prof -name "*stats*" | head; 
 for f in $(find gpurun_out/prof -name "*kernel_stats*.csv" | head -1); do head -30 $f; done
 echo "== pmc =="
+[ -n "$SKIP_PMC" ] && exit 0
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc -o gemm -- python $GRAFT_REPO_ROOT/tools/gemm_pmc.py > $GRAFT_REPO_ROOT/gpurun_out/pmc.log 2>&1
 cd $GRAFT_REPO_ROOT; ls gpurun_out/pmc | head
 # keep only the small summaries

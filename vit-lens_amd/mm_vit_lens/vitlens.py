@@ -1,0 +1,84 @@
+"""`ViTLens.encode({ModalityType: inputs})` with the reference's call surface (mm_vit_lens/vitlens.py:21-189).
+
+Inputs are tensors already in model space (the reference's per-modality processors are file I/O + CPU
+preprocessing, outside the hot path -- SURVEY §2 A7):
+   image [B,3,224,224] | text: list[str] or int64 [B,77] | depth [B,1,224,224] | audio [B,S,512,128] or [B,512,128]
+   | pc [B,8192,3]
+`encode` returns {modality: [B, 768]} (audio: mean over the S clips, vitlens.py:175-183), L2-normalised by default.
+"""
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from open_clip import ModalityType, tokenize, tri_create_model
+from .model_cfg import fetch_model_cfg
+
+
+class ViTLens(nn.Module):
+    def __init__(self, model_var: str = "vitlensL", modality_loaded: Optional[List[str]] = None,
+                 load_from_ckpt: Optional[str] = None, device="cuda"):
+        super().__init__()
+        self.model_var = model_var
+        self.modality_loaded = modality_loaded or [ModalityType.IMAGE, ModalityType.TEXT]
+        self.vitlens = nn.ModuleDict()
+        self._dev = torch.device(device)
+        base = None
+        for m in self.modality_loaded:
+            if m in (ModalityType.IMAGE, ModalityType.TEXT):
+                if base is None:
+                    cfg = fetch_model_cfg("image", model_var)
+                    base = tri_create_model(cfg.model, None, device=self._dev, args=cfg)
+                self.vitlens[m] = base
+            elif m in (ModalityType.DEPTH, ModalityType.AUDIO, ModalityType.PC):
+                cfg = fetch_model_cfg(m, model_var)
+                self.vitlens[m] = tri_create_model(cfg.model, None, device=self._dev, args=cfg)
+            else:
+                raise NotImplementedError(f"modality {m!r} is outside the hot path (SURVEY §8)")
+        if load_from_ckpt is not None:
+            self.load_checkpoint(load_from_ckpt)
+
+    @property
+    def device(self):
+        return self._dev
+
+    def load_checkpoint(self, path):
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        sd = ckpt.get("state_dict", ckpt)
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+        # released file prefixes modules as vitlens.<modality>.<part> (vitlens.py:153-159)
+        for m, model in self.vitlens.items():
+            sub = {k[len(f"vitlens.{m}."):]: v for k, v in sd.items() if k.startswith(f"vitlens.{m}.")}
+            if not sub:
+                continue
+            if m == ModalityType.IMAGE:
+                sub = {"image." + k: v for k, v in sub.items()}
+            elif m not in (ModalityType.TEXT,):
+                sub = {"visual." + k: v for k, v in sub.items()}
+            model.load_state_dict(sub, strict=False)
+
+    def export_checkpoint(self, path):
+        torch.save({"model_var": self.model_var, "modality_loaded": self.modality_loaded,
+                    "state_dict": self.state_dict()}, path)
+
+    @torch.no_grad()
+    def encode(self, input_dict: Dict[str, object], normalize: bool = True) -> Dict[str, torch.Tensor]:
+        out = {}
+        for m, x in input_dict.items():
+            model = self.vitlens[m]
+            if m == ModalityType.TEXT:
+                ids = tokenize(x) if not isinstance(x, torch.Tensor) else x
+                f = model.encode_text(ids.to(self._dev), normalize=False)
+            elif m == ModalityType.IMAGE:
+                f = model.encode_image(x.to(self._dev), normalize=False)
+            elif m == ModalityType.AUDIO and x.ndim == 4:
+                B, S = x.shape[:2]
+                f = model.encode_visual(x.reshape(B * S, *x.shape[2:]).to(self._dev), normalize=False)
+                f = f.reshape(B, S, -1).mean(dim=1).contiguous()
+            else:
+                f = model.encode_visual(x.to(self._dev), normalize=False)
+            if normalize:
+                from vitlens_hip import ops
+                f = ops.l2_normalize(f.contiguous().float())
+            out[m] = f
+        return out

@@ -1,0 +1,8 @@
+"""open_clip-compatible surface of the MI355X-native ViT-Lens hot path (drop-in for
+`from open_clip import ModalityType, tokenize, tri_create_model, create_loss, ...`)."""
+from .constants import OPENAI_DATASET_MEAN, OPENAI_DATASET_STD, ModalityType
+from .factory import (add_model_config, create_loss, get_model_config, get_tokenizer, list_models, load_checkpoint,
+                      tri_create_model, tri_create_model_and_transforms)
+from .loss import ClipLoss, ClipLossGeneral, TriClipLoss, gather_features
+from .model import CLIPTextCfg, CLIPVisionCfg, TriCLIP
+from .tokenizer import SimpleTokenizer, decode, tokenize

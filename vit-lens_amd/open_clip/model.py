@@ -1,0 +1,354 @@
+"""`TriCLIP` with the reference's surface (open_clip/model.py:391-621) on the MI355X kernels.
+
+The module tree owns ordinary fp32 `nn.Parameter`s under the reference's state_dict names,
+so checkpoints and optimizers see the same thing; `encode_image / encode_text / encode_visual / forward`
+run the towers through vitlens_hip engines (bf16 MFMA GEMMs, fp32 accumulation / statistics).  Engines
+are (re)built from the parameters whenever their versions change.  There is no eager fallback: the
+forward needs a GPU and libvitlens_hip.so.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import Any, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+@dataclass
+class CLIPVisionCfg:
+    layers: int = 12
+    width: int = 768
+    head_width: int = 64
+    mlp_ratio: float = 4.0
+    patch_size: int = 16
+    image_size: int = 224
+    visual_modality_type: str = "image"
+    use_perceiver: bool = False
+    perceiver_cfg: Optional[dict] = None
+    use_visual_adapter: bool = False
+    visual_adapter_cfg: Optional[dict] = None
+    visual_arch: str = "perceiver_vit"
+    exp_args: Optional[Any] = None
+
+
+@dataclass
+class CLIPTextCfg:
+    context_length: int = 77
+    vocab_size: int = 49408
+    width: int = 512
+    heads: int = 8
+    layers: int = 12
+
+
+class _Node(nn.Module):
+    """Bare parameter container; children are attached by dotted name."""
+
+
+def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer: bool = False):
+    parts = dotted.split(".")
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, _Node())
+        m = m._modules[p]
+    if buffer:
+        m.register_buffer(parts[-1], tensor)
+    else:
+        m.register_parameter(parts[-1], nn.Parameter(tensor))
+
+
+def _g(obj, name, default=None):
+    if obj is None:
+        return default
+    if isinstance(obj, dict):
+        return obj.get(name, default)
+    return getattr(obj, name, default)
+
+
+def _uni(shape, bound):
+    return (torch.rand(*shape) * 2 - 1) * bound
+
+
+def _block_params(prefix, D, hidden, text_init=None):
+    """name -> tensor for one ResidualAttentionBlock with the reference's initial distributions
+    (nn.MultiheadAttention: xavier_uniform in_proj, zero biases; nn.Linear: U(+-1/sqrt(fan_in)))."""
+    out = {}
+    for n in ("ln_1", "ln_2"):
+        out[f"{prefix}{n}.weight"] = torch.ones(D); out[f"{prefix}{n}.bias"] = torch.zeros(D)
+    out[prefix + "attn.in_proj_weight"] = _uni((3 * D, D), math.sqrt(6.0 / (4 * D)))
+    out[prefix + "attn.in_proj_bias"] = torch.zeros(3 * D)
+    out[prefix + "attn.out_proj.weight"] = _uni((D, D), D ** -0.5)
+    out[prefix + "attn.out_proj.bias"] = torch.zeros(D)
+    out[prefix + "mlp.c_fc.weight"] = _uni((hidden, D), D ** -0.5)
+    out[prefix + "mlp.c_fc.bias"] = _uni((hidden,), D ** -0.5)
+    out[prefix + "mlp.c_proj.weight"] = _uni((D, hidden), hidden ** -0.5)
+    out[prefix + "mlp.c_proj.bias"] = _uni((D,), hidden ** -0.5)
+    if text_init is not None:
+        attn_std, proj_std, fc_std = text_init
+        out[prefix + "attn.in_proj_weight"] = torch.randn(3 * D, D) * attn_std
+        out[prefix + "attn.out_proj.weight"] = torch.randn(D, D) * proj_std
+        out[prefix + "mlp.c_fc.weight"] = torch.randn(hidden, D) * fc_std
+        out[prefix + "mlp.c_proj.weight"] = torch.randn(D, hidden) * proj_std
+    return out
+
+
+class VisionTransformer(nn.Module):
+    """Parameter holder + HIP forward for one ViT tower (image tower, or Lens + ViT `visual` tower)."""
+
+    def __init__(self, embed_dim: int, cfg: CLIPVisionCfg):
+        super().__init__()
+        self.cfg, self.embed_dim = cfg, embed_dim
+        a = cfg.exp_args
+        D, P = cfg.width, cfg.patch_size
+        self.heads = D // cfg.head_width
+        self.modality = {"3dpc": "pc", "pointcloud": "pc", "point_cloud": "pc", "point cloud": "pc"}.get(
+            cfg.visual_modality_type, cfg.visual_modality_type)
+        grid = (cfg.image_size // P) ** 2
+        self.use_perceiver = bool(cfg.use_perceiver)
+        self.perceiver_identity = bool(_g(a, "perceiver_as_identity", False)) or not self.use_perceiver
+        if _g(a, "perceiver_as_transformer", False):
+            raise NotImplementedError("perceiver_as_transformer is outside the hot path (SURVEY §8)")
+        n_tok = _g(a, "perceiver_num_latents", grid) if self.use_perceiver else grid
+        scale = D ** -0.5
+        prm = {"class_embedding": scale * torch.randn(D), "positional_embedding": scale * torch.randn(n_tok + 1, D),
+               "proj": scale * torch.randn(D, embed_dim)}
+        for n in ("ln_pre", "ln_post"):
+            prm[n + ".weight"] = torch.ones(D); prm[n + ".bias"] = torch.zeros(D)
+        hidden = int(D * cfg.mlp_ratio)
+        for i in range(cfg.layers):
+            prm.update(_block_params(f"transformer.resblocks.{i}.", D, hidden))
+        bufs = {}
+        if self.modality in ("image", "tactile"):
+            prm["conv1.weight"] = _uni((D, 3, P, P), (3 * P * P) ** -0.5)
+        elif self.modality == "depth":
+            prm["visual_adapter.conv1.weight"] = _uni((D, 1, P, P), (P * P) ** -0.5)
+            prm["visual_adapter.pos_emb"] = scale * torch.randn(grid, D)
+        elif self.modality == "audio":
+            fd = (a.audio_mel_bins - P) // a.audio_fstride + 1
+            td = (a.audio_target_length - P) // a.audio_tstride + 1
+            prm["visual_adapter.conv1.weight"] = _uni((D, 1, P, P), (P * P) ** -0.5)
+            prm["visual_adapter.pos_emb"] = scale * torch.randn(fd * td, D)
+        elif self.modality == "pc":
+            E, Tr = a.pc_encoder_dims, a.pc_trans_dim
+            def lin(name, o, i, conv=False):
+                prm[f"visual_adapter.{name}.weight"] = _uni((o, i, 1) if conv else (o, i), i ** -0.5)
+                prm[f"visual_adapter.{name}.bias"] = _uni((o,), i ** -0.5)
+            def bn(name, c):
+                prm[f"visual_adapter.{name}.weight"] = torch.ones(c); prm[f"visual_adapter.{name}.bias"] = torch.zeros(c)
+                bufs[f"visual_adapter.{name}.running_mean"] = torch.zeros(c)
+                bufs[f"visual_adapter.{name}.running_var"] = torch.ones(c)
+                bufs[f"visual_adapter.{name}.num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+            lin("encoder.first_conv.0", 128, 3, True); bn("encoder.first_conv.1", 128); lin("encoder.first_conv.3", 256, 128, True)
+            lin("encoder.second_conv.0", 512, 512, True); bn("encoder.second_conv.1", 512); lin("encoder.second_conv.3", E, 512, True)
+            lin("reduce_dim", Tr, E); lin("pos_embed.0", 128, 3); lin("pos_embed.2", Tr, 128)
+        else:
+            raise NotImplementedError(f"modality {self.modality!r}")
+        if self.use_perceiver and not self.perceiver_identity:
+            Ld, C = a.perceiver_latent_dim, a.perceiver_input_chan
+            prm["perceiver.latents"] = torch.randn(a.perceiver_num_latents, Ld)
+            def ln(name, d):
+                prm[name + ".weight"] = torch.ones(d); prm[name + ".bias"] = torch.zeros(d)
+            def attn(q, qd, cd, heads, dh):
+                inner = heads * dh
+                prm[q + "to_q.weight"] = _uni((inner, qd), qd ** -0.5)
+                prm[q + "to_kv.weight"] = _uni((2 * inner, cd), cd ** -0.5)
+                prm[q + "to_out.weight"] = _uni((qd, inner), inner ** -0.5); prm[q + "to_out.bias"] = _uni((qd,), inner ** -0.5)
+            def ff(q, d):
+                prm[q + "net.0.weight"] = _uni((8 * d, d), d ** -0.5); prm[q + "net.0.bias"] = _uni((8 * d,), d ** -0.5)
+                prm[q + "net.2.weight"] = _uni((d, 4 * d), (4 * d) ** -0.5); prm[q + "net.2.bias"] = _uni((d,), (4 * d) ** -0.5)
+            for i in range(a.perceiver_depth):
+                q = f"perceiver.layers.{i}."
+                ln(q + "0.norm", Ld); ln(q + "0.norm_context", C)
+                attn(q + "0.fn.", Ld, C, a.perceiver_cross_heads, a.perceiver_cross_dim_head)
+                ln(q + "1.norm", Ld); ff(q + "1.fn.", Ld)
+                for j in range(a.perceiver_self_per_cross_attn):
+                    r = f"{q}2.{j}."
+                    ln(r + "0.norm", Ld); attn(r + "0.fn.", Ld, Ld, a.perceiver_latent_heads, a.perceiver_latent_dim_head)
+                    ln(r + "1.norm", Ld); ff(r + "1.fn.", Ld)
+        for k, v in prm.items():
+            _attach(self, k, v)
+        for k, v in bufs.items():
+            _attach(self, k, v, buffer=True)
+        self.image_mean = self.image_std = None
+        self._engine = None
+        self._engine_key = None
+
+    # -------------------------------------------------------------------------------------- lock recipes
+    def lock(self, unlocked_groups=0, freeze_bn_stats=False, unlock_cls=False, unlock_pos_emb=False,
+             unlock_trans_first_n_layers=None):
+        """VisionTransformer.lock, open_clip/transformer.py:553-627."""
+        if unlocked_groups != 0:
+            raise NotImplementedError("unlocked_groups != 0 is not used by the hot-path recipes")
+        for p in self.parameters():
+            p.requires_grad = False
+        on = []
+        for n, p in self.named_parameters():
+            if n.startswith("perceiver.") or n.startswith("visual_adapter."):
+                on.append(p)
+        if unlock_cls:
+            on.append(self.class_embedding)
+        if unlock_pos_emb:
+            on.append(self.positional_embedding)
+        if unlock_trans_first_n_layers is not None:
+            for i in range(unlock_trans_first_n_layers):
+                on.extend(self.transformer.resblocks._modules[str(i)].parameters())
+        for p in on:
+            p.requires_grad = True
+
+    def set_grad_checkpointing(self, enable=True):
+        self.grad_checkpointing = enable
+
+    # -------------------------------------------------------------------------------------- engines
+    def _cfgs(self):
+        from vitlens_hip import engine as E
+        c, a = self.cfg, self.cfg.exp_args
+        tower = E.TowerCfg(width=c.width, layers=c.layers, heads=self.heads, mlp_ratio=c.mlp_ratio, patch=c.patch_size,
+                           image_size=c.image_size, embed_dim=self.embed_dim)
+        lens = None
+        if self.modality not in ("image", "tactile"):
+            lens = E.LensCfg(
+                modality=self.modality, perceiver_identity=self.perceiver_identity,
+                depth=_g(a, "perceiver_depth", 1), self_per_cross=_g(a, "perceiver_self_per_cross_attn", 1),
+                num_latents=_g(a, "perceiver_num_latents", 256), latent_dim=_g(a, "perceiver_latent_dim", c.width),
+                input_chan=_g(a, "perceiver_input_chan", c.width), cross_heads=_g(a, "perceiver_cross_heads", 1),
+                cross_dim_head=_g(a, "perceiver_cross_dim_head", 64), latent_heads=_g(a, "perceiver_latent_heads", 16),
+                latent_dim_head=_g(a, "perceiver_latent_dim_head", 64), audio_fstride=_g(a, "audio_fstride", 10),
+                audio_tstride=_g(a, "audio_tstride", 10), audio_mel_bins=_g(a, "audio_mel_bins", 128),
+                audio_target_length=_g(a, "audio_target_length", 512), pc_num_group=_g(a, "pc_num_group", 512),
+                pc_group_size=_g(a, "pc_group_size", 32), pc_encoder_dims=_g(a, "pc_encoder_dims", 256),
+                pc_trans_dim=_g(a, "pc_trans_dim", 384), use_orig_pos=not _g(a, "disable_orig_pos", False),
+                disable_adapter_pos=bool(_g(a, "disable_visual_adapter_pos", False)))
+        return tower, lens
+
+    def engine(self):
+        from vitlens_hip import engine as E
+        dev = self.class_embedding.device
+        if dev.type != "cuda":
+            raise RuntimeError("the ViT-Lens towers run on the MI355X kernels only: move the model to a GPU")
+        key = (str(dev), tuple(p._version for p in self.parameters()), self.training)
+        if self._engine is None or key != self._engine_key:
+            sd = {("t." + k): v for k, v in self.state_dict().items()}
+            tower, lens = self._cfgs()
+            if lens is None:
+                self._engine = E.VitEngine(sd, "t.", tower, dev)
+            else:
+                self._engine = E.LensEngine(sd, "t.", tower, lens, dev)
+            self._engine_key = key
+        return self._engine
+
+    def forward(self, x: torch.Tensor, fwd_output_tokens: bool = False, **kwargs):
+        if fwd_output_tokens:
+            raise NotImplementedError("token outputs are only used by the video-distillation losses (out of scope)")
+        eng = self.engine()
+        x = x.to(self.class_embedding.device)
+        if self.modality in ("image", "tactile"):
+            return eng.encode_image(x)
+        return eng.encode(x, **kwargs)
+
+
+def _normalize(x):
+    """F.normalize(dim=-1) on the HIP kernel (model.py:522-540)."""
+    from vitlens_hip import ops
+    return ops.l2_normalize(x.contiguous().float())
+
+
+class TriCLIP(nn.Module):
+    def __init__(self, embed_dim: int, vision_cfg, text_cfg, quick_gelu: bool = False, cast_dtype=None,
+                 output_dict: bool = False):
+        super().__init__()
+        if quick_gelu:
+            raise NotImplementedError("QuickGELU towers are not part of the named configs")
+        vision_cfg = CLIPVisionCfg(**vision_cfg) if isinstance(vision_cfg, dict) else vision_cfg
+        text_cfg = CLIPTextCfg(**text_cfg) if isinstance(text_cfg, dict) else text_cfg
+        self.exp_args = vision_cfg.exp_args
+        self.output_dict = output_dict
+        self.visual_arch = vision_cfg.visual_arch
+        if self.visual_arch != "perceiver_vit":
+            raise NotImplementedError("only visual_arch='perceiver_vit' (Lens -> frozen ViT) is on the hot path")
+        img_cfg = CLIPVisionCfg(layers=vision_cfg.layers, width=vision_cfg.width, head_width=vision_cfg.head_width,
+                                mlp_ratio=vision_cfg.mlp_ratio, patch_size=vision_cfg.patch_size,
+                                image_size=vision_cfg.image_size, exp_args=vision_cfg.exp_args)
+        self.image = VisionTransformer(embed_dim, img_cfg)            # module_cfg.set_default_image_cfg
+        self.visual = VisionTransformer(embed_dim, vision_cfg)
+        # text tower flattened into the root (model.py:435-443)
+        self.text_cfg = text_cfg
+        self.context_length, self.vocab_size = text_cfg.context_length, text_cfg.vocab_size
+        W, Ly = text_cfg.width, text_cfg.layers
+        _attach(self, "token_embedding.weight", torch.randn(text_cfg.vocab_size, W) * 0.02)
+        self.positional_embedding = nn.Parameter(torch.randn(text_cfg.context_length, W) * 0.01)
+        self.text_projection = nn.Parameter(torch.randn(W, embed_dim) * W ** -0.5)
+        _attach(self, "ln_final.weight", torch.ones(W)); _attach(self, "ln_final.bias", torch.zeros(W))
+        stds = (W ** -0.5, (W ** -0.5) * ((2 * Ly) ** -0.5), (2 * W) ** -0.5)
+        for i in range(Ly):
+            for k, v in _block_params(f"transformer.resblocks.{i}.", W, 4 * W, text_init=stds).items():
+                _attach(self, k, v)
+        mask = torch.full((text_cfg.context_length, text_cfg.context_length), float("-inf")).triu_(1)
+        self.register_buffer("attn_mask", mask, persistent=False)
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+        self._text_engine, self._text_key = None, None
+
+    # ---- lock recipes (model.py:448-502) -------------------------------------------------------
+    def lock_image_tower(self, unlocked_groups=0, freeze_bn_stats=False, unlock_cls=False, unlock_pos_emb=False):
+        self.image.lock(unlocked_groups=unlocked_groups, freeze_bn_stats=freeze_bn_stats, unlock_cls=unlock_cls,
+                        unlock_pos_emb=unlock_pos_emb)
+
+    def lock_visual_tower(self, unlocked_groups=0, freeze_bn_stats=False, unlock_cls=False, unlock_pos_emb=False,
+                          unlock_trans_first_n_layers=None):
+        self.visual.lock(unlocked_groups=unlocked_groups, freeze_bn_stats=freeze_bn_stats, unlock_cls=unlock_cls,
+                         unlock_pos_emb=unlock_pos_emb, unlock_trans_first_n_layers=unlock_trans_first_n_layers)
+
+    def lock_text_tower(self, unlocked_layers: int = 0, freeze_layer_norm: bool = True):
+        for n, p in self.named_parameters():
+            if n.startswith(("transformer.", "token_embedding.", "ln_final.")) or n in ("positional_embedding", "text_projection"):
+                p.requires_grad = False
+
+    def set_grad_checkpointing(self, enable=True):
+        self.visual.set_grad_checkpointing(enable); self.image.set_grad_checkpointing(enable)
+
+    # ---- encoders ---------------------------------------------------------------------------------
+    def _text(self):
+        from vitlens_hip import engine as E
+        dev = self.positional_embedding.device
+        if dev.type != "cuda":
+            raise RuntimeError("the ViT-Lens towers run on the MI355X kernels only: move the model to a GPU")
+        names = [n for n, _ in self.named_parameters() if not n.startswith(("image.", "visual."))]
+        key = (str(dev), tuple(dict(self.named_parameters())[n]._version for n in names))
+        if self._text_engine is None or key != self._text_key:
+            sd = {k: v for k, v in self.state_dict().items() if not k.startswith(("image.", "visual."))}
+            t = self.text_cfg
+            self._text_engine = E.TextEngine(sd, E.TextCfg(context_length=t.context_length, vocab_size=t.vocab_size,
+                                                           width=t.width, heads=t.heads, layers=t.layers,
+                                                           embed_dim=self.text_projection.shape[1]), dev)
+            self._text_key = key
+        return self._text_engine
+
+    def encode_image(self, image, normalize: bool = False):
+        n_img = None
+        if image.ndim == 5:                                           # [b, t, c, h, w]: mean over frames
+            n_img = image.size(1)
+            image = image.reshape(-1, *image.shape[2:])
+        features = self.image(image)
+        if n_img is not None:
+            features = features.reshape(-1, n_img, features.shape[-1]).mean(1).contiguous()
+        return _normalize(features) if normalize else features
+
+    def encode_visual(self, visual_x, normalize: bool = False, **kwargs):
+        features = self.visual(visual_x, **kwargs)
+        return _normalize(features) if normalize else features
+
+    def encode_text(self, text, normalize: bool = False):
+        features = self._text().encode_text(text.to(self.positional_embedding.device))
+        return _normalize(features) if normalize else features
+
+    def forward(self, image=None, text=None, visual_x=None):
+        image_features = self.encode_image(image, normalize=True) if image is not None else None
+        if image is not None and image.ndim == 5:
+            image_features = _normalize(image_features)
+        text_features = self.encode_text(text, normalize=True) if text is not None else None
+        visual_features = self.encode_visual(visual_x, normalize=True) if visual_x is not None else None
+        if self.output_dict:
+            return {"image_features": image_features, "text_features": text_features,
+                    "visual_features": visual_features, "logit_scale": self.logit_scale.exp()}
+        return image_features, text_features, visual_features, self.logit_scale.exp()

@@ -49,6 +49,10 @@ def gemm(a, w, bias=None, out=None, res=None, epi=EPI_BF16, act=ACT_NONE, alpha=
     N = w.shape[0]
     if w.shape[1] != K:
         raise ValueError(f"gemm: K mismatch {a.shape} vs {w.shape}")
+    if K % 64:   # kernels stream 64-wide K slabs: zero-pad odd reduction lengths (toy configs only)
+        Kp = (K + 63) // 64 * 64
+        a = torch.nn.functional.pad(a, (0, Kp - K)); w = torch.nn.functional.pad(w, (0, Kp - K))
+        K = Kp
     if out is None:
         n_out = N // 2 if epi == EPI_GEGLU else N
         odt = torch.float32 if epi in (EPI_F32, EPI_RES_F32) else torch.bfloat16
@@ -163,6 +167,13 @@ def transpose_to_bf16(x, ldo=None, out=None):
     if out is None:
         out = torch.empty(Cc, ldo, device=x.device, dtype=torch.bfloat16)
     check(_lib.vl_transpose_to_bf16(_p(x), _dt(x), x.stride(0), R, Cc, _p(out), ldo, _stream()))
+    return out
+
+
+def split_bf16x3(x, pattern):
+    _chk2d(x, "x", torch.float32)
+    out = torch.empty(x.shape[0], 3 * x.shape[1], device=x.device, dtype=torch.bfloat16)
+    check(_lib.vl_split_bf16x3(_p(x.contiguous()), _p(out), x.shape[0], x.shape[1], pattern, _stream()))
     return out
 
 

@@ -1,0 +1,170 @@
+"""One tri-modal contrastive training step (the reference's `tri_train_one_epoch` loop body,
+training/train.py:115-249) for the depth recipe, entirely on the HIP kernels:
+
+    image tower fwd (frozen) | text tower fwd (frozen) | Lens(depth)->ViT fwd (saved activations)
+      -> [one packed RCCL all-gather of img|txt|vis embeddings when world_size > 1]
+      -> TriClipLoss (logits GEMM + fused row/col CE) and its gradient w.r.t. the visual embeddings
+      -> backward through the visual tower (dX all blocks, dW for the unlocked first n + adapter)
+      -> [one flat RCCL all-reduce of the fp32 gradient buffer = DDP mean]
+      -> AdamW on the fp32 masters, bf16 operand refresh, logit_scale.clamp_(0, ln 100)
+
+Micro-batching follows the reference's feature-cache scheme (train.py:154-210): every micro-batch sees the
+full batch of negatives; here the activations of all micro-batches stay resident in the 288 GB of HBM so
+nothing is recomputed.
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .engine import LensCfg, LensEngine, TextCfg, TextEngine, TowerCfg, VitEngine
+from .train import AdamW, DepthLensTrainer
+
+
+# ------------------------------------------------------------------------------------------------ loss core
+def pair_forward(x, y, scale: float, label_off: int = 0, w_row: float = 0.5, w_col: float = 0.5):
+    """loss contribution w_row*CE(scale*x y^T) + w_col*CE(columns); returns (loss[1] tensor, ctx)."""
+    xb, yb = ops.split_bf16x3(x, 0), ops.split_bf16x3(y, 1)
+    logits = ops.gemm(xb, yb, None, epi=ops.EPI_F32, alpha=scale)
+    row_lse, col_lse, diag = ops.ce_stats(logits, label_off, want_cols=(w_col != 0.0))
+    loss = torch.zeros(1, device=x.device, dtype=torch.float32)
+    ops.ce_loss_accum(loss, row_lse if w_row != 0.0 else None, col_lse, diag, x.shape[0], y.shape[0], label_off, w_row, w_col)
+    return loss, (x, y, logits, row_lse, col_lse, label_off, w_row, w_col, scale)
+
+
+def pair_backward(ctx, g: float = 1.0, need_dx=True, need_dy=True):
+    x, y, logits, row_lse, col_lse, label_off, w_row, w_col, scale = ctx
+    dscale = torch.zeros(1, device=x.device, dtype=torch.float32)
+    G, GT = ops.ce_grad(logits, row_lse if w_row != 0.0 else None, col_lse, label_off, w_row * g, w_col * g, scale,
+                        dscale, need_g=need_dx, need_gt=need_dy)
+    dx = dy = None
+    if need_dx:
+        dx = ops.gemm(G, ops.transpose_to_bf16(y, ldo=G.shape[1]), None, epi=ops.EPI_F32, alpha=scale)
+    if need_dy:
+        dy = ops.gemm(GT, ops.transpose_to_bf16(x, ldo=GT.shape[1]), None, epi=ops.EPI_F32, alpha=scale)
+    return dx, dy, dscale
+
+
+class TriModalDepthStep:
+    def __init__(self, sd: Dict[str, torch.Tensor], tower: TowerCfg, text: TextCfg, device, micro_batch: int = 256,
+                 unlock_first_n: int = 4, lr: float = 5e-4, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2,
+                 rank: int = 0, world_size: int = 1, gemm_cfg: int = -1):
+        self.dev, self.mb, self.rank, self.world = torch.device(device), micro_batch, rank, world_size
+        self.image = VitEngine(sd, "image.", tower, device, gemm_cfg=gemm_cfg)
+        self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg)
+        self.lens = LensEngine(sd, "visual.", tower, LensCfg(modality="depth", perceiver_identity=True), device, gemm_cfg=gemm_cfg)
+        self.trainers = []            # one activation store per micro-batch (created lazily)
+        self.unlock_first_n = unlock_first_n
+        self.logit_scale = sd["logit_scale"].detach().float().reshape(1).to(device)
+        # fp32 masters of the trainable set (reference lock recipe: adapter + first n blocks + logit_scale)
+        self.masters: Dict[str, torch.Tensor] = {"logit_scale": self.logit_scale}
+        self.bf16_targets = {}
+        eng = self.lens.vit
+        for l in range(unlock_first_n):
+            p = f"visual.transformer.resblocks.{l}."
+            w = eng.blocks[l]
+            for nm, key in (("attn.in_proj_weight", "in_w"), ("attn.out_proj.weight", "out_w"), ("mlp.c_fc.weight", "fc_w"),
+                            ("mlp.c_proj.weight", "proj_w")):
+                self.masters[p + nm] = sd[p + nm].detach().float().to(device).contiguous()
+                self.bf16_targets[p + nm] = (l, key)
+            for nm, key in (("ln_1.weight", "ln1_w"), ("ln_1.bias", "ln1_b"), ("ln_2.weight", "ln2_w"), ("ln_2.bias", "ln2_b"),
+                            ("attn.in_proj_bias", "in_b"), ("attn.out_proj.bias", "out_b"), ("mlp.c_fc.bias", "fc_b"),
+                            ("mlp.c_proj.bias", "proj_b")):
+                self.masters[p + nm] = w[key]                   # f32 tensors the kernels read directly
+        self.masters["visual.visual_adapter.pos_emb"] = self.lens.adapter_pos
+        self.masters["visual.visual_adapter.conv1.weight_gemm"] = self.lens.conv_w.float()
+        self.opt = AdamW(self.masters, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.flat_grad = None
+        self.grads: Dict[str, torch.Tensor] = {}
+
+    # -------------------------------------------------------------------------------------------
+    def _trainer(self, i):
+        while len(self.trainers) <= i:
+            t = DepthLensTrainer(self.lens, unlock_first_n=self.unlock_first_n)
+            if self.trainers:                      # share weight transposes + gradient buffers across micro-batches
+                t.tower.wT = self.trainers[0].tower.wT
+                t.tower.proj = self.trainers[0].tower.proj
+                t.tower.grads = self.trainers[0].tower.grads
+            self.trainers.append(t)
+        return self.trainers[i]
+
+    def _alloc_flat_grads(self):
+        """All gradient buffers are views into ONE flat fp32 tensor -> a single all-reduce per step."""
+        n = sum(v.numel() for v in self.masters.values())
+        self.flat_grad = torch.zeros(n, device=self.dev, dtype=torch.float32)
+        off = 0
+        for k, v in self.masters.items():
+            self.grads[k] = self.flat_grad[off:off + v.numel()].view(v.shape)
+            off += v.numel()
+        for t in self.trainers:
+            t.tower.grads = self.grads
+        # trainers created later share the dict too
+        DepthLensTrainer._shared_grads = self.grads
+
+    def _refresh_operands(self):
+        eng = self.lens.vit
+        for name, (l, key) in self.bf16_targets.items():
+            m = self.masters[name]
+            ops.cast_bf16(m, out=eng.blocks[l][key])
+            ops.transpose_to_bf16(m, ldo=m.shape[0], out=self.trainers[0].tower.wT[l][key])
+        ops.cast_bf16(self.masters["visual.visual_adapter.conv1.weight_gemm"], out=self.lens.conv_w)
+
+    # -------------------------------------------------------------------------------------------
+    def step(self, images: torch.Tensor, texts: torch.Tensor, depths: torch.Tensor) -> torch.Tensor:
+        loss = self.forward_backward(images, texts, depths)
+        self.optimizer_step()
+        return loss
+
+    def optimizer_step(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)   # DDP: mean of per-rank gradients
+            self.opt.step(self.grads, grad_scale=1.0 / self.world)
+        else:
+            self.opt.step(self.grads)
+        self._refresh_operands()
+        ops.clamp_scalar(self.logit_scale, 0.0, math.log(100.0))
+
+    def forward_backward(self, images: torch.Tensor, texts: torch.Tensor, depths: torch.Tensor) -> torch.Tensor:
+        B = images.shape[0]
+        mb = min(self.mb, B)
+        assert B % mb == 0, "per-GPU batch must be a multiple of the micro-batch"
+        nmb = B // mb
+        if self.flat_grad is None:
+            for i in range(nmb):
+                self._trainer(i)
+            self._alloc_flat_grads()
+        self.flat_grad.zero_()
+        E = self.image.cfg.embed_dim
+        fi = torch.empty(B, E, device=self.dev); ft = torch.empty(B, E, device=self.dev)
+        fv = torch.empty(B, E, device=self.dev); vraw = torch.empty(B, E, device=self.dev)
+        vnorm = torch.empty(B, device=self.dev)
+        for i in range(nmb):
+            s = slice(i * mb, (i + 1) * mb)
+            ops.l2_normalize(self.image.encode_image(images[s]), out=fi[s])
+            ops.l2_normalize(self.text.encode_text(texts[s]), out=ft[s])
+            vraw[s] = self._trainer(i).forward(depths[s])
+        ops.l2_normalize(vraw, out=fv, norms=vnorm)
+        scale = float(self.logit_scale.exp())
+        if self.world > 1:
+            import torch.distributed as dist
+            packed = torch.cat([fi, ft, fv], dim=1)
+            allp = torch.empty(self.world * B, 3 * E, device=self.dev)
+            dist.all_gather_into_tensor(allp, packed)             # ONE exchange: [b, 3*768] per rank over xGMI
+            ai, at, av = [t.contiguous() for t in allp.split(E, dim=1)]
+        else:
+            ai, at, av = fi, ft, fv
+        l1, c1 = pair_forward(ai, av, scale)
+        l2, c2 = pair_forward(at, av, scale)
+        loss = l1 + l2
+        _, dv1, ds1 = pair_backward(c1, need_dx=False)
+        _, dv2, ds2 = pair_backward(c2, need_dx=False)
+        dv = dv1 + dv2                                            # d loss / d all_visual  [W*B, E]
+        dv_local = dv[self.rank * B:(self.rank + 1) * B].contiguous()   # peers carry no grad (loss.py:71-74)
+        dvraw = ops.l2_normalize_bwd(fv, dv_local, vnorm)
+        for i in range(nmb):
+            self._trainer(i).backward(dvraw[i * mb:(i + 1) * mb].contiguous())
+        # logit_scale is exp()'d in forward (model.py:619): d/d(log-scale) = dscale * scale
+        self.grads["logit_scale"] += (ds1 + ds2) * scale
+        return loss
