@@ -36,6 +36,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define VL_EPI_DGELU 6    /* out bf16[M,N]   = alpha*acc * gelu'(res bf16[M,N])  (dX through GELU) */
 #define VL_ACT_NONE 0
 #define VL_ACT_GELU 1     /* exact-erf GELU (nn.GELU default)                            */
+#define VL_ACT_RELU 2
 
 /* dtype tags for mixed-dtype entry points */
 #define VL_F32 0
@@ -64,10 +65,12 @@ int vl_gemm_qkv_bf16(const void* A, const void* Win, const float* bias, void* q,
                      int B, int L, int H, int dh, int Lp, int K, int lda, float qscale, int first,
                      int count, int cfg, hipStream_t stream);
 int vl_gemm_set_persist_variant(int v);
-/* vl_gemm_bf16 + `out2`: with VL_EPI_BF16/VL_ACT_GELU also stores the pre-activation (bf16) for the backward. */
+/* vl_gemm_bf16 + `out2` (with VL_EPI_BF16/VL_ACT_GELU also stores the pre-activation, bf16, for the
+ * backward) + `res_div` (VL_EPI_RES_BF16: residual row = m / res_div, i.e. one row broadcast over a group:
+ * the PointNet concat([global, local]) conv of dvae.py:207-210 split into two GEMMs). */
 int vl_gemm_bf16_ex(const void* A, const void* W, const float* bias, void* out, const void* res, void* out2,
                     int M, int N, int K, int lda, int ldw, int ldo, float alpha, int epi, int act,
-                    int cfg, hipStream_t stream);
+                    int res_div, int cfg, hipStream_t stream);
 /* vl_gemm_qkv_bf16 + optional extra layouts kept for the attention backward:
  * qt,kt [B,H,dh,Lp] (transposed q/k), v [B,H,L,dh] (row-major v).  Any output pointer may be NULL. */
 int vl_gemm_qkv_bf16_ex(const void* A, const void* Win, const float* bias, void* q, void* k, void* vt,
@@ -162,6 +165,16 @@ int vl_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* qt
                      int B, int H, int Lq, int Lk, int Lqp, int Lkp, int dh, int causal, float scale,
                      hipStream_t stream);
 /* torch.optim.AdamW step on one tensor (grad is multiplied by grad_scale first); step counts from 1. */
+/* ---- point-cloud tokenizer (PointBERT grouping) ---- */
+/* farthest point sampling: xyz [B,N,3] f32, start [B] (the reference draws it with torch.randint, misc.py:60);
+ * idx [B,G] int64 (bit-exact vs misc.fps), centers [B,G,3] optional. */
+int vl_fps(const float* xyz, const int64_t* start, int64_t* idx, float* centers, int B, int N, int G, hipStream_t stream);
+/* k nearest neighbours of each centre (set semantics = topk(sorted=False), dvae.py:107-118) + gather +
+ * centre subtraction: nidx [B,G,k] int32 optional, patches bf16 [B*G*k, Kp] optional (xyz in cols 0..2). */
+int vl_knn_group(const float* xyz, const int64_t* center_idx, int* nidx, void* patches, int B, int N, int G,
+                 int k, int Kp, hipStream_t stream);
+int vl_group_max(const void* x, long ldx, void* out, int out_dtype, long ldo, long groups, int M, int C, hipStream_t stream);
+int vl_pad3_bf16(const float* c, void* out, long R, int Kp, hipStream_t stream);
 int vl_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, float grad_scale, hipStream_t stream);
 int vl_clamp_scalar(float* p, float lo, float hi, hipStream_t stream);

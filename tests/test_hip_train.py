@@ -54,7 +54,7 @@ def test_depth_tower_backward_vs_reference_grads():
         if name.endswith("conv1.weight_gemm"):
             ref = grads["visual.visual_adapter.conv1.weight"].reshape(g.shape[0], -1)
             got = g[:, :ref.shape[1]]
-            assert float(g[:, ref.shape[1]:].abs().max()) == 0.0
+            assert g.shape[1] == ref.shape[1] or float(g[:, ref.shape[1]:].abs().max()) == 0.0
         else:
             ref, got = grads[name], g
         assert got.shape == ref.shape, name

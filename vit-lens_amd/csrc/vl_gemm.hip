@@ -37,7 +37,8 @@ struct GemmP {
   int M, N, K;
   int lda, ldw, ldo; // row strides in elements
   float alpha;
-  int act;           // 0 none, 1 gelu(erf)
+  int act;           // 0 none, 1 gelu(erf), 2 relu
+  int res_div;       // residual row = m / res_div (>=1): broadcast one row over a group of res_div rows
   // QKV scatter
   bf16_t *q, *k, *vt;
   bf16_t *qt, *kt, *v;   // optional extra layouts for the attention backward (transposed q/k, row-major v)
@@ -62,29 +63,61 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
+// The epilogue parameters (pointers, strides, scatter geometry) are re-read from the kernarg segment through an
+// opaque pointer at the moment a tile is stored.  Without this the compiler keeps ~40 scalars live across
+// the whole k-loop and spills SGPRs to scratch INSIDE it (measured: QKV-scatter GEMM 0.60 -> 2.49 ms).
+typedef const __attribute__((address_space(4))) GemmP* KernargP;
+__device__ __forceinline__ GemmP reload_params() {
+  GemmP r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  KernargP kp = (KernargP)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp));
+  __builtin_memcpy(&r, (const void*)kp, sizeof(GemmP));
+#endif
+  return r;
+}
+
 // ---- epilogue: lane owns row m = mrow0 + 32*i + fr, columns n = ncol0 + 32*j + 8*q + 4*fg + {0..3} ----
 template <int EPI, int MT, int NTL>
 __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL], int mrow0, int ncol0, int fr, int fg) {
+  // per-row (per-lane) quantities first, then columns OUTER / rows INNER: the wave-uniform column
+  // quantities (bias, q/k/v part, head) are consumed immediately instead of staying live in SGPRs.
+  int mrow[MT];
+  [[maybe_unused]] int qb[MT], ql[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int m = mrow0 + i * 32 + fr;
-    if (m >= p.M) continue;
-    [[maybe_unused]] int qb = 0, ql = 0;
-    if constexpr (EPI == EPI_QKV) { const int ma = m + p.m_off; qb = ma / p.L; ql = ma - qb * p.L; }
+    mrow[i] = mrow0 + i * 32 + fr;
+    if constexpr (EPI == EPI_QKV) { const int ma = mrow[i] + p.m_off; qb[i] = ma / p.L; ql[i] = ma - qb[i] * p.L; }
+  }
 #pragma unroll
-    for (int j = 0; j < NTL; ++j) {
+  for (int j = 0; j < NTL; ++j) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = ncol0 + j * 32 + q * 8 + fg * 4;
-        if (n >= p.N) continue;
+    for (int q = 0; q < 4; ++q) {
+      const int n = ncol0 + j * 32 + q * 8 + fg * 4;
+      if (n >= p.N) continue;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bv = *(const f32x4*)(p.bias + n);
+      [[maybe_unused]] int which = 0, hh = 0, dd = 0;
+      [[maybe_unused]] bf16_t* rowsel = nullptr; [[maybe_unused]] bf16_t* colsel = nullptr;
+      if constexpr (EPI == EPI_QKV) {
+        // head-dim % 8 == 0: (part, head) are wave-uniform for this 8-column group -> scalar ALU
+        const int nu = ncol0 + j * 32 + q * 8;
+        const int D = p.H * p.dh;
+        const int wq = nu / D;
+        const int c = nu - wq * D;
+        which = wq + p.which0; hh = c / p.dh; dd = c - hh * p.dh + fg * 4;
+        bf16_t* const pq = p.q; bf16_t* const pk = p.k; bf16_t* const pv = p.v;
+        bf16_t* const pqt = p.qt; bf16_t* const pkt = p.kt; bf16_t* const pvt = p.vt;
+        rowsel = which == 0 ? pq : (which == 1 ? pk : pv);
+        colsel = which == 0 ? pqt : (which == 1 ? pkt : pvt);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = mrow[i];
+        if (m >= p.M) continue;
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e] * p.alpha;
-        if (p.bias) {
-          const f32x4 b = *(const f32x4*)(p.bias + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += b[e];
-        }
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[i][j][q * 4 + e], p.alpha, bv[e]);
         if constexpr (EPI == EPI_BF16) {
           if (p.act == 1) {
             if (p.out2) {
@@ -93,6 +126,9 @@ __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+          } else if (p.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
           }
           u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
           *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
@@ -104,9 +140,13 @@ __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL
           f32x4 o = {v[0] + r[0], v[1] + r[1], v[2] + r[2], v[3] + r[3]};
           *(f32x4*)((float*)p.out + (size_t)m * p.ldo + n) = o;
         } else if constexpr (EPI == EPI_RES_BF16) {
-          const u32x2 r = *(const u32x2*)((const bf16_t*)p.res + (size_t)m * p.ldo + n);
+          const u32x2 r = *(const u32x2*)((const bf16_t*)p.res + (size_t)((m + p.m_off) / p.res_div) * p.ldo + n);
           v[0] += bf2f((bf16_t)(r[0] & 0xffff)); v[1] += bf2f((bf16_t)(r[0] >> 16));
           v[2] += bf2f((bf16_t)(r[1] & 0xffff)); v[3] += bf2f((bf16_t)(r[1] >> 16));
+          if (p.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
           u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
           *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
         } else if constexpr (EPI == EPI_DGELU) {
@@ -116,42 +156,22 @@ __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL
           u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
           *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
         } else if constexpr (EPI == EPI_QKV) {
-          // head-dim % 8 == 0: (which, head) are wave-uniform for the 8-column group -> SALU divides
-          const int nu = ncol0 + j * 32 + q * 8;
-          const int D = p.H * p.dh;
-          const int wq = nu / D;
-          const int c = nu - wq * D;
-          const int which = wq + p.which0;
-          const int h = c / p.dh, d = c - h * p.dh + fg * 4;
-          const size_t bh = (size_t)qb * p.H + h;
+          const size_t bh = (size_t)qb[i] * p.H + hh;
+          const size_t row_off = (bh * p.L + ql[i]) * p.dh + dd;      // [B,H,L,dh] layouts
+          const size_t col_off = (bh * p.dh + dd) * p.Lp + ql[i];     // [B,H,dh,Lp] layouts
+          bf16_t* rowp = rowsel;
+          bf16_t* colp = colsel;
           if (which == 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= p.qscale;
+          }
+          if (rowp) {
             u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-            if (p.q) *(u32x2*)(p.q + (bh * p.L + ql) * p.dh + d) = o;
-            if (p.qt) {
-              bf16_t* dst = p.qt + (bh * p.dh + d) * p.Lp + ql;
+            *(u32x2*)(rowp + row_off) = o;
+          }
+          if (colp) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) dst[(size_t)e * p.Lp] = f2bf(v[e]);
-            }
-          } else if (which == 1) {
-            u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-            if (p.k) *(u32x2*)(p.k + (bh * p.L + ql) * p.dh + d) = o;
-            if (p.kt) {
-              bf16_t* dst = p.kt + (bh * p.dh + d) * p.Lp + ql;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) dst[(size_t)e * p.Lp] = f2bf(v[e]);
-            }
-          } else {
-            if (p.vt) {
-              bf16_t* dst = p.vt + (bh * p.dh + d) * p.Lp + ql;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) dst[(size_t)e * p.Lp] = f2bf(v[e]);
-            }
-            if (p.v) {
-              u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-              *(u32x2*)(p.v + (bh * p.L + ql) * p.dh + d) = o;
-            }
+            for (int e = 0; e < 4; ++e) colp[col_off + (size_t)e * p.Lp] = f2bf(v[e]);
           }
         } else if constexpr (EPI == EPI_GEGLU) {
           // interleaved rows: (a_j, gate_j, a_j+1, gate_j+1)
@@ -275,7 +295,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
     __syncthreads();
   }
 
-  store_tile<EPI, MT, NTL>(p, acc, m0 + wave_m * WTM, n0 + wave_n * WTN, fr, fg);
+  { const GemmP pe = reload_params(); store_tile<EPI, MT, NTL>(pe, acc, m0 + wave_m * WTM, n0 + wave_n * WTN, fr, fg); }
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, bool DMA>
@@ -428,7 +448,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
     }
     // ---- tile finished: store and reset (the next tile's first slab is already in flight) ----
     if (kt + 1 == nk) {
-      store_tile<EPI, MT, NTL>(p, acc, cur_m0 + wave_m * WTM, cur_n0 + wave_n * WTN, fr, fg);
+      { const GemmP pe = reload_params(); store_tile<EPI, MT, NTL>(pe, acc, cur_m0 + wave_m * WTM, cur_n0 + wave_n * WTN, fr, fg); }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -576,7 +596,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
     __builtin_amdgcn_sched_barrier(0);
 
     if (kt + 1 == nk) {
-      store_tile<EPI, MT, NTL>(p, acc, cur_m0 + wave_m * WTM, cur_n0 + wave_n * WTN, fr, fg);
+      { const GemmP pe = reload_params(); store_tile<EPI, MT, NTL>(pe, acc, cur_m0 + wave_m * WTM, cur_n0 + wave_n * WTN, fr, fg); }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -669,7 +689,7 @@ static hipError_t run_gemm(const GemmP& p, int cfg, hipStream_t s) {
   pr.A = p.A + (size_t)rows_main * p.lda;
   constexpr size_t osz = (EPI == EPI_F32 || EPI == EPI_RES_F32) ? 4 : 2;
   if (p.out) pr.out = (unsigned char*)p.out + (size_t)rows_main * p.ldo * osz;
-  if (p.res) pr.res = (const unsigned char*)p.res + (size_t)rows_main * p.ldo * osz;
+  if (p.res && p.res_div <= 1) pr.res = (const unsigned char*)p.res + (size_t)rows_main * p.ldo * osz;
   return dispatch<EPI>(pr, 1, s);
 }
 
@@ -677,16 +697,18 @@ static hipError_t run_gemm(const GemmP& p, int cfg, hipStream_t s) {
 
 extern "C" int vl_gemm_bf16_ex(const void* A, const void* W, const float* bias, void* out, const void* res, void* out2,
                                int M, int N, int K, int lda, int ldw, int ldo, float alpha, int epi, int act,
-                               int cfg, hipStream_t stream);
+                               int res_div, int cfg, hipStream_t stream);
 extern "C" int vl_gemm_bf16(const void* A, const void* W, const float* bias, void* out, const void* res,
                             int M, int N, int K, int lda, int ldw, int ldo, float alpha, int epi, int act,
                             int cfg, hipStream_t stream) {
-  return vl_gemm_bf16_ex(A, W, bias, out, res, nullptr, M, N, K, lda, ldw, ldo, alpha, epi, act, cfg, stream);
+  return vl_gemm_bf16_ex(A, W, bias, out, res, nullptr, M, N, K, lda, ldw, ldo, alpha, epi, act, 1, cfg, stream);
 }
 
 extern "C" int vl_gemm_bf16_ex(const void* A, const void* W, const float* bias, void* out, const void* res, void* out2,
                                int M, int N, int K, int lda, int ldw, int ldo, float alpha, int epi, int act,
-                               int cfg, hipStream_t stream) {
+                               int res_div, int cfg, hipStream_t stream) {
+  VL_CHECK_ARG(res_div >= 1, "vl_gemm_bf16: res_div must be >= 1");
+  VL_CHECK_ARG(res_div == 1 || epi == VL_EPI_RES_BF16, "vl_gemm_bf16: row-broadcast residual needs VL_EPI_RES_BF16");
   VL_CHECK_ARG(M > 0 && N > 0 && K > 0, "vl_gemm_bf16: empty problem");
   VL_CHECK_ARG((K & 63) == 0, "vl_gemm_bf16: K must be a multiple of 64");
   VL_CHECK_ARG((N & 3) == 0, "vl_gemm_bf16: N must be a multiple of 4");
@@ -694,7 +716,7 @@ extern "C" int vl_gemm_bf16_ex(const void* A, const void* W, const float* bias, 
   VL_CHECK_ARG((ldo & 3) == 0, "vl_gemm_bf16: ldo must be a multiple of 4");
   GemmP p{};
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = bias; p.out = out; p.res = res; p.out2 = out2;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.alpha = alpha; p.act = act;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.alpha = alpha; p.act = act; p.res_div = res_div;
   hipError_t e;
   switch (epi) {
     case VL_EPI_BF16: e = run_gemm<EPI_BF16>(p, cfg, stream); break;
@@ -729,7 +751,7 @@ extern "C" int vl_gemm_qkv_bf16_ex(const void* A, const void* W, const float* bi
   VL_CHECK_ARG(Lp >= L, "vl_gemm_qkv_bf16: Lp < L");
   GemmP p{};
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = bias;
-  p.M = B * L; p.N = count * H * dh; p.K = K; p.which0 = first; p.lda = lda; p.ldw = K; p.ldo = 0; p.alpha = 1.f;
+  p.M = B * L; p.N = count * H * dh; p.K = K; p.which0 = first; p.res_div = 1; p.lda = lda; p.ldw = K; p.ldo = 0; p.alpha = 1.f;
   p.q = (bf16_t*)q; p.k = (bf16_t*)k; p.vt = (bf16_t*)vt; p.qt = (bf16_t*)qt; p.kt = (bf16_t*)kt; p.v = (bf16_t*)v; p.L = L; p.H = H; p.dh = dh; p.Lp = Lp; p.qscale = qscale;
   hipError_t e = run_gemm<EPI_QKV>(p, cfg, stream);
   if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));

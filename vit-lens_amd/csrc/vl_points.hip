@@ -1,0 +1,213 @@
+// Point-cloud grouping for the PointBERT tokenizer of the 3D Lens (latency-bound integer/index work).
+//
+//   vl_fps        farthest-point sampling, bit-exact restatement of misc.fps
+//                 (open_clip/modal_3d/models/pointbert/misc.py:48-68): one workgroup per cloud keeps
+//                 every point and its running min-distance in REGISTERS for all `npoint` dependent
+//                 iterations (the reference launches ~6 tiny kernels per iteration); the argmax is a
+//                 wave shuffle + one LDS hop; ties resolve to the lowest index like torch.max.
+//                 Distances are computed as ((dx*dx + dy*dy) + dz*dz) with every operation rounded
+//                 separately (no FMA contraction) to reproduce the CPU reference's fp32 values.
+//   vl_knn_group  k nearest points of every centre with the reference's expanded distance
+//                 -2ab + |a|^2 + |b|^2 (dvae.py:107-140) via an exact radix select of the k-th smallest
+//                 key (no sort, no N x G distance matrix in HBM), then gather + centre-subtract
+//                 (Group.forward, dvae.py:150-176) straight into the bf16 GEMM operand of the first conv.
+//   vl_group_max  max over the points of a group (torch.max(feature, dim=2), dvae.py:206,211)
+#include "vl_common.h"
+#include "vitlens_hip.h"
+
+namespace {
+
+constexpr int FPS_THREADS = 1024;
+
+template <int PPT>
+__global__ void __launch_bounds__(FPS_THREADS) fps_kernel(const float* xyz, const int64_t* start, int64_t* out_idx,
+                                                          float* centers, int N, int G) {
+  __shared__ float s_val[16];
+  __shared__ int s_idx[16];
+  __shared__ int s_win;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* P = xyz + (size_t)b * N * 3;
+  float px[PPT], py[PPT], pz[PPT], dist[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int i = tid + k * FPS_THREADS;
+    if (i < N) { px[k] = P[i * 3]; py[k] = P[i * 3 + 1]; pz[k] = P[i * 3 + 2]; dist[k] = 1e10f; }
+    else { px[k] = py[k] = pz[k] = 0.f; dist[k] = -1.f; }   // never selected: real distances are >= 0
+  }
+  int far = (int)start[b];
+  for (int it = 0; it < G; ++it) {
+    if (tid == 0) {
+      out_idx[(size_t)b * G + it] = far;
+      if (centers) { float* c = centers + ((size_t)b * G + it) * 3; c[0] = P[far * 3]; c[1] = P[far * 3 + 1]; c[2] = P[far * 3 + 2]; }
+    }
+    const float cx = P[far * 3], cy = P[far * 3 + 1], cz = P[far * 3 + 2];
+    float best = -2.f; int besti = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const int i = tid + k * FPS_THREADS;
+      if (i < N) {
+        const float dx = __fsub_rn(px[k], cx), dy = __fsub_rn(py[k], cy), dz = __fsub_rn(pz[k], cz);
+        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        const float m = fminf(dist[k], d);
+        dist[k] = m;
+        if (m > best) { best = m; besti = i; }      // increasing i within a thread: strict > keeps the lowest index
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v2 = __shfl_xor(best, o, 64); const int i2 = __shfl_xor(besti, o, 64);
+      if (v2 > best || (v2 == best && i2 < besti)) { best = v2; besti = i2; }
+    }
+    if (lane == 0) { s_val[wv] = best; s_idx[wv] = besti; }
+    __syncthreads();
+    if (wv == 0) {
+      float v = lane < 16 ? s_val[lane] : -3.f; int i = lane < 16 ? s_idx[lane] : 0x7fffffff;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        const float v2 = __shfl_xor(v, o, 64); const int i2 = __shfl_xor(i, o, 64);
+        if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+      }
+      if (lane == 0) s_win = i;
+    }
+    __syncthreads();
+    far = s_win;
+  }
+}
+
+__device__ __forceinline__ unsigned int sort_key(float f) {
+  const unsigned int u = __builtin_bit_cast(unsigned int, f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// one wave per centre; the N sortable distance keys of the wave live in LDS (conflict-free lane-strided access)
+__global__ void __launch_bounds__(256) knn_group_kernel(const float* xyz, const int64_t* cidx, int N, int G, int k,
+                                                        int* nidx, bf16_t* patches, int Kp) {
+  extern __shared__ unsigned int s_keys[];
+  const int lane = threadIdx.x & 63;
+  unsigned int* key = s_keys + (size_t)(threadIdx.x >> 6) * N;
+  const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);        // global centre index b*G + g
+  const int b = (int)(w / G);
+  const float* P = xyz + (size_t)b * N * 3;
+  const int ci = (int)cidx[w];
+  const float cx = P[ci * 3], cy = P[ci * 3 + 1], cz = P[ci * 3 + 2];
+  const float cc = __fadd_rn(__fadd_rn(__fmul_rn(cx, cx), __fmul_rn(cy, cy)), __fmul_rn(cz, cz));
+  const int npl = N >> 6;
+  for (int j = 0; j < npl; ++j) {
+    const int i = lane + j * 64;
+    const float x = P[i * 3], y = P[i * 3 + 1], z = P[i * 3 + 2];
+    const float dot = fmaf(cz, z, fmaf(cy, y, cx * x));
+    const float pp = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+    const float d = __fadd_rn(__fadd_rn(-2.0f * dot, cc), pp);      // dist = -2ab; dist += |a|^2; dist += |b|^2
+    key[i] = sort_key(d);
+  }
+  // largest T with count(key < T) < k  ==  k-th smallest key   (each lane only re-reads its own LDS words)
+  unsigned int T = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned int trial = T | (1u << bit);
+    int c = 0;
+    for (int j = 0; j < npl; ++j) c += key[lane + j * 64] < trial;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (c < k) T = trial;
+  }
+  int nless = 0;
+  for (int j = 0; j < npl; ++j) nless += key[lane + j * 64] < T;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nless += __shfl_xor(nless, o, 64);
+  int need_eq = k - nless;                                   // ties at the k-th distance: lowest indices first
+  int base = 0;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int j = 0; j < npl; ++j) {
+    const int i = lane + j * 64;
+    const unsigned int kj = key[i];
+    const bool less = kj < T;
+    const bool eq = kj == T;
+    const unsigned long long bl = __ballot(less), be = __ballot(eq);
+    const int eq_rank = __popcll(be & lt_mask);
+    const bool take_eq = eq && eq_rank < need_eq;
+    const unsigned long long bt = bl | __ballot(take_eq);
+    const bool take = less || take_eq;
+    if (take) {
+      const int slot = base + __popcll(bt & lt_mask);
+      if (nidx) nidx[w * k + slot] = i;
+      if (patches) {
+        bf16_t* o = patches + ((size_t)w * k + slot) * Kp;
+        o[0] = f2bf(__fsub_rn(P[i * 3], cx)); o[1] = f2bf(__fsub_rn(P[i * 3 + 1], cy)); o[2] = f2bf(__fsub_rn(P[i * 3 + 2], cz));
+        for (int e = 3; e < Kp; ++e) o[e] = 0;
+      }
+    }
+    base += __popcll(bt);
+    need_eq -= min(need_eq, __popcll(be));
+  }
+}
+
+// out[g, c] = max_{m < M} x[g*M + m, c]
+template <typename TOUT>
+__global__ void __launch_bounds__(256) group_max_kernel(const bf16_t* x, long ldx, TOUT* out, long ldo, long groups, int M, int C) {
+  const long n = groups * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long g = i / C; const int c = (int)(i - g * C);
+    float m = -INFINITY;
+    for (int r = 0; r < M; ++r) m = fmaxf(m, bf2f(x[(g * M + r) * ldx + c]));
+    if constexpr (sizeof(TOUT) == 4) out[g * ldo + c] = m; else out[g * ldo + c] = f2bf(m);
+  }
+}
+
+// centres [R,3] f32 -> bf16 [R,Kp] zero padded (operand of the pos_embed MLP's first Linear)
+__global__ void __launch_bounds__(256) pad3_kernel(const float* c, bf16_t* out, long R, int Kp) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < R * Kp; i += (long)gridDim.x * 256) {
+    const long r = i / Kp; const int e = (int)(i - r * Kp);
+    out[i] = e < 3 ? f2bf(c[r * 3 + e]) : (bf16_t)0;
+  }
+}
+
+}  // namespace
+
+extern "C" int vl_set_error(const char* msg);
+#define VL_HIP_OK(e) do { hipError_t _e = (e); if (_e != hipSuccess) return vl_set_error(hipGetErrorString(_e)); } while (0)
+static int grid_for(long n) { long g = (n + 255) / 256; return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
+
+extern "C" int vl_fps(const float* xyz, const int64_t* start, int64_t* idx, float* centers, int B, int N, int G,
+                      hipStream_t stream) {
+  if (B <= 0 || N <= 0 || G <= 0 || G > N) return vl_set_error("vl_fps: bad shape");
+  const int ppt = (N + FPS_THREADS - 1) / FPS_THREADS;
+  if (ppt <= 1) hipLaunchKernelGGL(fps_kernel<1>, dim3(B), dim3(FPS_THREADS), 0, stream, xyz, start, idx, centers, N, G);
+  else if (ppt <= 2) hipLaunchKernelGGL(fps_kernel<2>, dim3(B), dim3(FPS_THREADS), 0, stream, xyz, start, idx, centers, N, G);
+  else if (ppt <= 4) hipLaunchKernelGGL(fps_kernel<4>, dim3(B), dim3(FPS_THREADS), 0, stream, xyz, start, idx, centers, N, G);
+  else if (ppt <= 8) hipLaunchKernelGGL(fps_kernel<8>, dim3(B), dim3(FPS_THREADS), 0, stream, xyz, start, idx, centers, N, G);
+  else if (ppt <= 16) hipLaunchKernelGGL(fps_kernel<16>, dim3(B), dim3(FPS_THREADS), 0, stream, xyz, start, idx, centers, N, G);
+  else return vl_set_error("vl_fps: at most 16384 points per cloud");
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vl_knn_group(const float* xyz, const int64_t* center_idx, int* nidx, void* patches, int B, int N, int G,
+                            int k, int Kp, hipStream_t stream) {
+  if (B <= 0 || G <= 0 || k <= 0 || k > N) return vl_set_error("vl_knn_group: bad shape");
+  if ((N & 63) || ((long)B * G) % 4) return vl_set_error("vl_knn_group: N must be a multiple of 64 and B*G of 4");
+  if (patches && Kp < 3) return vl_set_error("vl_knn_group: Kp < 3");
+  const dim3 grid((unsigned)(((long)B * G) / 4)), block(256);
+  const size_t smem = (size_t)4 * N * sizeof(unsigned int);
+  if (smem > 160 * 1024) return vl_set_error("vl_knn_group: at most 10240 points per cloud");
+  static bool attr = false;
+  if (!attr) { VL_HIP_OK(hipFuncSetAttribute((const void*)knn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+  hipLaunchKernelGGL(knn_group_kernel, grid, block, smem, stream, xyz, center_idx, N, G, k, nidx, (bf16_t*)patches, Kp);
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vl_group_max(const void* x, long ldx, void* out, int out_dtype, long ldo, long groups, int M, int C,
+                            hipStream_t stream) {
+  if (groups <= 0 || M <= 0 || C <= 0) return vl_set_error("vl_group_max: bad shape");
+  if (out_dtype == VL_F32) hipLaunchKernelGGL(group_max_kernel<float>, dim3(grid_for(groups * C)), dim3(256), 0, stream, (const bf16_t*)x, ldx, (float*)out, ldo, groups, M, C);
+  else hipLaunchKernelGGL(group_max_kernel<bf16_t>, dim3(grid_for(groups * C)), dim3(256), 0, stream, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, groups, M, C);
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vl_pad3_bf16(const float* c, void* out, long R, int Kp, hipStream_t stream) {
+  if (R <= 0 || Kp < 3) return vl_set_error("vl_pad3_bf16: bad shape");
+  hipLaunchKernelGGL(pad3_kernel, dim3(grid_for(R * Kp)), dim3(256), 0, stream, c, (bf16_t*)out, R, Kp);
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}

@@ -37,7 +37,11 @@ SIGNATURES = {
     "vl_ce_stats": [P, L, I, I, I, P, P, P, P, P],
     "vl_ce_loss_accum": [P, P, P, I, I, I, F, F, P, P],
     "vl_ce_grad": [P, L, I, I, I, P, P, F, F, P, L, P, L, F, P, P],
-    "vl_gemm_bf16_ex": [P, P, P, P, P, P, I, I, I, I, I, I, F, I, I, I, P],
+    "vl_gemm_bf16_ex": [P, P, P, P, P, P, I, I, I, I, I, I, F, I, I, I, I, P],
+    "vl_fps": [P, P, P, P, I, I, I, P],
+    "vl_knn_group": [P, P, P, P, I, I, I, I, I, P],
+    "vl_group_max": [P, L, P, I, L, L, I, I, P],
+    "vl_pad3_bf16": [P, P, L, I, P],
     "vl_gemm_qkv_bf16_ex": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, I, I, P],
     "vl_layernorm_bwd": [P, I, L, P, I, L, P, P, P, P, P, P, L, I, I, P],
     "vl_layernorm_bwd_params": [P, I, L, P, I, L, P, P, P, P, I, I, P],

@@ -9,7 +9,7 @@ from ._lib import load_library, check
 
 F32, BF16 = 0, 1
 EPI_BF16, EPI_F32, EPI_RES_F32, EPI_RES_BF16, EPI_GEGLU, EPI_DGELU = 0, 1, 2, 3, 5, 6
-ACT_NONE, ACT_GELU = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 LOG2E = 1.4426950408889634
 
 _lib = load_library()
@@ -42,7 +42,7 @@ def _chk2d(t, name, dtype=None):
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
 
 
-def gemm(a, w, bias=None, out=None, res=None, epi=EPI_BF16, act=ACT_NONE, alpha=1.0, cfg=-1, out2=None):
+def gemm(a, w, bias=None, out=None, res=None, epi=EPI_BF16, act=ACT_NONE, alpha=1.0, cfg=-1, out2=None, res_div=1):
     """out = epilogue(a @ w.T).  a [M,K] bf16, w [N,K] bf16.  out2: optional pre-activation copy (bf16)."""
     _chk2d(a, "a", torch.bfloat16); _chk2d(w, "w", torch.bfloat16)
     M, K = a.shape
@@ -62,12 +62,14 @@ def gemm(a, w, bias=None, out=None, res=None, epi=EPI_BF16, act=ACT_NONE, alpha=
         _chk2d(res, "res")
         if res.stride(0) != out.stride(0) or res.dtype != out.dtype:
             raise ValueError("gemm: residual must share out's row stride and dtype")
+        if res_div > 1 and res.shape[0] * res_div < M:
+            raise ValueError("gemm: broadcast residual has too few rows")
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N):
         raise ValueError("gemm: bias must be f32 [N]")
     if out2 is not None and (out2.stride(0) != out.stride(0) or out2.dtype != torch.bfloat16):
         raise ValueError("gemm: out2 must be bf16 with out's row stride")
     check(_lib.vl_gemm_bf16_ex(_p(a), _p(w), _p(bias), _p(out), _p(res), _p(out2), M, N, K, a.stride(0), w.stride(0),
-                               out.stride(0), float(alpha), epi, act, cfg, _stream()))
+                               out.stride(0), float(alpha), epi, act, res_div, cfg, _stream()))
     return out
 
 
@@ -271,3 +273,36 @@ def axpy(y, x, alpha=1.0):
 
 def batch_rowsum(x, out, B, T, D, batch_stride_rows, row_offset):
     check(_lib.vl_batch_rowsum(_p(x), _p(out), B, T, D, batch_stride_rows, row_offset, _stream()))
+
+
+# ------------------------------------------------------------------------------------------------ point clouds
+def fps(xyz, start, G, want_centers=True):
+    B, N, _ = xyz.shape
+    idx = torch.empty(B, G, device=xyz.device, dtype=torch.int64)
+    centers = torch.empty(B, G, 3, device=xyz.device, dtype=torch.float32) if want_centers else None
+    check(_lib.vl_fps(_p(xyz.contiguous()), _p(start.contiguous()), _p(idx), _p(centers), B, N, G, _stream()))
+    return idx, centers
+
+
+def knn_group(xyz, center_idx, k, Kp=64, want_idx=False):
+    B, N, _ = xyz.shape
+    G = center_idx.shape[1]
+    nidx = torch.empty(B, G, k, device=xyz.device, dtype=torch.int32) if want_idx else None
+    patches = torch.empty(B * G * k, Kp, device=xyz.device, dtype=torch.bfloat16)
+    check(_lib.vl_knn_group(_p(xyz.contiguous()), _p(center_idx.contiguous()), _p(nidx), _p(patches), B, N, G, k, Kp, _stream()))
+    return patches, nidx
+
+
+def group_max(x, M, out_dtype=torch.bfloat16):
+    _chk2d(x, "x", torch.bfloat16)
+    groups = x.shape[0] // M
+    out = torch.empty(groups, x.shape[1], device=x.device, dtype=out_dtype)
+    check(_lib.vl_group_max(_p(x), x.stride(0), _p(out), _dt(out), out.stride(0), groups, M, x.shape[1], _stream()))
+    return out
+
+
+def pad3(c, Kp=64):
+    c = c.reshape(-1, 3).contiguous()
+    out = torch.empty(c.shape[0], Kp, device=c.device, dtype=torch.bfloat16)
+    check(_lib.vl_pad3_bf16(_p(c), _p(out), c.shape[0], Kp, _stream()))
+    return out
