@@ -42,7 +42,7 @@ struct GemmP {
   // QKV scatter
   bf16_t *q, *k, *vt;
   bf16_t *qt, *kt, *v;   // optional extra layouts for the attention backward (transposed q/k, row-major v)
-  int L, H, dh, Lp;
+  int L, H, dh, Lp, dh_shift;
   int which0;        // first part produced by this GEMM: 0 = q, 1 = k, 2 = v
   float qscale;
   int m_off;         // absolute row of local row 0 (QKV scatter of a row-split launch)
@@ -80,44 +80,36 @@ __device__ __forceinline__ GemmP reload_params() {
 // ---- epilogue: lane owns row m = mrow0 + 32*i + fr, columns n = ncol0 + 32*j + 8*q + 4*fg + {0..3} ----
 template <int EPI, int MT, int NTL>
 __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL], int mrow0, int ncol0, int fr, int fg) {
-  // per-row (per-lane) quantities first, then columns OUTER / rows INNER: the wave-uniform column
-  // quantities (bias, q/k/v part, head) are consumed immediately instead of staying live in SGPRs.
-  int mrow[MT];
-  [[maybe_unused]] int qb[MT], ql[MT];
+  // rows OUTER: a lane writes the 8 column groups of one row back to back, so the 128-byte lines of that row
+  // are completed while still in the write-combining window (columns-outer order cost the fc GEMM 40 %).
+  // (pointer fields are copied to locals: selecting among struct members by index forces the struct to scratch)
+  [[maybe_unused]] bf16_t* const pq = p.q; [[maybe_unused]] bf16_t* const pk = p.k; [[maybe_unused]] bf16_t* const pv = p.v;
+  [[maybe_unused]] bf16_t* const pqt = p.qt; [[maybe_unused]] bf16_t* const pkt = p.kt; [[maybe_unused]] bf16_t* const pvt = p.vt;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    mrow[i] = mrow0 + i * 32 + fr;
-    if constexpr (EPI == EPI_QKV) { const int ma = mrow[i] + p.m_off; qb[i] = ma / p.L; ql[i] = ma - qb[i] * p.L; }
-  }
+    const int m = mrow0 + i * 32 + fr;
+    if (m >= p.M) continue;
+    [[maybe_unused]] int qb = 0, ql = 0, vz = 0;
+    if constexpr (EPI == EPI_QKV) {
+      const int ma = m + p.m_off; qb = ma / p.L; ql = ma - qb * p.L;
+      // opaque per-lane zero: keeps the (part, head, offset) arithmetic below in VGPRs inside this loop;
+      // as hoisted wave-uniform values it needed ~60 SGPRs and spilled them into the k-loop.
+      asm volatile("" : "+v"(vz));
+    }
 #pragma unroll
-  for (int j = 0; j < NTL; ++j) {
+    for (int j = 0; j < NTL; ++j) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int n = ncol0 + j * 32 + q * 8 + fg * 4;
-      if (n >= p.N) continue;
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bv = *(const f32x4*)(p.bias + n);
-      [[maybe_unused]] int which = 0, hh = 0, dd = 0;
-      [[maybe_unused]] bf16_t* rowsel = nullptr; [[maybe_unused]] bf16_t* colsel = nullptr;
-      if constexpr (EPI == EPI_QKV) {
-        // head-dim % 8 == 0: (part, head) are wave-uniform for this 8-column group -> scalar ALU
-        const int nu = ncol0 + j * 32 + q * 8;
-        const int D = p.H * p.dh;
-        const int wq = nu / D;
-        const int c = nu - wq * D;
-        which = wq + p.which0; hh = c / p.dh; dd = c - hh * p.dh + fg * 4;
-        bf16_t* const pq = p.q; bf16_t* const pk = p.k; bf16_t* const pv = p.v;
-        bf16_t* const pqt = p.qt; bf16_t* const pkt = p.kt; bf16_t* const pvt = p.vt;
-        rowsel = which == 0 ? pq : (which == 1 ? pk : pv);
-        colsel = which == 0 ? pqt : (which == 1 ? pkt : pvt);
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int m = mrow[i];
-        if (m >= p.M) continue;
+      for (int q = 0; q < 4; ++q) {
+        const int n = ncol0 + j * 32 + q * 8 + fg * 4;
+        if (n >= p.N) continue;
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[i][j][q * 4 + e], p.alpha, bv[e]);
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e] * p.alpha;
+        if (p.bias) {
+          const f32x4 bv = *(const f32x4*)(p.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bv[e];
+        }
         if constexpr (EPI == EPI_BF16) {
           if (p.act == 1) {
             if (p.out2) {
@@ -156,11 +148,18 @@ __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL
           u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
           *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
         } else if constexpr (EPI == EPI_QKV) {
-          const size_t bh = (size_t)qb[i] * p.H + hh;
-          const size_t row_off = (bh * p.L + ql[i]) * p.dh + dd;      // [B,H,L,dh] layouts
-          const size_t col_off = (bh * p.dh + dd) * p.Lp + ql[i];     // [B,H,dh,Lp] layouts
-          bf16_t* rowp = rowsel;
-          bf16_t* colp = colsel;
+          // column -> (part, head, offset); D = H*dh, dh a power of two (dh_shift), at most 3 parts
+          const int D = p.H << p.dh_shift;
+          const int nv = n + vz;
+          const int wq = (nv >= D) + (nv >= 2 * D);
+          const int c = nv - wq * D;
+          const int which = wq + p.which0;
+          const int hh = c >> p.dh_shift, dd = c & ((1 << p.dh_shift) - 1);
+          const size_t bh = (size_t)qb * p.H + hh;
+          const size_t row_off = ((bh * p.L + ql) << p.dh_shift) + dd;          // [B,H,L,dh] layouts
+          const size_t col_off = ((bh << p.dh_shift) + dd) * p.Lp + ql;         // [B,H,dh,Lp] layouts
+          bf16_t* rowp = which == 0 ? pq : (which == 1 ? pk : pv);
+          bf16_t* colp = which == 0 ? pqt : (which == 1 ? pkt : pvt);
           if (which == 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= p.qscale;
@@ -623,8 +622,8 @@ static int num_cus() {
   return g_num_cus;
 }
 
-static int g_persist_variant = 2;   // 1 = plain persistent loop, 2 = hand-scheduled k-step
-extern "C" int vl_gemm_set_persist_variant(int v) { g_persist_variant = (v == 1) ? 1 : 2; return 0; }
+static int g_persist_variant = 2;   // 1 = plain persistent loop, 2 = hand-scheduled k-step, 3 = two 256x128 workgroups per CU
+extern "C" int vl_gemm_set_persist_variant(int v) { g_persist_variant = (v >= 1 && v <= 3) ? v : 2; return 0; }
 
 template <int EPI, int VAR>
 hipError_t launch_persist_v(const GemmP& p, hipStream_t s) {
@@ -643,8 +642,156 @@ hipError_t launch_persist_v(const GemmP& p, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3(G), dim3(512), smem, s, p);
   return hipGetLastError();
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Two-workgroups-per-CU variant: 256 x 128 tile, 4 waves (2 x 2, 128 x 64 accumulators each -- same
+// LDS-read : MFMA ratio as the 8-wave kernel), BK = 32 so two stages cost 48 KB and TWO workgroups are
+// resident per CU.  Each SIMD then hosts one wave of each workgroup; the workgroups have independent
+// barriers and drift apart, so the matrix pipe is fed by one while the other sits in its barrier /
+// LDS-DMA wait (the single-workgroup kernel idles the pipe ~45 % of the time there).
+template <int EPI>
+__global__ void __launch_bounds__(256, 2)
+    gemm_nt_persist3_kernel(const GemmP p) {
+  constexpr int BM = 256, BN = 128, NW = 4, WTM = 128, WTN = 64, MT = 4, NTL = 2;
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;     // 64-byte rows (BK = 32)
+  constexpr int GN = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int ntiles = tiles_m * tiles_n;
+  const int G = gridDim.x;
+  const int slot = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  if (slot >= ntiles) return;
+  const int my_tiles = (ntiles - slot + G - 1) / G;
+  const int nk = p.K >> 5;
+  const int total = my_tiles * nk;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wid & 1, wave_n = wid >> 1;
+  const int srow = lane >> 2, pch = lane & 3;        // one DMA instruction = 16 rows x 64 B
+  const int fr = lane & 31, fg = lane >> 5;
+  const int fsw = (fr >> 2) & 3;                     // 4 rows per 256-byte bank row, 4 chunks per row
+
+  auto tile_origin = [&](int ti, int& m0, int& n0) {
+    const int v = ti * G + slot;
+    const int gsz = GN * tiles_m;
+    const int gid = v / gsz, rem = v - gid * gsz;
+    const int first_n = gid * GN;
+    const int gn = min(tiles_n - first_n, GN);
+    const int tm = rem / gn;
+    m0 = tm * BM; n0 = (first_n + (rem - tm * gn)) * BN;
+  };
+  // 16 A row-groups + 8 W row-groups of 16 rows per stage; 4 waves -> 4 + 2 DMA instructions per wave
+  const bf16_t* src[6];
+  auto set_sources = [&](int m0, int n0, int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (i * NW + wid) * 16 + srow;
+      int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
+      src[i] = p.A + (size_t)gm * p.lda + (pch ^ ((row >> 2) & 3)) * 8 + k0;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (i * NW + wid) * 16 + srow;
+      int gn_ = n0 + row; gn_ = gn_ < p.N ? gn_ : p.N - 1;
+      src[4 + i] = p.W + (size_t)gn_ * p.ldw + (pch ^ ((row >> 2) & 3)) * 8 + k0;
+    }
+  };
+  auto dma = [&](int i, unsigned char* stage_base) {
+    unsigned char* dst = stage_base + (i < 4 ? (i * NW + wid) * 1024 : A_BYTES + ((i - 4) * NW + wid) * 1024);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+
+  f32x16 acc[MT][NTL];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int cur_m0, cur_n0, nxt_m0, nxt_n0;
+  tile_origin(0, cur_m0, cur_n0);
+  nxt_m0 = cur_m0; nxt_n0 = cur_n0;
+  set_sources(cur_m0, cur_n0, 0);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dma(i, smem);
+  int kt = 0, ti = 0, lkt = 0, lti = 0;
+  auto advance_load = [&]() {
+    ++lkt;
+    if (lkt == nk) { lkt = 0; ++lti; if (lti < my_tiles) tile_origin(lti, nxt_m0, nxt_n0); else { lti = my_tiles - 1; } }
+    set_sources(nxt_m0, nxt_n0, lkt << 5);
+  };
+  advance_load();
+  __syncthreads();
+
+  for (int s = 0; s < total; ++s) {
+    unsigned char* cur = smem + (s & 1) * STAGE;
+    unsigned char* oth = smem + ((s & 1) ^ 1) * STAGE;
+    const unsigned char* sA = cur + (wave_m * WTM + fr) * 64;
+    const unsigned char* sB = cur + A_BYTES + (wave_n * WTN + fr) * 64;
+    bf16x8 af[2][MT], wf[2][NTL];
+    auto ldfrag = [&](int kk, int c) {
+      const int off = ((kk * 2 + fg) ^ fsw) * 16;
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) wf[c][j] = *(const bf16x8*)(sB + j * 32 * 64 + off);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[c][i] = *(const bf16x8*)(sA + i * 32 * 64 + off);
+    };
+    auto mma = [&](int c) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][j], af[c][i], acc[i][j], 0, 0, 0);
+    };
+    ldfrag(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    dma(0, oth); dma(1, oth); dma(2, oth); dma(3, oth); dma(4, oth); dma(5, oth);
+    ldfrag(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1);
+    __builtin_amdgcn_sched_barrier(0);
+
+    if (kt + 1 == nk) {
+      { const GemmP pe = reload_params(); store_tile<EPI, MT, NTL>(pe, acc, cur_m0 + wave_m * WTM, cur_n0 + wave_n * WTN, fr, fg); }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      kt = 0; ++ti;
+      if (ti < my_tiles) tile_origin(ti, cur_m0, cur_n0);
+    } else {
+      ++kt;
+    }
+    advance_load();
+    __syncthreads();
+  }
+}
+
+template <int EPI>
+hipError_t launch_persist3(const GemmP& p, hipStream_t s) {
+  const int tiles = ((p.M + 255) / 256) * ((p.N + 127) / 128);
+  auto kern = gemm_nt_persist3_kernel<EPI>;
+  constexpr int smem = 2 * (256 * 64 + 128 * 64);
+  int G = 2 * (num_cus() & ~7);
+  if (tiles < G) G = (tiles + 7) & ~7;
+  hipLaunchKernelGGL(kern, dim3(G), dim3(256), smem, s, p);
+  return hipGetLastError();
+}
+
 template <int EPI>
 hipError_t launch_persist(const GemmP& p, hipStream_t s) {
+  if (g_persist_variant == 3) return launch_persist3<EPI>(p, s);
   return g_persist_variant == 1 ? launch_persist_v<EPI, 1>(p, s) : launch_persist_v<EPI, 2>(p, s);
 }
 
@@ -653,6 +800,7 @@ hipError_t dispatch(const GemmP& p, int cfg, hipStream_t s) {
   // cfg bit0: 0 = 256x256 tile (8 waves), 1 = 128x128 tile (4 waves); bit1: 1 = register staging
   if (cfg == 4) return launch_persist_v<EPI, 1>(p, s);
   if (cfg == 5) return launch_persist_v<EPI, 2>(p, s);
+  if (cfg == 6) return launch_persist3<EPI>(p, s);
   switch (cfg & 3) {
     case 0: return launch<256, 256, 2, 4, EPI, true>(p, s);
     case 1: return launch<128, 128, 2, 2, EPI, true>(p, s);
@@ -674,12 +822,13 @@ static int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } retu
 template <int EPI>
 static hipError_t run_gemm(const GemmP& p, int cfg, hipStream_t s) {
   if (cfg >= 0) return dispatch<EPI>(p, cfg, s);
-  const int G = num_cus() & ~7;
-  const int tiles_n = (p.N + 255) / 256, full_m = p.M / 256;
+  const bool two_wg = g_persist_variant == 3;
+  const int G = (num_cus() & ~7) * (two_wg ? 2 : 1);
+  const int tiles_n = two_wg ? (p.N + 127) / 128 : (p.N + 255) / 256, full_m = p.M / 256;
   if ((long)full_m * tiles_n < G) return dispatch<EPI>(p, 1, s);
   const int step = G / gcd_i(G, tiles_n);
   const int main_m = (full_m / step) * step;
-  if (main_m == 0) return dispatch<EPI>(p, 4, s);
+  if (main_m == 0) return launch_persist<EPI>(p, s);
   const int rows_main = main_m * 256;
   GemmP pm = p; pm.M = rows_main;
   hipError_t e = launch_persist<EPI>(pm, s);
@@ -747,12 +896,12 @@ extern "C" int vl_gemm_qkv_bf16_ex(const void* A, const void* W, const float* bi
   VL_CHECK_ARG(first >= 0 && count >= 1 && first + count <= 3, "vl_gemm_qkv_bf16: bad (first, count)");
   VL_CHECK_ARG(B > 0 && L > 0 && H > 0, "vl_gemm_qkv_bf16: empty problem");
   VL_CHECK_ARG((K & 63) == 0, "vl_gemm_qkv_bf16: K must be a multiple of 64");
-  VL_CHECK_ARG((dh & 7) == 0, "vl_gemm_qkv_bf16: head dim must be a multiple of 8");
+  VL_CHECK_ARG(dh >= 8 && (dh & (dh - 1)) == 0, "vl_gemm_qkv_bf16: head dim must be a power of two >= 8");
   VL_CHECK_ARG(Lp >= L, "vl_gemm_qkv_bf16: Lp < L");
   GemmP p{};
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = bias;
   p.M = B * L; p.N = count * H * dh; p.K = K; p.which0 = first; p.res_div = 1; p.lda = lda; p.ldw = K; p.ldo = 0; p.alpha = 1.f;
-  p.q = (bf16_t*)q; p.k = (bf16_t*)k; p.vt = (bf16_t*)vt; p.qt = (bf16_t*)qt; p.kt = (bf16_t*)kt; p.v = (bf16_t*)v; p.L = L; p.H = H; p.dh = dh; p.Lp = Lp; p.qscale = qscale;
+  p.q = (bf16_t*)q; p.k = (bf16_t*)k; p.vt = (bf16_t*)vt; p.qt = (bf16_t*)qt; p.kt = (bf16_t*)kt; p.v = (bf16_t*)v; p.L = L; p.H = H; p.dh = dh; p.Lp = Lp; p.qscale = qscale; p.dh_shift = __builtin_ctz((unsigned)dh);
   hipError_t e = run_gemm<EPI_QKV>(p, cfg, stream);
   if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
   return 0;
