@@ -34,6 +34,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define VL_EPI_RES_BF16 3 /* out bf16[M,N]   = res bf16 + alpha*acc + bias               */
 #define VL_EPI_GEGLU 5    /* out bf16[M,N/2] = a*gelu(gate), W rows interleaved (a,gate) */
 #define VL_EPI_DGELU 6    /* out bf16[M,N]   = alpha*acc * gelu'(res bf16[M,N])  (dX through GELU) */
+#define VL_EPI_DGEGLU 7   /* acc = dy[M,N]; res = h bf16[M,2N] interleaved (a,g); out bf16[M,2N] = d h  (dX through GEGLU) */
 #define VL_ACT_NONE 0
 #define VL_ACT_GELU 1     /* exact-erf GELU (nn.GELU default)                            */
 #define VL_ACT_RELU 2
@@ -155,6 +156,8 @@ int vl_layernorm_bwd_params(const void* dy, int dy_dtype, long dy_stride, const 
 /* out[j] += scale * sum_r a[r,j]  (bias gradients) */
 int vl_colsum(const void* a, int a_dtype, long lda, float* out, int rows, int cols, float scale, hipStream_t stream);
 int vl_gelu_bf16(const void* u, void* y, long n, hipStream_t stream);
+/* y[m,j] = h[m,2j] * gelu(h[m,2j+1])  (recompute of the GEGLU output from the saved pre-activation) */
+int vl_geglu_bf16(const void* h, void* y, long rows, int n_out, hipStream_t stream);
 /* delta[b,h,l] = sum_d dO[b,h,l,d] * O[b*L+l, h*dh+d] */
 int vl_attn_delta(const void* dO, const void* o, float* delta, int B, int H, int L, int dh, hipStream_t stream);
 /* Attention backward (see csrc/vl_attn_bwd.hip): dq/dk/dv are token-major bf16 destinations with row

@@ -86,6 +86,18 @@ __global__ void __launch_bounds__(256) gelu_kernel(const bf16_t* u, bf16_t* y, l
   }
 }
 
+__global__ void __launch_bounds__(256) geglu_kernel(const bf16_t* h, bf16_t* y, long n) {
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 256 * 4) {
+    const u32x4 v = *(const u32x4*)(h + 2 * i);
+    u32x2 o;
+    o[0] = pack2bf(bf2f((bf16_t)(v[0] & 0xffff)) * gelu_erf(bf2f((bf16_t)(v[0] >> 16))),
+                   bf2f((bf16_t)(v[1] & 0xffff)) * gelu_erf(bf2f((bf16_t)(v[1] >> 16))));
+    o[1] = pack2bf(bf2f((bf16_t)(v[2] & 0xffff)) * gelu_erf(bf2f((bf16_t)(v[2] >> 16))),
+                   bf2f((bf16_t)(v[3] & 0xffff)) * gelu_erf(bf2f((bf16_t)(v[3] >> 16))));
+    *(u32x2*)(y + i) = o;
+  }
+}
+
 // AdamW (PyTorch semantics): p *= 1 - lr*wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
 //                            p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
 __global__ void __launch_bounds__(256) adamw_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1,
@@ -171,6 +183,15 @@ extern "C" int vl_gelu_bf16(const void* u, void* y, long n, hipStream_t stream) 
   if (n <= 0) return 0;
   if (n & 7) return vl_set_error("vl_gelu_bf16: n must be a multiple of 8");
   hipLaunchKernelGGL(gelu_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (const bf16_t*)u, (bf16_t*)y, n);
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vl_geglu_bf16(const void* h, void* y, long rows, int n_out, hipStream_t stream) {
+  const long n = rows * n_out;
+  if (n <= 0) return 0;
+  if (n_out & 3) return vl_set_error("vl_geglu_bf16: n_out must be a multiple of 4");
+  hipLaunchKernelGGL(geglu_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, (const bf16_t*)h, (bf16_t*)y, n);
   VL_HIP_OK(hipGetLastError());
   return 0;
 }

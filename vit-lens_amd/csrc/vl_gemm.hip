@@ -25,6 +25,7 @@ enum Epi : int {
   EPI_QKV = 4,    // scatter to q[B,H,L,dh], k[B,H,L,dh], vt[B,H,dh,Lp]
   EPI_GEGLU = 5,  // rows interleaved (a_j, gate_j): out bf16[M, N/2] = a * gelu(gate)
   EPI_DGELU = 6,  // out bf16 = acc * gelu'(aux[m,n])   (backward through GELU fused into the dX GEMM)
+  EPI_DGEGLU = 7, // acc = dy[M,N]; res = h[M,2N] interleaved (a,g): out[M,2N] = (dy*gelu(g), dy*a*gelu'(g)) interleaved
 };
 
 struct GemmP {
@@ -174,9 +175,22 @@ __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL
           }
         } else if constexpr (EPI == EPI_GEGLU) {
           // interleaved rows: (a_j, gate_j, a_j+1, gate_j+1)
+          if (p.out2) {   // pre-activation kept for the backward: bf16 [M, N], row stride 2*ldo
+            u32x2 o2; o2[0] = pack2bf(v[0], v[1]); o2[1] = pack2bf(v[2], v[3]);
+            *(u32x2*)((bf16_t*)p.out2 + (size_t)m * (2 * p.ldo) + n) = o2;
+          }
           const float o0 = v[0] * gelu_erf(v[1]);
           const float o1 = v[2] * gelu_erf(v[3]);
           *(unsigned int*)((bf16_t*)p.out + (size_t)m * p.ldo + (n >> 1)) = pack2bf(o0, o1);
+        } else if constexpr (EPI == EPI_DGEGLU) {
+          const u32x4 hv = *(const u32x4*)((const bf16_t*)p.res + (size_t)m * p.ldo + 2 * n);
+          u32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float a = bf2f((bf16_t)(hv[e] & 0xffff)), g = bf2f((bf16_t)(hv[e] >> 16));
+            o[e] = pack2bf(v[e] * gelu_erf(g), v[e] * a * gelu_erf_grad(g));
+          }
+          *(u32x4*)((bf16_t*)p.out + (size_t)m * p.ldo + 2 * n) = o;
         }
       }
     }
@@ -1037,6 +1051,7 @@ extern "C" int vl_gemm_bf16_ex(const void* A, const void* W, const float* bias, 
     case VL_EPI_RES_BF16: VL_CHECK_ARG(res, "vl_gemm_bf16: residual missing"); e = run_gemm<EPI_RES_BF16>(p, cfg, stream); break;
     case VL_EPI_GEGLU: e = run_gemm<EPI_GEGLU>(p, cfg, stream); break;
     case VL_EPI_DGELU: VL_CHECK_ARG(res, "vl_gemm_bf16: pre-activation tensor missing"); e = run_gemm<EPI_DGELU>(p, cfg, stream); break;
+    case VL_EPI_DGEGLU: VL_CHECK_ARG(res, "vl_gemm_bf16: pre-activation tensor missing"); VL_CHECK_ARG((ldo & 7) == 0, "vl_gemm_bf16: DGEGLU needs ldo % 8 == 0"); e = run_gemm<EPI_DGEGLU>(p, cfg, stream); break;
     default: return vl_set_error("vl_gemm_bf16: unknown epilogue");
   }
   if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));

@@ -47,6 +47,7 @@ SIGNATURES = {
     "vl_layernorm_bwd_params": [P, I, L, P, I, L, P, P, P, P, I, I, P],
     "vl_colsum": [P, I, L, P, I, I, F, P],
     "vl_gelu_bf16": [P, P, L, P],
+    "vl_geglu_bf16": [P, P, L, I, P],
     "vl_attn_delta": [P, P, P, I, I, I, I, P],
     "vl_attn_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, I, I, I, I, I, F, P],
     "vl_adamw_step": [P, P, P, P, L, F, F, F, F, F, I, F, P],

@@ -8,7 +8,7 @@ import torch
 from ._lib import load_library, check
 
 F32, BF16 = 0, 1
-EPI_BF16, EPI_F32, EPI_RES_F32, EPI_RES_BF16, EPI_GEGLU, EPI_DGELU = 0, 1, 2, 3, 5, 6
+EPI_BF16, EPI_F32, EPI_RES_F32, EPI_RES_BF16, EPI_GEGLU, EPI_DGELU, EPI_DGEGLU = 0, 1, 2, 3, 5, 6, 7
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 LOG2E = 1.4426950408889634
 
@@ -54,7 +54,7 @@ def gemm(a, w, bias=None, out=None, res=None, epi=EPI_BF16, act=ACT_NONE, alpha=
         a = torch.nn.functional.pad(a, (0, Kp - K)); w = torch.nn.functional.pad(w, (0, Kp - K))
         K = Kp
     if out is None:
-        n_out = N // 2 if epi == EPI_GEGLU else N
+        n_out = N // 2 if epi == EPI_GEGLU else (2 * N if epi == EPI_DGEGLU else N)
         odt = torch.float32 if epi in (EPI_F32, EPI_RES_F32) else torch.bfloat16
         out = torch.empty(M, n_out, device=a.device, dtype=odt)
     _chk2d(out, "out")
@@ -66,8 +66,8 @@ def gemm(a, w, bias=None, out=None, res=None, epi=EPI_BF16, act=ACT_NONE, alpha=
             raise ValueError("gemm: broadcast residual has too few rows")
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N):
         raise ValueError("gemm: bias must be f32 [N]")
-    if out2 is not None and (out2.stride(0) != out.stride(0) or out2.dtype != torch.bfloat16):
-        raise ValueError("gemm: out2 must be bf16 with out's row stride")
+    if out2 is not None and (out2.stride(0) != out.stride(0) * (2 if epi == EPI_GEGLU else 1) or out2.dtype != torch.bfloat16):
+        raise ValueError("gemm: out2 must be bf16 with out's row stride (twice that for GEGLU)")
     check(_lib.vl_gemm_bf16_ex(_p(a), _p(w), _p(bias), _p(out), _p(res), _p(out2), M, N, K, a.stride(0), w.stride(0),
                                out.stride(0), float(alpha), epi, act, res_div, cfg, _stream()))
     return out
@@ -233,6 +233,11 @@ def layernorm_bwd_params(dy, x, mean, rstd, dw, db, rows, D, x_row_stride=None, 
 def colsum(a, out, scale=1.0):
     _chk2d(a, "a")
     check(_lib.vl_colsum(_p(a), _dt(a), a.stride(0), _p(out), a.shape[0], a.shape[1], float(scale), _stream()))
+
+
+def geglu_bf16(h, out):
+    check(_lib.vl_geglu_bf16(_p(h), _p(out), h.shape[0], h.shape[1] // 2, _stream()))
+    return out
 
 
 def gelu_bf16(u, out):
