@@ -241,3 +241,265 @@ class AdamW:
             wd = self.wd if self.decays(k, p) else 0.0
             ops.adamw_step(p.view(-1), g.view(-1), self.m[k].view(-1), self.v[k].view(-1), self.lr, self.betas[0],
                            self.betas[1], self.eps, wd, self.t, grad_scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# Perceiver ("Lens") training: autograd of Perceiver.forward (open_clip/perceiver.py:289-328)
+# ------------------------------------------------------------------------------------------------
+class _AttnSaved:
+    def __init__(self, B, H, Lq, Lk, dh, device):
+        bf = lambda *s: torch.empty(*s, device=device, dtype=BF)
+        z = lambda *s: torch.zeros(*s, device=device, dtype=BF)
+        Lqp, Lkp = (Lq + 7) // 8 * 8, (Lk + 7) // 8 * 8
+        self.q, self.k, self.v = bf(B, H, Lq, dh), bf(B, H, Lk, dh), bf(B, H, Lk, dh)
+        self.qt, self.kt, self.vt = z(B, H, dh, Lqp), z(B, H, dh, Lkp), z(B, H, dh, Lkp)
+        self.a = bf(B * Lq, H * dh)
+        self.lse = torch.empty(B, H, Lq, device=device, dtype=torch.float32)
+        self.dO, self.dOt = bf(B, H, Lq, dh), z(B, H, dh, Lqp)
+        self.delta = torch.empty(B, H, Lq, device=device, dtype=torch.float32)
+
+
+def deinterleave_geglu(g: torch.Tensor) -> torch.Tensor:
+    """gradient / weight in the kernels' interleaved (a_j, gate_j) row order -> the reference's [a ; gate] order."""
+    return torch.cat([g[0::2], g[1::2]], dim=0)
+
+
+class PerceiverTrainer:
+    def __init__(self, pe, param_prefix: str = "visual.perceiver."):
+        self.pe, self.P = pe, param_prefix
+        c = pe.cfg
+        self.grads: Dict[str, torch.Tensor] = {}
+        t = lambda w: w.t().contiguous()
+        self.wT = []
+        for lay in pe.layers:
+            d = {"x": {"q": t(lay["x_attn"]["q_w"]), "kv": t(lay["x_attn"]["kv_w"]), "out": t(lay["x_attn"]["to_out_w"])},
+                 "xff": {"w0": t(lay["x_ff"]["w0"]), "w2": t(lay["x_ff"]["w2"])}, "selfs": []}
+            for sl in lay["selfs"]:
+                d["selfs"].append({"qkv": t(sl["attn"]["qkv_w"]), "out": t(sl["attn"]["to_out_w"]),
+                                   "w0": t(sl["ff"]["w0"]), "w2": t(sl["ff"]["w2"])})
+            self.wT.append(d)
+        self._st = {}
+
+    def grad_buffer(self, name, shape):
+        g = self.grads.get(name)
+        if g is None:
+            g = torch.zeros(tuple(shape), device=self.pe.device, dtype=torch.float32)
+            self.grads[name] = g
+        return g
+
+    def _state(self, B, Tc):
+        key = (B, Tc)
+        if key in self._st:
+            return self._st[key]
+        c, dev = self.pe.cfg, self.pe.device
+        n, D = c.num_latents, c.latent_dim
+        R = B * n
+        f32 = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        bf = lambda *s: torch.empty(*s, device=dev, dtype=BF)
+        nres = c.depth * (2 + 2 * c.self_per_cross) + 1
+        st = {"X": [f32(R, D) for _ in range(nres)], "h": bf(R, D), "ctx": bf(B * Tc, c.input_chan), "hid": bf(R, 4 * D),
+              "dx": f32(R, D), "dxb": bf(R, D), "dh8": bf(R, 8 * D), "dhn": bf(R, D), "dqkv": bf(R, 3 * c.latent_heads * c.latent_dim_head),
+              "dq": bf(R, c.cross_heads * c.cross_dim_head), "dkv": bf(B * Tc, 2 * c.cross_heads * c.cross_dim_head),
+              "dctx": bf(B * Tc, c.input_chan), "ddata": f32(B * Tc, c.input_chan), "layers": []}
+        for _ in range(c.depth):
+            lay = {"x_stats": [f32(R), f32(R)], "c_stats": [f32(B * Tc), f32(B * Tc)],
+                   "x_attn": _AttnSaved(B, c.cross_heads, n, Tc, c.cross_dim_head, dev),
+                   "xff_stats": [f32(R), f32(R)], "xff_h": bf(R, 8 * D), "selfs": []}
+            for _ in range(c.self_per_cross):
+                lay["selfs"].append({"stats": [f32(R), f32(R)], "attn": _AttnSaved(B, c.latent_heads, n, n, c.latent_dim_head, dev),
+                                     "ff_stats": [f32(R), f32(R)], "ff_h": bf(R, 8 * D)})
+            st["layers"].append(lay)
+        self._st[key] = st
+        return st
+
+    # ---- forward ----------------------------------------------------------------------------------
+    def _ff_fwd(self, st, xi, norm, ff, stats, hsave, rows, D):
+        X, cfg = st["X"], self.pe.gemm_cfg
+        ops.layernorm(X[xi], norm[0], norm[1], st["h"], rows, D, mean=stats[0], rstd=stats[1])
+        ops.gemm(st["h"], ff["w0"], ff["b0"], out=st["hid"], epi=ops.EPI_GEGLU, cfg=cfg, out2=hsave)
+        ops.gemm(st["hid"], ff["w2"], ff["b2"], out=X[xi + 1], res=X[xi], epi=ops.EPI_RES_F32, cfg=cfg)
+
+    def forward(self, data: torch.Tensor, B: int) -> torch.Tensor:
+        pe, c = self.pe, self.pe.cfg
+        Tc, n, D = data.shape[0] // B, c.num_latents, c.latent_dim
+        st = self._state(B, Tc)
+        X, cfg, rows = st["X"], pe.gemm_cfg, B * n
+        X[0].view(B, n, D).copy_(pe.latents)
+        xi = 0
+        for li, lay in enumerate(pe.layers):
+            S = st["layers"][li]
+            a, A = lay["x_attn"], S["x_attn"]
+            ops.layernorm(X[xi], lay["x_norm"][0], lay["x_norm"][1], st["h"], rows, D, mean=S["x_stats"][0], rstd=S["x_stats"][1])
+            ops.layernorm(data, lay["x_norm_ctx"][0], lay["x_norm_ctx"][1], st["ctx"], B * Tc, c.input_chan,
+                          mean=S["c_stats"][0], rstd=S["c_stats"][1])
+            ops.gemm_qkv(st["h"], a["q_w"], None, A.q, None, None, B, n, c.cross_heads, c.cross_dim_head, first=0, count=1,
+                         cfg=cfg, qt=A.qt)
+            ops.gemm_qkv(st["ctx"], a["kv_w"], None, None, A.k, A.vt, B, Tc, c.cross_heads, c.cross_dim_head, first=1, count=2,
+                         cfg=cfg, kt=A.kt, v=A.v)
+            ops.attn_fwd(A.q, A.k, A.vt, A.a, lse=A.lse)
+            ops.gemm(A.a, a["to_out_w"], a["to_out_b"], out=X[xi + 1], res=X[xi], epi=ops.EPI_RES_F32, cfg=cfg)
+            xi += 1
+            self._ff_fwd(st, xi, lay["x_ff_norm"], lay["x_ff"], S["xff_stats"], S["xff_h"], rows, D)
+            xi += 1
+            for sj, sl in enumerate(lay["selfs"]):
+                T = S["selfs"][sj]
+                a, A = sl["attn"], T["attn"]
+                ops.layernorm(X[xi], sl["norm"][0], sl["norm"][1], st["h"], rows, D, mean=T["stats"][0], rstd=T["stats"][1])
+                ops.gemm_qkv(st["h"], a["qkv_w"], None, A.q, A.k, A.vt, B, n, c.latent_heads, c.latent_dim_head, cfg=cfg,
+                             qt=A.qt, kt=A.kt, v=A.v)
+                ops.attn_fwd(A.q, A.k, A.vt, A.a, lse=A.lse)
+                ops.gemm(A.a, a["to_out_w"], a["to_out_b"], out=X[xi + 1], res=X[xi], epi=ops.EPI_RES_F32, cfg=cfg)
+                xi += 1
+                self._ff_fwd(st, xi, sl["ff_norm"], sl["ff"], T["ff_stats"], T["ff_h"], rows, D)
+                xi += 1
+        self.ctx = (B, Tc, data)
+        return X[xi]
+
+    # ---- backward ---------------------------------------------------------------------------------
+    def _dw(self, name, dy, x, rows):
+        g = self.grad_buffer(name, (dy.shape[1], x.shape[1]))
+        rp = (rows + 63) // 64 * 64
+        ops.gemm(ops.transpose_to_bf16(dy, ldo=rp), ops.transpose_to_bf16(x, ldo=rp), None, out=g, res=g,
+                 epi=ops.EPI_RES_F32, cfg=self.pe.gemm_cfg)
+
+    def _ln_params(self, name, dy, x, stats, rows, D):
+        ops.layernorm_bwd_params(dy, x, stats[0], stats[1], self.grad_buffer(name + ".weight", (D,)),
+                                 self.grad_buffer(name + ".bias", (D,)), rows, D)
+
+    def _ff_bwd(self, st, xi, norm, ff, wT, stats, hsave, rows, D, pname):
+        """x_{xi+1} = x_xi + W2 geglu(W0 LN(x_xi) + b0) + b2 ; st['dx'] holds dL/dx_{xi+1} on entry, dL/dx_xi on exit."""
+        X, cfg = st["X"], self.pe.gemm_cfg
+        ops.geglu_bf16(hsave, st["hid"])
+        self._dw(pname + "1.fn.net.2.weight", st["dx"], st["hid"], rows)
+        ops.colsum(st["dx"], self.grad_buffer(pname + "1.fn.net.2.bias", (D,)))
+        ops.gemm(st["dxb"], wT["w2"], None, out=st["dh8"], res=hsave, epi=ops.EPI_DGEGLU, cfg=cfg)     # d(pre-activation), interleaved
+        ops.layernorm(X[xi], norm[0], norm[1], st["h"], rows, D)
+        self._dw(pname + "1.fn.net.0.weight_il", st["dh8"], st["h"], rows)
+        ops.colsum(st["dh8"], self.grad_buffer(pname + "1.fn.net.0.bias_il", (8 * D,)))
+        ops.gemm(st["dh8"], wT["w0"], None, out=st["dhn"], epi=ops.EPI_BF16, cfg=cfg)
+        self._ln_params(pname + "1.norm", st["dhn"], X[xi], stats, rows, D)
+        ops.layernorm_bwd(st["dhn"], X[xi], stats[0], stats[1], norm[0], rows, D, dres=st["dx"], dx=st["dx"], dx_bf16=st["dxb"])
+
+    def backward(self, dlat: torch.Tensor) -> torch.Tensor:
+        """dlat f32 [B*n, D] = dL/d(latent output) -> returns dL/d(data) f32 [B*Tc, C]; fills self.grads
+        (GEGLU first-layer gradients are kept in the kernels' interleaved row order under '*_il' names)."""
+        pe, c = self.pe, self.pe.cfg
+        B, Tc, data = self.ctx
+        n, D = c.num_latents, c.latent_dim
+        st = self._state(B, Tc)
+        X, cfg, rows, P = st["X"], pe.gemm_cfg, B * n, self.P
+        st["dx"].copy_(dlat)
+        ops.cast_bf16(st["dx"], out=st["dxb"])
+        st["ddata"].zero_()
+        xi = len(X) - 1
+        for li in reversed(range(c.depth)):
+            lay, S, wT = pe.layers[li], st["layers"][li], self.wT[li]
+            for sj in reversed(range(c.self_per_cross)):
+                sl, T, w = lay["selfs"][sj], S["selfs"][sj], wT["selfs"][sj]
+                pn = f"{P}layers.{li}.2.{sj}."
+                xi -= 1
+                self._ff_bwd(st, xi, sl["ff_norm"], sl["ff"], w, T["ff_stats"], T["ff_h"], rows, D, pn)
+                xi -= 1
+                a, A = sl["attn"], T["attn"]
+                H, dh = c.latent_heads, c.latent_dim_head
+                inner = H * dh
+                self._dw(pn + "0.fn.to_out.weight", st["dx"], A.a, rows)
+                ops.colsum(st["dx"], self.grad_buffer(pn + "0.fn.to_out.bias", (D,)))
+                ops.gemm_qkv(st["dxb"], w["out"], None, A.dO, None, None, B, n, H, dh, cfg=cfg, first=0, count=1, qt=A.dOt, raw_scale=1.0)
+                ops.attn_delta(A.dO, A.a, A.delta)
+                dqkv = st["dqkv"]
+                ops.attn_bwd(A.q, A.k, A.v, A.qt, A.kt, A.dO, A.dOt, A.lse, A.delta, dqkv, dqkv[:, inner:], dqkv[:, 2 * inner:],
+                             3 * inner, 3 * inner)
+                ops.layernorm(X[xi], sl["norm"][0], sl["norm"][1], st["h"], rows, D)
+                self._dw(pn + "0.fn.to_qkv.weight", dqkv, st["h"], rows)            # rows [to_q ; to_kv]
+                ops.gemm(dqkv, w["qkv"], None, out=st["dhn"], epi=ops.EPI_BF16, cfg=cfg)
+                self._ln_params(pn + "0.norm", st["dhn"], X[xi], T["stats"], rows, D)
+                ops.layernorm_bwd(st["dhn"], X[xi], T["stats"][0], T["stats"][1], sl["norm"][0], rows, D, dres=st["dx"],
+                                  dx=st["dx"], dx_bf16=st["dxb"])
+            pn = f"{P}layers.{li}."
+            xi -= 1
+            self._ff_bwd(st, xi, lay["x_ff_norm"], lay["x_ff"], wT["xff"], S["xff_stats"], S["xff_h"], rows, D, pn)
+            xi -= 1
+            a, A, w = lay["x_attn"], S["x_attn"], wT["x"]
+            H, dh = c.cross_heads, c.cross_dim_head
+            inner = H * dh
+            self._dw(pn + "0.fn.to_out.weight", st["dx"], A.a, rows)
+            ops.colsum(st["dx"], self.grad_buffer(pn + "0.fn.to_out.bias", (D,)))
+            ops.gemm_qkv(st["dxb"], w["out"], None, A.dO, None, None, B, n, H, dh, cfg=cfg, first=0, count=1, qt=A.dOt, raw_scale=1.0)
+            ops.attn_delta(A.dO, A.a, A.delta)
+            dkv = st["dkv"]
+            ops.attn_bwd(A.q, A.k, A.v, A.qt, A.kt, A.dO, A.dOt, A.lse, A.delta, st["dq"], dkv, dkv[:, inner:], inner, 2 * inner)
+            # query side: LN(x) -> to_q
+            ops.layernorm(X[xi], lay["x_norm"][0], lay["x_norm"][1], st["h"], rows, D)
+            self._dw(pn + "0.fn.to_q.weight", st["dq"], st["h"], rows)
+            ops.gemm(st["dq"], w["q"], None, out=st["dhn"], epi=ops.EPI_BF16, cfg=cfg)
+            self._ln_params(pn + "0.norm", st["dhn"], X[xi], S["x_stats"], rows, D)
+            ops.layernorm_bwd(st["dhn"], X[xi], S["x_stats"][0], S["x_stats"][1], lay["x_norm"][0], rows, D, dres=st["dx"],
+                              dx=st["dx"], dx_bf16=st["dxb"])
+            # context side: LN_ctx(data) -> to_kv ; every cross layer reads the same data -> accumulate
+            C = c.input_chan
+            ops.layernorm(data, lay["x_norm_ctx"][0], lay["x_norm_ctx"][1], st["ctx"], B * Tc, C)
+            self._dw(pn + "0.fn.to_kv.weight", dkv, st["ctx"], B * Tc)
+            ops.gemm(dkv, w["kv"], None, out=st["dctx"], epi=ops.EPI_BF16, cfg=cfg)
+            self._ln_params(pn + "0.norm_context", st["dctx"], data, S["c_stats"], B * Tc, C)
+            ops.layernorm_bwd(st["dctx"], data, S["c_stats"][0], S["c_stats"][1], lay["x_norm_ctx"][0], B * Tc, C,
+                              dres=st["ddata"], dx=st["ddata"])
+        ops.batch_rowsum(st["dx"], self.grad_buffer(P + "latents", (n, D)), B, n, D, n, 0)
+        return st["ddata"]
+
+    def reference_named_grads(self) -> Dict[str, torch.Tensor]:
+        """Gradients under the reference's parameter names/layouts (de-interleaved GEGLU, split to_q/to_kv)."""
+        out = {}
+        c = self.pe.cfg
+        for k, g in self.grads.items():
+            if k.endswith("net.0.weight_il"):
+                out[k[:-3]] = deinterleave_geglu(g)
+            elif k.endswith("net.0.bias_il"):
+                out[k[:-3]] = deinterleave_geglu(g)
+            elif k.endswith("to_qkv.weight"):
+                inner = c.latent_heads * c.latent_dim_head
+                out[k.replace("to_qkv", "to_q")] = g[:inner]; out[k.replace("to_qkv", "to_kv")] = g[inner:]
+            else:
+                out[k] = g
+        return out
+
+
+class AudioLensTrainer:
+    """`visual.` tower of the audio recipe (TRAIN_INFERENCE.md:283-299): AST tokenizer + Perceiver trainable,
+    ViT blocks locked, class_embedding unlocked (--lock-visual --unlock-cls)."""
+
+    def __init__(self, lens_engine):
+        self.le = lens_engine
+        self.tower = TowerTrainer(lens_engine.vit, train_blocks=(), train_cls=True, param_prefix="visual.")
+        self.perc = PerceiverTrainer(lens_engine.perceiver, "visual.perceiver.")
+        self.perc.grads = self.tower.grads            # one gradient dictionary
+        self.ctx = None
+
+    @property
+    def grads(self):
+        return self.tower.grads
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        le, L = self.le, self.le.lens
+        p = le.tower.patch
+        B = x.shape[0]
+        cols, gh, gw = ops.im2col(x.contiguous().float().unsqueeze(1), p, p, L.audio_fstride, L.audio_tstride,
+                                  le.conv_w.shape[1], transpose_hw=True)
+        tok = ops.gemm(cols, le.conv_w, None, epi=ops.EPI_BF16, cfg=le.gemm_cfg)
+        T = tok.shape[0] // B
+        xin = torch.empty_like(tok)
+        ops.add_rows(tok, le.adapter_pos, xin, tok.shape[0], T, tok.shape[1])
+        lat = self.perc.forward(xin, B)
+        self.ctx = (cols, B, T)
+        return self.tower.forward(lat, B)
+
+    def backward(self, dfeat: torch.Tensor):
+        cols, B, T = self.ctx
+        dlat = self.tower.backward(dfeat)
+        ddata = self.perc.backward(dlat)                          # f32 [B*T, D]
+        D = ddata.shape[1]
+        g = self.tower.grad_buffer("visual.visual_adapter.conv1.weight_gemm", torch.empty(D, cols.shape[1]))
+        rp = (ddata.shape[0] + 63) // 64 * 64
+        ops.gemm(ops.transpose_to_bf16(ddata, ldo=rp), ops.transpose_to_bf16(cols, ldo=rp), None, out=g, res=g,
+                 epi=ops.EPI_RES_F32, cfg=self.le.gemm_cfg)
+        ops.batch_rowsum(ddata, self.tower.grad_buffer("visual.visual_adapter.pos_emb", self.le.adapter_pos), B, T, D, T, 0)
