@@ -168,3 +168,138 @@ class TriModalDepthStep:
         # logit_scale is exp()'d in forward (model.py:619): d/d(log-scale) = dscale * scale
         self.grads["logit_scale"] += (ds1 + ds2) * scale
         return loss
+
+
+class DualAudioStep:
+    """Audio <-> text dual-tower step (reference `train_dual_one_epoch` + ClipLossGeneral, training/train.py:315-470,
+    recipe TRAIN_INFERENCE.md:283-299 with --use_dual_loss --align_to text): text tower frozen, visual tower =
+    AST tokenizer + Perceiver (trainable) -> locked ViT with unlocked class_embedding.  Multi-GPU semantics are the
+    tri-modal step's (packed all-gather, flat gradient all-reduce = mean of per-rank gradients of the global loss)."""
+
+    def __init__(self, sd, tower: TowerCfg, text: TextCfg, lens: LensCfg, device, micro_batch: int = 256, lr: float = 2e-4,
+                 betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2, rank: int = 0, world_size: int = 1,
+                 gemm_cfg: int = -1):
+        from .train import AudioLensTrainer
+        self.dev, self.mb, self.rank, self.world = torch.device(device), micro_batch, rank, world_size
+        self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg)
+        self.lens = LensEngine(sd, "visual.", tower, lens, device, gemm_cfg=gemm_cfg)
+        self._mk = lambda: AudioLensTrainer(self.lens)
+        self.trainers = []
+        self.logit_scale = sd["logit_scale"].detach().float().reshape(1).to(device)
+        pe, P = self.lens.perceiver, "visual.perceiver."
+        f32 = lambda k: sd[k].detach().float().to(device).contiguous()
+        self.masters: Dict[str, torch.Tensor] = {"logit_scale": self.logit_scale, "visual.class_embedding": self.lens.vit.cls,
+                                                 "visual.visual_adapter.pos_emb": self.lens.adapter_pos,
+                                                 "visual.visual_adapter.conv1.weight_gemm": self.lens.conv_w.float(),
+                                                 P + "latents": pe.latents}
+        self.refresh = []        # (master name, forward bf16 tensor, key path of the transposed copy in trainer.perc.wT)
+        from .engine import _interleave_geglu
+        for li, lay in enumerate(pe.layers):
+            q = f"{P}layers.{li}."
+            self._attn(q + "0.", lay["x_attn"], lay["x_norm"], (li, "x"), sd, f32, ctx_norm=lay["x_norm_ctx"])
+            self._ff(q + "1.", lay["x_ff"], lay["x_ff_norm"], (li, "xff"), sd, f32)
+            for sj, sl in enumerate(lay["selfs"]):
+                r = f"{q}2.{sj}."
+                self._attn(r + "0.", sl["attn"], sl["norm"], (li, "selfs", sj), sd, f32)
+                self._ff(r + "1.", sl["ff"], sl["ff_norm"], (li, "selfs", sj), sd, f32)
+        self.opt = AdamW(self.masters, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.flat_grad, self.grads = None, {}
+
+    def _attn(self, p, a, norm, path, sd, f32, ctx_norm=None):
+        self.masters[p + "norm.weight"], self.masters[p + "norm.bias"] = norm
+        if ctx_norm is not None:
+            self.masters[p + "norm_context.weight"], self.masters[p + "norm_context.bias"] = ctx_norm
+            self.masters[p + "fn.to_q.weight"] = f32(p + "fn.to_q.weight"); self.refresh.append((p + "fn.to_q.weight", a["q_w"], path + ("q",)))
+            self.masters[p + "fn.to_kv.weight"] = f32(p + "fn.to_kv.weight"); self.refresh.append((p + "fn.to_kv.weight", a["kv_w"], path + ("kv",)))
+        else:
+            self.masters[p + "fn.to_qkv.weight"] = torch.cat([f32(p + "fn.to_q.weight"), f32(p + "fn.to_kv.weight")], 0)
+            self.refresh.append((p + "fn.to_qkv.weight", a["qkv_w"], path + ("qkv",)))
+        self.masters[p + "fn.to_out.weight"] = f32(p + "fn.to_out.weight"); self.refresh.append((p + "fn.to_out.weight", a["to_out_w"], path + ("out",)))
+        self.masters[p + "fn.to_out.bias"] = a["to_out_b"]
+
+    def _ff(self, p, ff, norm, path, sd, f32):
+        from .engine import _interleave_geglu
+        self.masters[p + "norm.weight"], self.masters[p + "norm.bias"] = norm
+        w0, _ = _interleave_geglu(f32(p + "fn.net.0.weight"), f32(p + "fn.net.0.bias"))
+        self.masters[p + "fn.net.0.weight_il"] = w0.contiguous(); self.refresh.append((p + "fn.net.0.weight_il", ff["w0"], path + ("w0",)))
+        self.masters[p + "fn.net.0.bias_il"] = ff["b0"]
+        self.masters[p + "fn.net.2.weight"] = f32(p + "fn.net.2.weight"); self.refresh.append((p + "fn.net.2.weight", ff["w2"], path + ("w2",)))
+        self.masters[p + "fn.net.2.bias"] = ff["b2"]
+
+    def _trainer(self, i):
+        while len(self.trainers) <= i:
+            t = self._mk()
+            if self.trainers:
+                t.tower.wT, t.tower.proj = self.trainers[0].tower.wT, self.trainers[0].tower.proj
+                t.perc.wT = self.trainers[0].perc.wT
+            self.trainers.append(t)
+        return self.trainers[i]
+
+    def _alloc_flat_grads(self):
+        n = sum(v.numel() for v in self.masters.values())
+        self.flat_grad = torch.zeros(n, device=self.dev, dtype=torch.float32)
+        off = 0
+        for k, v in self.masters.items():
+            self.grads[k] = self.flat_grad[off:off + v.numel()].view(v.shape); off += v.numel()
+        for t in self.trainers:
+            t.tower.grads = self.grads; t.perc.grads = self.grads
+
+    def _refresh_operands(self):
+        wT = self.trainers[0].perc.wT
+        for name, fwd, path in self.refresh:
+            m = self.masters[name]
+            ops.cast_bf16(m, out=fwd)
+            node = wT[path[0]]
+            for k in path[1:-1]:
+                node = node[k]
+            ops.transpose_to_bf16(m, ldo=m.shape[0], out=node[path[-1]])
+        ops.cast_bf16(self.masters["visual.visual_adapter.conv1.weight_gemm"], out=self.lens.conv_w)
+
+    def forward_backward(self, audio: torch.Tensor, texts: torch.Tensor) -> torch.Tensor:
+        B = audio.shape[0]
+        mb = min(self.mb, B)
+        assert B % mb == 0
+        nmb = B // mb
+        if self.flat_grad is None:
+            for i in range(nmb):
+                self._trainer(i)
+            self._alloc_flat_grads()
+        self.flat_grad.zero_()
+        E = self.lens.tower.embed_dim
+        ft = torch.empty(B, E, device=self.dev); fv = torch.empty(B, E, device=self.dev)
+        vraw = torch.empty(B, E, device=self.dev); vnorm = torch.empty(B, device=self.dev)
+        for i in range(nmb):
+            s = slice(i * mb, (i + 1) * mb)
+            ops.l2_normalize(self.text.encode_text(texts[s]), out=ft[s])
+            vraw[s] = self._trainer(i).forward(audio[s])
+        ops.l2_normalize(vraw, out=fv, norms=vnorm)
+        scale = float(self.logit_scale.exp())
+        if self.world > 1:
+            import torch.distributed as dist
+            allp = torch.empty(self.world * B, 2 * E, device=self.dev)
+            dist.all_gather_into_tensor(allp, torch.cat([fv, ft], dim=1))
+            av, at = [t.contiguous() for t in allp.split(E, dim=1)]
+        else:
+            av, at = fv, ft
+        loss, c = pair_forward(av, at, scale)                       # ClipLossGeneral(x=visual, y=text)
+        dv, _, ds = pair_backward(c, need_dy=False)
+        dvraw = ops.l2_normalize_bwd(fv, dv[self.rank * B:(self.rank + 1) * B].contiguous(), vnorm)
+        for i in range(nmb):
+            self._trainer(i).backward(dvraw[i * mb:(i + 1) * mb].contiguous())
+        self.grads["logit_scale"] += ds * scale
+        return loss
+
+    def optimizer_step(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+            self.opt.step(self.grads, grad_scale=1.0 / self.world)
+        else:
+            self.opt.step(self.grads)
+        self._refresh_operands()
+        ops.clamp_scalar(self.logit_scale, 0.0, math.log(100.0))
+
+    def step(self, audio, texts):
+        loss = self.forward_backward(audio, texts)
+        self.optimizer_step()
+        return loss
