@@ -245,3 +245,24 @@ def test_audio_lens_backward_vs_reference_grads():
     # latents, adapter (2), cls, per layer: cross attn 3 w + 1 b + 2 LN x2, ff 2w+2b+LN2, selfs ...
     assert n >= 40, n
     assert "visual.class_embedding" in got and "visual.perceiver.latents" in got
+
+
+def test_dual_audio_step_runs_and_matches_reference_loss():
+    """Audio <-> text dual step (ClipLossGeneral): loss vs the reference's value on the tiny golden model, then two
+    optimizer steps (masters move, bf16 operands + transposes refreshed, loss does not increase)."""
+    from vitlens_hip import engine as E, step as ST
+    sd, ins, outs, grads, meta = split(load_npz("tiny_audio.npz"))
+    tower, text, lens = specs_from_meta(meta)
+    tc = E.TowerCfg(width=tower.width, layers=tower.layers, heads=tower.heads, patch=tower.patch,
+                    image_size=tower.image_size, embed_dim=tower.embed_dim)
+    xc = E.TextCfg(context_length=text.context_length, vocab_size=text.vocab_size, width=text.width, heads=text.heads,
+                   layers=text.layers, embed_dim=text.embed_dim)
+    lc = E.LensCfg(**{k: getattr(lens, k) for k in E.LensCfg.__dataclass_fields__ if hasattr(lens, k)})
+    st = ST.DualAudioStep(sd, tc, xc, lc, "cuda", micro_batch=2, lr=1e-3)
+    loss = st.forward_backward(ins["visual_x"].cuda(), ins["text"].cuda())
+    assert abs(float(loss) - float(outs["dual_loss"])) < 3e-2, (float(loss), float(outs["dual_loss"]))
+    assert all(torch.isfinite(g).all() for g in st.grads.values())
+    st.optimizer_step()
+    l2 = st.step(ins["visual_x"].cuda(), ins["text"].cuda())
+    l3 = st.step(ins["visual_x"].cuda(), ins["text"].cuda())
+    assert torch.isfinite(l3) and float(l3) < float(loss) + 1e-3, (float(loss), float(l2), float(l3))
