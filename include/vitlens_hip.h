@@ -66,6 +66,7 @@ int vl_gemm_qkv_bf16(const void* A, const void* Win, const float* bias, void* q,
                      int B, int L, int H, int dh, int Lp, int K, int lda, float qscale, int first,
                      int count, int cfg, hipStream_t stream);
 int vl_gemm_set_persist_variant(int v);
+int vl_gemm_set_wide_stores(int on);   /* 16-byte epilogue stores (default on); off = 8-byte stores, for A/B runs */
 /* vl_gemm_bf16 + `out2` (with VL_EPI_BF16/VL_ACT_GELU also stores the pre-activation, bf16, for the
  * backward) + `res_div` (VL_EPI_RES_BF16: residual row = m / res_div, i.e. one row broadcast over a group:
  * the PointNet concat([global, local]) conv of dvae.py:207-210 split into two GEMMs). */

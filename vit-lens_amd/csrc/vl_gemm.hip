@@ -40,6 +40,7 @@ struct GemmP {
   float alpha;
   int act;           // 0 none, 1 gelu(erf), 2 relu
   int res_div;       // residual row = m / res_div (>=1): broadcast one row over a group of res_div rows
+  int wide;          // 1: 16-byte epilogue stores via half-wave exchange (bf16 row outputs)
   // QKV scatter
   bf16_t *q, *k, *vt;
   bf16_t *qt, *kt, *v;   // optional extra layouts for the attention backward (transposed q/k, row-major v)
@@ -79,8 +80,113 @@ __device__ __forceinline__ GemmP reload_params() {
 }
 
 // ---- epilogue: lane owns row m = mrow0 + 32*i + fr, columns n = ncol0 + 32*j + 8*q + 4*fg + {0..3} ----
+// lower half-wave <-> upper half-wave exchange of two packed dword pairs (column groups q, q+1):
+// afterwards lanes 0-31 own 16 contiguous bytes of group q and lanes 32-63 16 contiguous bytes of group q+1
+__device__ __forceinline__ u32x4 pair_swap(u32x2 a, u32x2 b) {
+  const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+  const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+  u32x4 o = {(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+  return o;
+}
+
+// 16-byte-store epilogue for the bf16 row-major outputs (EPI_BF16 incl. GELU/ReLU + pre-activation copy,
+// EPI_DGELU, and the q / k / v row layouts of EPI_QKV).  Halves the number of store instructions of the
+// narrow path; the tile epilogue is store-ISSUE bound (each instruction touches 32 rows).
+template <int EPI, int MT, int NTL>
+__device__ __forceinline__ void store_tile_wide(const GemmP& p, f32x16 (&acc)[MT][NTL], int mrow0, int ncol0, int fr, int fg) {
+  [[maybe_unused]] bf16_t* const pq = p.q; [[maybe_unused]] bf16_t* const pk = p.k; [[maybe_unused]] bf16_t* const pv = p.v;
+  [[maybe_unused]] bf16_t* const pqt = p.qt; [[maybe_unused]] bf16_t* const pkt = p.kt; [[maybe_unused]] bf16_t* const pvt = p.vt;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = mrow0 + i * 32 + fr;
+    const bool row_ok = m < p.M;
+    [[maybe_unused]] int qb = 0, ql = 0, vz = 0;
+    if constexpr (EPI == EPI_QKV) {
+      const int ma = (row_ok ? m : p.M - 1) + p.m_off; qb = ma / p.L; ql = ma - qb * p.L;
+      asm volatile("" : "+v"(vz));
+    }
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {
+        const int nbase = ncol0 + j * 32 + qp * 16;             // 16 columns handled by this lane pair
+        if (nbase >= p.N) continue;                              // wave-uniform (N % 16 == 0 on this path)
+        u32x2 pk2[2], pre2[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int q = qp * 2 + h;
+          const int n = nbase + h * 8 + fg * 4;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e] * p.alpha;
+          if (p.bias) {
+            const f32x4 bv = *(const f32x4*)(p.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bv[e];
+          }
+          if constexpr (EPI == EPI_BF16) {
+            pre2[h][0] = pack2bf(v[0], v[1]); pre2[h][1] = pack2bf(v[2], v[3]);
+            if (p.act == 1) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            } else if (p.act == 2) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+          } else if constexpr (EPI == EPI_DGELU) {
+            const int mm = row_ok ? m : p.M - 1;
+            const u32x2 r = *(const u32x2*)((const bf16_t*)p.res + (size_t)mm * p.ldo + n);
+            v[0] *= gelu_erf_grad(bf2f((bf16_t)(r[0] & 0xffff))); v[1] *= gelu_erf_grad(bf2f((bf16_t)(r[0] >> 16)));
+            v[2] *= gelu_erf_grad(bf2f((bf16_t)(r[1] & 0xffff))); v[3] *= gelu_erf_grad(bf2f((bf16_t)(r[1] >> 16)));
+          } else if constexpr (EPI == EPI_QKV) {
+            const int D = p.H << p.dh_shift;
+            const int nv = n + vz;
+            const int wq = (nv >= D) + (nv >= 2 * D);
+            if (wq + p.which0 == 0) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= p.qscale;
+            }
+            // transposed copies keep the narrow 2-byte column stores
+            const int c = nv - wq * D, which = wq + p.which0;
+            const int hh = c >> p.dh_shift, dd = c & ((1 << p.dh_shift) - 1);
+            bf16_t* colp = which == 0 ? pqt : (which == 1 ? pkt : pvt);
+            if (colp && row_ok) {
+              const size_t col_off = ((((size_t)qb * p.H + hh) << p.dh_shift) + dd) * p.Lp + ql;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) colp[col_off + (size_t)e * p.Lp] = f2bf(v[e]);
+            }
+          }
+          pk2[h][0] = pack2bf(v[0], v[1]); pk2[h][1] = pack2bf(v[2], v[3]);
+        }
+        const u32x4 w = pair_swap(pk2[0], pk2[1]);
+        const int nst = nbase + fg * 8;                          // this lane's 8 contiguous columns
+        if constexpr (EPI == EPI_BF16) {
+          if (p.act == 1 && p.out2) {
+            const u32x4 w2 = pair_swap(pre2[0], pre2[1]);
+            if (row_ok) *(u32x4*)((bf16_t*)p.out2 + (size_t)m * p.ldo + nst) = w2;
+          }
+          if (row_ok) *(u32x4*)((bf16_t*)p.out + (size_t)m * p.ldo + nst) = w;
+        } else if constexpr (EPI == EPI_DGELU) {
+          if (row_ok) *(u32x4*)((bf16_t*)p.out + (size_t)m * p.ldo + nst) = w;
+        } else if constexpr (EPI == EPI_QKV) {
+          const int D = p.H << p.dh_shift;
+          const int nv = nst + vz;
+          const int wq = (nv >= D) + (nv >= 2 * D);
+          const int c = nv - wq * D, which = wq + p.which0;
+          const int hh = c >> p.dh_shift, dd = c & ((1 << p.dh_shift) - 1);
+          bf16_t* rowp = which == 0 ? pq : (which == 1 ? pk : pv);
+          if (rowp && row_ok) *(u32x4*)(rowp + (((((size_t)qb * p.H + hh) * p.L + ql) << p.dh_shift) + dd)) = w;
+        }
+      }
+    }
+  }
+}
+
 template <int EPI, int MT, int NTL>
 __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL], int mrow0, int ncol0, int fr, int fg) {
+  if constexpr (EPI == EPI_BF16 || EPI == EPI_DGELU || EPI == EPI_QKV) {
+    if ((p.N & 15) == 0 && p.wide) { store_tile_wide<EPI, MT, NTL>(p, acc, mrow0, ncol0, fr, fg); return; }
+  }
   // rows OUTER: a lane writes the 8 column groups of one row back to back, so the 128-byte lines of that row
   // are completed while still in the write-combining window (columns-outer order cost the fc GEMM 40 %).
   // (pointer fields are copied to locals: selecting among struct members by index forces the struct to scratch)
@@ -636,6 +742,8 @@ static int num_cus() {
   return g_num_cus;
 }
 
+static int g_wide_stores = 1;
+extern "C" int vl_gemm_set_wide_stores(int on) { g_wide_stores = on ? 1 : 0; return 0; }
 static int g_persist_variant = 2;   // 1 = plain persistent loop, 2 = hand-scheduled k-step, 3 = two 256x128 workgroups per CU
 extern "C" int vl_gemm_set_persist_variant(int v) { g_persist_variant = (v >= 1 && v <= 4) ? v : 2; return 0; }
 
@@ -1042,7 +1150,7 @@ extern "C" int vl_gemm_bf16_ex(const void* A, const void* W, const float* bias, 
   VL_CHECK_ARG((ldo & 3) == 0, "vl_gemm_bf16: ldo must be a multiple of 4");
   GemmP p{};
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = bias; p.out = out; p.res = res; p.out2 = out2;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.alpha = alpha; p.act = act; p.res_div = res_div;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.alpha = alpha; p.act = act; p.res_div = res_div; p.wide = g_wide_stores;
   hipError_t e;
   switch (epi) {
     case VL_EPI_BF16: e = run_gemm<EPI_BF16>(p, cfg, stream); break;
@@ -1078,7 +1186,7 @@ extern "C" int vl_gemm_qkv_bf16_ex(const void* A, const void* W, const float* bi
   VL_CHECK_ARG(Lp >= L, "vl_gemm_qkv_bf16: Lp < L");
   GemmP p{};
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = bias;
-  p.M = B * L; p.N = count * H * dh; p.K = K; p.which0 = first; p.res_div = 1; p.lda = lda; p.ldw = K; p.ldo = 0; p.alpha = 1.f;
+  p.M = B * L; p.N = count * H * dh; p.K = K; p.which0 = first; p.res_div = 1; p.wide = g_wide_stores; p.lda = lda; p.ldw = K; p.ldo = 0; p.alpha = 1.f;
   p.q = (bf16_t*)q; p.k = (bf16_t*)k; p.vt = (bf16_t*)vt; p.qt = (bf16_t*)qt; p.kt = (bf16_t*)kt; p.v = (bf16_t*)v; p.L = L; p.H = H; p.dh = dh; p.Lp = Lp; p.qscale = qscale; p.dh_shift = __builtin_ctz((unsigned)dh);
   hipError_t e = run_gemm<EPI_QKV>(p, cfg, stream);
   if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));

@@ -311,3 +311,11 @@ def pad3(c, Kp=64):
     out = torch.empty(c.shape[0], Kp, device=c.device, dtype=torch.bfloat16)
     check(_lib.vl_pad3_bf16(_p(c), _p(out), c.shape[0], Kp, _stream()))
     return out
+
+
+def set_wide_stores(on: bool):
+    _lib.vl_gemm_set_wide_stores(1 if on else 0)
+
+
+def set_persist_variant(v: int):
+    _lib.vl_gemm_set_persist_variant(int(v))
