@@ -35,7 +35,7 @@ def main():
         bias = torch.randn(N, device="cuda")
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         resf = torch.randn(M, N, device="cuda")
-        for cfg in (-1,):
+        for cfg in (5, -1):
             for epi, act, label in ((ops.EPI_BF16, 0, "bf16"), (ops.EPI_BF16, 1, "bf16+gelu"), (ops.EPI_RES_F32, 0, "res_f32")):
                 if quick and (label == "bf16+gelu" and name not in ("fc",)):
                     continue
@@ -50,16 +50,6 @@ def main():
                 res["gemm"].append({"shape": name, "M": M, "N": N, "K": K, "cfg": cfg, "epi": label, "ms": med, "min_ms": mn, "tflops": tf})
                 print(f"gemm {name:5s} cfg{cfg} {label:10s} {med:8.3f} ms  {tf:7.1f} TF/s", flush=True)
         del a, w, out, resf
-    # A/B: 16-byte vs 8-byte epilogue stores (auto config)
-    for name, M, N, K in (("fc", T, 4096, 1024), ("out", T, 1024, 1024)):
-        a = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
-        bias = torch.randn(N, device="cuda"); out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-        for wide in (1, 0, 1, 0):
-            ops.set_wide_stores(wide)
-            med, mn = timeit(lambda: ops.gemm(a, w, bias, out=out, epi=ops.EPI_BF16, act=1, cfg=-1))
-            print(f"wide={wide} gemm {name} bf16+gelu {med:8.3f} ms {2.0 * M * N * K / med / 1e9:7.1f} TF/s", flush=True)
-        ops.set_wide_stores(1)
-        del a, w, out
     # qkv + attention at the bench shape
     B, L, H, dh = 256, 257, 16, 64
     D = H * dh
@@ -68,12 +58,10 @@ def main():
     q = torch.empty(B, H, L, dh, device="cuda", dtype=torch.bfloat16); k = torch.empty_like(q)
     vt = torch.zeros(B, H, dh, 264, device="cuda", dtype=torch.bfloat16)
     o = torch.empty(B * L, D, device="cuda", dtype=torch.bfloat16)
-    for wide in (1, 0, 1, 0):
-        ops.set_wide_stores(wide)
-        med, mn = timeit(lambda: ops.gemm_qkv(x, w, bias, q, k, vt, B, L, H, dh, cfg=-1))
-        print(f"wide={wide} qkv-scatter {med:8.3f} ms {2.0 * B * L * 3 * D * D / med / 1e9:7.1f} TF/s", flush=True)
-        res["gemm"].append({"shape": "qkv_scatter", "wide": wide, "ms": med, "tflops": 2.0 * B * L * 3 * D * D / med / 1e9})
-    ops.set_wide_stores(1)
+    for cfg in (5, -1):
+        med, mn = timeit(lambda: ops.gemm_qkv(x, w, bias, q, k, vt, B, L, H, dh, cfg=cfg))
+        print(f"cfg{cfg} qkv-scatter {med:8.3f} ms {2.0 * B * L * 3 * D * D / med / 1e9:7.1f} TF/s", flush=True)
+        res["gemm"].append({"shape": "qkv_scatter", "cfg": cfg, "ms": med, "tflops": 2.0 * B * L * 3 * D * D / med / 1e9})
     med, mn = timeit(lambda: ops.attn_fwd(q, k, vt, o))
     fl = 4.0 * B * H * L * L * dh
     print(f"attn fwd {med:8.3f} ms {fl / med / 1e9:7.1f} TF/s", flush=True)

@@ -742,7 +742,7 @@ static int num_cus() {
   return g_num_cus;
 }
 
-static int g_wide_stores = 1;
+static int g_wide_stores = 0;   // measured (profiles/r01e_kernel_bench_wide.log): the 16-byte exchange stores are 5-7 % SLOWER than the 8-byte path on fc/out
 extern "C" int vl_gemm_set_wide_stores(int on) { g_wide_stores = on ? 1 : 0; return 0; }
 static int g_persist_variant = 2;   // 1 = plain persistent loop, 2 = hand-scheduled k-step, 3 = two 256x128 workgroups per CU
 extern "C" int vl_gemm_set_persist_variant(int v) { g_persist_variant = (v >= 1 && v <= 4) ? v : 2; return 0; }
