@@ -179,6 +179,24 @@ int vl_knn_group(const float* xyz, const int64_t* center_idx, int* nidx, void* p
                  int k, int Kp, hipStream_t stream);
 int vl_group_max(const void* x, long ldx, void* out, int out_dtype, long ldo, long groups, int M, int C, hipStream_t stream);
 int vl_pad3_bf16(const float* c, void* out, long R, int Kp, hipStream_t stream);
+/* ---- trainable point tokenizer: nn.BatchNorm1d over [R = B*G*M, C] bf16 activations (dvae.py:184-194) ----
+ * ws: caller workspace of (nchunk + 1) * 2 * C floats (row-chunk partial sums; deterministic, no atomics).
+ * vl_bn_stats: biased batch mean/var per column; running_mean/var (optional) updated as nn.BatchNorm1d does
+ * (momentum, unbiased variance).  vl_bn_apply: y = gamma*(x-mean)/sqrt(var+eps)+beta (+ReLU); pass the batch
+ * statistics (train) or the running statistics (eval).  vl_bn_bwd: dgamma/dbeta are ACCUMULATED; dx (optional)
+ * is the input gradient; train=0 treats mean/var as constants (eval-mode BN). */
+int vl_bn_stats(const void* x, long ldx, int R, int C, float* ws, int nchunk, float* mean, float* var,
+                float* running_mean, float* running_var, float momentum, hipStream_t stream);
+int vl_bn_apply(const void* x, long ldx, const float* mean, const float* var, const float* gamma, const float* beta,
+                float eps, int relu, void* out, long ldo, long R, int C, hipStream_t stream);
+int vl_bn_bwd(const void* dy, long lddy, const void* x, long ldx, const float* mean, const float* var,
+              const float* gamma, const float* beta, float eps, int relu, int train, float* ws, int nchunk,
+              float* dgamma, float* dbeta, void* dx, long lddx, int R, int C, hipStream_t stream);
+/* backward of torch.max over the M rows of each group (gradient to the first arg-max row), added to `base`
+ * (optional); and the sum over the M rows of each group (backward of the expand in dvae.py:207-208). bf16. */
+int vl_group_max_bwd(const void* f, long ldf, const void* dg, long lddg, const void* base, long ldb, void* out,
+                     long ldo, long groups, int M, int C, hipStream_t stream);
+int vl_group_sum(const void* x, long ldx, void* out, long ldo, long groups, int M, int C, hipStream_t stream);
 int vl_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, float grad_scale, hipStream_t stream);
 int vl_clamp_scalar(float* p, float lo, float hi, hipStream_t stream);

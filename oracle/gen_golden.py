@@ -258,6 +258,42 @@ def dist_case(world=2, b=3, d=16, port=29611):
     print(f"gather_w{world}:", len(res), "arrays")
 
 
+def pc_bn_train_case(oc, seed):
+    """Same tiny point-cloud model and inputs as tiny_pc.npz, but with the PointTokenizer's BatchNorm layers in
+    TRAIN mode (batch statistics, running-stat update) - what `model.train()` gives the PC recipe
+    (training/train.py:90).  Only the quantities that differ from tiny_pc.npz are stored."""
+    torch.manual_seed(seed)
+    args = tiny_args("pc")
+    model = oc.tri_create_model("tiny-lens", None, precision="fp32", device="cpu", output_dict=True, args=args)
+    model.eval()
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.8, 1.2)
+            m.weight.data.normal_(1, 0.05)
+            m.bias.data.normal_(0, 0.05)
+    ref = np.load(os.path.join(OUT, "tiny_pc.npz"))
+    for k, v in model.state_dict().items():      # the two cases must share weights
+        if "num_batches_tracked" not in k:
+            assert np.array_equal(ref["sd/" + k], v.numpy()), k
+    image, text, vx = (torch.tensor(ref["in/" + k]) for k in ("image", "text", "visual_x"))
+    model.visual.visual_adapter.train()
+    from open_clip.loss import TriClipLoss
+    torch.manual_seed(seed + 7)
+    out = model(image=image, text=text, visual_x=vx)
+    loss = TriClipLoss()(out["image_features"], out["text_features"], out["visual_features"], out["logit_scale"])
+    loss.backward()
+    res = {"out/step_loss": loss.detach().numpy(), "out/visual_features": out["visual_features"].detach().numpy()}
+    for name, prm in model.named_parameters():
+        if (name.startswith("visual.") or name == "logit_scale") and prm.grad is not None:
+            res["grad/" + name] = prm.grad.numpy()
+    for k, v in model.state_dict().items():
+        if "running_" in k:
+            res["sd_after/" + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "tiny_pc_bntrain.npz"), **res)
+    print(f"tiny_pc_bntrain: {len(res)} arrays, loss {float(loss):.6f}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     oc = ref_loader.load()
@@ -267,6 +303,7 @@ def main():
         oc.add_model_config(td)
         for i, m in enumerate(("depth", "audio", "pc")):
             tiny_case(oc, m, seed=20 + i)
+        pc_bn_train_case(oc, seed=22)
     per_op_case(oc)
     tokenizer_case(oc)
     dist_case(2)

@@ -202,12 +202,19 @@ def knn_indices(xyz: Tensor, centers: Tensor, k: int) -> Tensor:
     return d.topk(k, dim=-1, largest=False, sorted=False).indices
 
 
-def batch_norm_1d(x: Tensor, sd: SD, p: str, training: bool, eps: float = 1e-5) -> Tensor:
+def batch_norm_1d(x: Tensor, sd: SD, p: str, training: bool, eps: float = 1e-5,
+                  running_out: Optional[Dict[str, Tensor]] = None, momentum: float = 0.1) -> Tensor:
     """nn.BatchNorm1d on [B, C, n] (dvae.py:183-194): batch stats (biased var) in train
-    mode, running stats in eval mode."""
+    mode, running stats in eval mode.  In train mode the module also updates its running
+    statistics (momentum 0.1, UNBIASED variance); they are returned through `running_out`."""
     if training:
         mu = x.mean(dim=(0, 2), keepdim=True)
         var = ((x - mu) ** 2).mean(dim=(0, 2), keepdim=True)
+        if running_out is not None:
+            n = x.shape[0] * x.shape[2]
+            running_out[p + "running_mean"] = ((1 - momentum) * sd[p + "running_mean"] + momentum * mu.detach().flatten())
+            running_out[p + "running_var"] = ((1 - momentum) * sd[p + "running_var"]
+                                              + momentum * var.detach().flatten() * n / max(n - 1, 1))
     else:
         mu = sd[p + "running_mean"].view(1, -1, 1)
         var = sd[p + "running_var"].view(1, -1, 1)
@@ -215,7 +222,7 @@ def batch_norm_1d(x: Tensor, sd: SD, p: str, training: bool, eps: float = 1e-5) 
 
 
 def point_tokens(sd: SD, p: str, pts: Tensor, lens: LensSpec, fps_start: Tensor,
-                 training: bool = False) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+                 training: bool = False, running_out: Optional[Dict[str, Tensor]] = None) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """PointTokenizer.forward, point_encoder.py:350-362 (Group dvae.py:150-176,
     Encoder dvae.py:196-212).  Returns (x [B,G,trans], pos [B,G,trans], fps idx, knn idx)."""
     a = p + "visual_adapter."
@@ -230,12 +237,12 @@ def point_tokens(sd: SD, p: str, pts: Tensor, lens: LensSpec, fps_start: Tensor,
     def conv1(x, name):
         return torch.einsum("oc,bcn->bon", sd[a + name + ".weight"][:, :, 0], x) + sd[a + name + ".bias"].view(1, -1, 1)
     f = conv1(g, "encoder.first_conv.0")
-    f = torch.relu(batch_norm_1d(f, sd, a + "encoder.first_conv.1.", training))
+    f = torch.relu(batch_norm_1d(f, sd, a + "encoder.first_conv.1.", training, running_out=running_out))
     f = conv1(f, "encoder.first_conv.3")                                 # [BG,256,M]
     fg = f.max(dim=2, keepdim=True).values
     f = torch.cat([fg.expand(-1, -1, M), f], dim=1)                      # [BG,512,M]
     f = conv1(f, "encoder.second_conv.0")
-    f = torch.relu(batch_norm_1d(f, sd, a + "encoder.second_conv.1.", training))
+    f = torch.relu(batch_norm_1d(f, sd, a + "encoder.second_conv.1.", training, running_out=running_out))
     f = conv1(f, "encoder.second_conv.3")
     tok = f.max(dim=2).values.reshape(B, G, lens.pc_encoder_dims)
     tok = linear(tok, sd[a + "reduce_dim.weight"], sd[a + "reduce_dim.bias"])
@@ -316,7 +323,7 @@ def encode_image(sd: SD, image: Tensor, spec: TowerSpec, normalize: bool = False
 
 def encode_visual(sd: SD, x: Tensor, spec: TowerSpec, lens: LensSpec, normalize: bool = False,
                   prefix: str = "visual.", fps_start: Optional[Tensor] = None,
-                  training: bool = False) -> Tensor:
+                  training: bool = False, running_out: Optional[Dict[str, Tensor]] = None) -> Tensor:
     """TriCLIP.encode_visual, model.py:524-526 -> VisionTransformer.forward 723-792."""
     if lens.modality == "image":
         tok = image_tokens(sd, prefix, x, spec)
@@ -326,7 +333,7 @@ def encode_visual(sd: SD, x: Tensor, spec: TowerSpec, lens: LensSpec, normalize:
         elif lens.modality == "audio":
             t, pos = audio_tokens(sd, prefix, x, lens)
         elif lens.modality == "pc":
-            t, pos, _, _ = point_tokens(sd, prefix, x, lens, fps_start, training)
+            t, pos, _, _ = point_tokens(sd, prefix, x, lens, fps_start, training, running_out)
         else:
             raise NotImplementedError(lens.modality)
         tok = t + (0 * pos if lens.disable_adapter_pos else pos)

@@ -71,6 +71,37 @@ def test_step_param_grads(modality):
         close(sd[k].grad, g, rtol=2e-4, atol=2e-6)
 
 
+@pytest.mark.parametrize("bn_train", [False, True])
+def test_step_param_grads_point_cloud(bn_train):
+    """PC recipe: tokenizer (incl. BatchNorm affine) + Perceiver + ViT gradients; eval-mode BN against tiny_pc.npz,
+    train-mode BN (batch statistics + running-stat update) against tiny_pc_bntrain.npz."""
+    sd, ins, outs, grads, meta = split(load_npz("tiny_pc.npz"))
+    tower, text, lens = specs_from_meta(meta)
+    if bn_train:
+        _, _, outs, grads, _ = split(load_npz("tiny_pc_bntrain.npz"))
+        after = {k[9:]: torch.from_numpy(v) for k, v in load_npz("tiny_pc_bntrain.npz").items() if k.startswith("sd_after/")}
+    sd = {k: (v.clone().requires_grad_(True) if ((k.startswith("visual.") and "running" not in k) or k == "logit_scale") else v)
+          for k, v in sd.items()}
+    running = {}
+    i = O.encode_image(sd, ins["image"], tower, normalize=True)
+    t = O.encode_text(sd, ins["text"], text, normalize=True)
+    v = O.encode_visual(sd, ins["visual_x"], tower, lens, normalize=True, fps_start=ins["fps_start"], training=bn_train,
+                        running_out=running)
+    close(v, outs["visual_features"], rtol=1e-4, atol=1e-5)
+    loss = O.tri_clip_loss(i, t, v, sd["logit_scale"].exp())
+    close(loss, outs["step_loss"])
+    loss.backward()
+    assert len(grads) > 100
+    for k, g in grads.items():
+        # conv biases in front of a train-mode BatchNorm have a mathematically zero gradient (round-off only)
+        atol = 1e-6 if (bn_train and k.endswith(("first_conv.0.bias", "second_conv.0.bias"))) else 2e-6
+        close(sd[k].grad, g, rtol=5e-4, atol=atol)
+    if bn_train:
+        assert len(running) == 4
+        for k, r in running.items():
+            close(r, after[k], rtol=1e-5, atol=1e-6)
+
+
 def test_point_grouping_indices():
     sd, ins, outs, grads, meta = split(load_npz("tiny_pc.npz"))
     tower, text, lens = specs_from_meta(meta)

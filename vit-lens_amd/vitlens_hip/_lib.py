@@ -43,6 +43,11 @@ SIGNATURES = {
     "vl_knn_group": [P, P, P, P, I, I, I, I, I, P],
     "vl_group_max": [P, L, P, I, L, L, I, I, P],
     "vl_pad3_bf16": [P, P, L, I, P],
+    "vl_bn_stats": [P, L, I, I, P, I, P, P, P, P, F, P],
+    "vl_bn_apply": [P, L, P, P, P, P, F, I, P, L, L, I, P],
+    "vl_bn_bwd": [P, L, P, L, P, P, P, P, F, I, I, P, I, P, P, P, L, I, I, P],
+    "vl_group_max_bwd": [P, L, P, L, P, L, P, L, L, I, I, P],
+    "vl_group_sum": [P, L, P, L, L, I, I, P],
     "vl_gemm_qkv_bf16_ex": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, I, I, P],
     "vl_layernorm_bwd": [P, I, L, P, I, L, P, P, P, P, P, P, L, I, I, P],
     "vl_layernorm_bwd_params": [P, I, L, P, I, L, P, P, P, P, I, I, P],

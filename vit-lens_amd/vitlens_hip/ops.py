@@ -313,6 +313,57 @@ def pad3(c, Kp=64):
     return out
 
 
+def _bn_chunks(R):
+    return max(1, min(1024, R // 64))
+
+
+def bn_stats(x, running_mean=None, running_var=None, momentum=0.1):
+    """Batch statistics of nn.BatchNorm1d over the rows of x [R,C] bf16 -> (mean, biased var) f32 [C]."""
+    _chk2d(x, "x", torch.bfloat16)
+    R, C = x.shape
+    n = _bn_chunks(R)
+    ws = torch.empty((n + 1) * 2 * C, device=x.device, dtype=torch.float32)
+    mean = torch.empty(C, device=x.device, dtype=torch.float32); var = torch.empty_like(mean)
+    check(_lib.vl_bn_stats(_p(x), x.stride(0), R, C, _p(ws), n, _p(mean), _p(var), _p(running_mean), _p(running_var),
+                           momentum, _stream()))
+    return mean, var
+
+
+def bn_apply(x, mean, var, gamma, beta, eps=1e-5, relu=False, out=None):
+    _chk2d(x, "x", torch.bfloat16)
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.vl_bn_apply(_p(x), x.stride(0), _p(mean), _p(var), _p(gamma), _p(beta), eps, int(relu), _p(out), out.stride(0),
+                           x.shape[0], x.shape[1], _stream()))
+    return out
+
+
+def bn_bwd(dy, x, mean, var, gamma, beta, dgamma, dbeta, eps=1e-5, relu=False, train=True, need_dx=True):
+    """dgamma/dbeta (f32 [C]) are accumulated; returns dx bf16 [R,C] (None when need_dx is False)."""
+    _chk2d(dy, "dy", torch.bfloat16); _chk2d(x, "x", torch.bfloat16)
+    R, C = x.shape
+    n = _bn_chunks(R)
+    ws = torch.empty((n + 1) * 2 * C, device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x) if need_dx else None
+    check(_lib.vl_bn_bwd(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(mean), _p(var), _p(gamma), _p(beta), eps, int(relu),
+                         int(train), _p(ws), n, _p(dgamma), _p(dbeta), _p(dx), dx.stride(0) if need_dx else 0, R, C, _stream()))
+    return dx
+
+
+def group_max_bwd(f, dg, M, base=None):
+    _chk2d(f, "f", torch.bfloat16); _chk2d(dg, "dg", torch.bfloat16)
+    out = torch.empty_like(f)
+    check(_lib.vl_group_max_bwd(_p(f), f.stride(0), _p(dg), dg.stride(0), _p(base), base.stride(0) if base is not None else 0,
+                                _p(out), out.stride(0), f.shape[0] // M, M, f.shape[1], _stream()))
+    return out
+
+
+def group_sum(x, M):
+    _chk2d(x, "x", torch.bfloat16)
+    out = torch.empty(x.shape[0] // M, x.shape[1], device=x.device, dtype=torch.bfloat16)
+    check(_lib.vl_group_sum(_p(x), x.stride(0), _p(out), out.stride(0), x.shape[0] // M, M, x.shape[1], _stream()))
+    return out
+
+
 def set_wide_stores(on: bool):
     _lib.vl_gemm_set_wide_stores(1 if on else 0)
 

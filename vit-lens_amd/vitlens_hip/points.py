@@ -65,3 +65,153 @@ class PointTokenizerEngine:
         out = torch.empty_like(tok)
         ops.gemm(p1, self.wp2, self.bp2, out=out, res=tok, epi=ops.EPI_RES_BF16, cfg=c)      # pos + tokens
         return out
+
+
+class PointTokenizerTrainer:
+    """Trainable PointTokenizer (point_encoder.py:325-362): same dataflow as PointTokenizerEngine but with the
+    BatchNorm layers kept apart from the 1x1 convolutions (train-mode batch statistics + running-stat update, or
+    eval-mode running statistics), activations kept for the backward pass, and all parameter gradients
+    accumulated into `grads` under the reference's parameter names (conv weights as [out, in] matrices;
+    the 3-channel inputs are zero-padded to 64 for the GEMM, gradients are cut back to 3 columns).
+
+    FPS / kNN produce indices only (misc.fps, knn_point run under no_grad-equivalent integer ops), so the
+    backward stops at the gathered, centre-subtracted patches."""
+
+    KP = 64
+    BN_EPS, BN_MOMENTUM = 1e-5, 0.1           # nn.BatchNorm1d defaults (dvae.py:186,191)
+
+    def __init__(self, sd, a: str, lens, device, grads=None, gemm_cfg=-1, bn_training=True):
+        self.a, self.lens, self.device, self.cfg, self.bn_training = a, lens, torch.device(device), gemm_cfg, bn_training
+        self.grads = {} if grads is None else grads
+        f32 = lambda k: sd[a + k].detach().float().to(device).contiguous()
+        m = self.masters = {}
+        for k in ("encoder.first_conv.0", "encoder.first_conv.3", "encoder.second_conv.0", "encoder.second_conv.3"):
+            m[a + k + ".weight"] = f32(k + ".weight")[:, :, 0].contiguous(); m[a + k + ".bias"] = f32(k + ".bias")
+        for k in ("encoder.first_conv.1", "encoder.second_conv.1"):
+            m[a + k + ".weight"] = f32(k + ".weight"); m[a + k + ".bias"] = f32(k + ".bias")
+        for k in ("reduce_dim", "pos_embed.0", "pos_embed.2"):
+            m[a + k + ".weight"] = f32(k + ".weight"); m[a + k + ".bias"] = f32(k + ".bias")
+        self.running = {k: (f32(k + ".running_mean"), f32(k + ".running_var")) for k in ("encoder.first_conv.1", "encoder.second_conv.1")}
+        self.op = {}
+        self.refresh_operands()
+        self.ctx = None
+
+    # bf16 GEMM operands (forward: W, backward: W^T) derived from the f32 masters
+    def refresh_operands(self):
+        a, m, o = self.a, self.masters, self.op
+        bf = lambda t: t.to(BF).contiguous()
+
+        def padk(w):
+            out = torch.zeros(w.shape[0], self.KP, device=w.device, dtype=BF)
+            out[:, :w.shape[1]] = w.to(BF)
+            return out
+        w3 = m[a + "encoder.second_conv.0.weight"]
+        half = w3.shape[1] // 2
+        o["w1"] = padk(m[a + "encoder.first_conv.0.weight"])
+        o["w2"] = bf(m[a + "encoder.first_conv.3.weight"]); o["w2T"] = bf(m[a + "encoder.first_conv.3.weight"].t())
+        o["w3g"], o["w3l"] = bf(w3[:, :half]), bf(w3[:, half:])
+        o["w3gT"], o["w3lT"] = bf(w3[:, :half].t()), bf(w3[:, half:].t())
+        o["w4"] = bf(m[a + "encoder.second_conv.3.weight"]); o["w4T"] = bf(m[a + "encoder.second_conv.3.weight"].t())
+        o["wr"] = bf(m[a + "reduce_dim.weight"]); o["wrT"] = bf(m[a + "reduce_dim.weight"].t())
+        o["wp0"] = padk(m[a + "pos_embed.0.weight"])
+        o["wp2"] = bf(m[a + "pos_embed.2.weight"]); o["wp2T"] = bf(m[a + "pos_embed.2.weight"].t())
+
+    def grad_buffer(self, name):
+        g = self.grads.get(name)
+        if g is None:
+            g = torch.zeros_like(self.masters[name]); self.grads[name] = g
+        return g
+
+    def _bn(self, z, k):
+        a, m = self.a, self.masters
+        if self.bn_training:
+            rm, rv = self.running[k]
+            mean, var = ops.bn_stats(z, rm, rv, self.BN_MOMENTUM)
+        else:
+            mean, var = self.running[k]
+        h = ops.bn_apply(z, mean, var, m[a + k + ".weight"], m[a + k + ".bias"], self.BN_EPS, relu=True)
+        return h, mean, var
+
+    def forward(self, pts: torch.Tensor, fps_start=None) -> torch.Tensor:
+        """pts [B,N,3] -> tokens + pos, bf16 [B*G, trans_dim]."""
+        L, a, m, o, c = self.lens, self.a, self.masters, self.op, self.cfg
+        M = L.pc_group_size
+        pts = pts.to(self.device).contiguous().float()
+        if fps_start is None:
+            fps_start = torch.randint(0, pts.shape[1], (pts.shape[0],), device=self.device, dtype=torch.long)
+        cidx, centers = ops.fps(pts, fps_start.to(self.device), L.pc_num_group)
+        patches, _ = ops.knn_group(pts, cidx, L.pc_group_size, Kp=self.KP)
+        z1 = ops.gemm(patches, o["w1"], m[a + "encoder.first_conv.0.bias"], cfg=c)
+        h1, m1, v1 = self._bn(z1, "encoder.first_conv.1")
+        f = ops.gemm(h1, o["w2"], m[a + "encoder.first_conv.3.bias"], cfg=c)
+        g = ops.group_max(f, M)
+        t = ops.gemm(g, o["w3g"], m[a + "encoder.second_conv.0.bias"], cfg=c)
+        z3 = torch.empty(f.shape[0], o["w3l"].shape[0], device=self.device, dtype=BF)
+        ops.gemm(f, o["w3l"], None, out=z3, res=t, res_div=M, epi=ops.EPI_RES_BF16, cfg=c)
+        h2, m3, v3 = self._bn(z3, "encoder.second_conv.1")
+        f2 = ops.gemm(h2, o["w4"], m[a + "encoder.second_conv.3.bias"], cfg=c)
+        g2 = ops.group_max(f2, M)
+        tok = ops.gemm(g2, o["wr"], m[a + "reduce_dim.bias"], cfg=c)
+        c3 = ops.pad3(centers, self.KP)
+        u = torch.empty(c3.shape[0], o["wp0"].shape[0], device=self.device, dtype=BF)
+        p1 = ops.gemm(c3, o["wp0"], m[a + "pos_embed.0.bias"], act=ops.ACT_GELU, cfg=c, out2=u)
+        out = torch.empty_like(tok)
+        ops.gemm(p1, o["wp2"], m[a + "pos_embed.2.bias"], out=out, res=tok, epi=ops.EPI_RES_BF16, cfg=c)
+        self.ctx = (patches, z1, m1, v1, h1, f, g, z3, m3, v3, h2, f2, g2, c3, u, p1)
+        return out
+
+    def _dw(self, name, dy, x, cols=None):
+        """grads[name] += dy^T x (both bf16 [rows, *])."""
+        rows = dy.shape[0]
+        rp = (rows + 63) // 64 * 64
+        g = self.grad_buffer(name)
+        if cols is None:
+            ops.gemm(ops.transpose_to_bf16(dy, ldo=rp), ops.transpose_to_bf16(x, ldo=rp), None, out=g, res=g,
+                     epi=ops.EPI_RES_F32, cfg=self.cfg)
+        else:       # zero-padded input channels: compute the padded product, accumulate the real columns
+            full = ops.gemm(ops.transpose_to_bf16(dy, ldo=rp), ops.transpose_to_bf16(x, ldo=rp), None, epi=ops.EPI_F32, cfg=self.cfg)
+            ops.axpy(g, full[:, :cols].contiguous(), 1.0)
+
+    def _db(self, name, dy):
+        ops.colsum(dy, self.grad_buffer(name))
+
+    def backward(self, dctx: torch.Tensor):
+        """dctx f32|bf16 [B*G, trans_dim] = gradient w.r.t. the returned tokens+pos."""
+        L, a, m, o, c = self.lens, self.a, self.masters, self.op, self.cfg
+        M = L.pc_group_size
+        patches, z1, m1, v1, h1, f, g, z3, m3, v3, h2, f2, g2, c3, u, p1 = self.ctx
+        dout = dctx if dctx.dtype == BF else ops.cast_bf16(dctx.contiguous())
+        tr = self.bn_training
+        # positional MLP: pos = W2 gelu(W0 c + b0) + b2
+        self._dw(a + "pos_embed.2.weight", dout, p1); self._db(a + "pos_embed.2.bias", dout)
+        du = torch.empty_like(u)
+        ops.gemm(dout, o["wp2T"], None, out=du, res=u, epi=ops.EPI_DGELU, cfg=c)
+        self._dw(a + "pos_embed.0.weight", du, c3, cols=3); self._db(a + "pos_embed.0.bias", du)
+        # token branch
+        self._dw(a + "reduce_dim.weight", dout, g2); self._db(a + "reduce_dim.bias", dout)
+        dg2 = ops.gemm(dout, o["wrT"], None, cfg=c)
+        df2 = ops.group_max_bwd(f2, dg2, M)
+        self._dw(a + "encoder.second_conv.3.weight", df2, h2); self._db(a + "encoder.second_conv.3.bias", df2)
+        dh2 = ops.gemm(df2, o["w4T"], None, cfg=c)
+        k = "encoder.second_conv.1"
+        dz3 = ops.bn_bwd(dh2, z3, m3, v3, m[a + k + ".weight"], m[a + k + ".bias"], self.grad_buffer(a + k + ".weight"),
+                         self.grad_buffer(a + k + ".bias"), self.BN_EPS, relu=True, train=tr)
+        dt = ops.group_sum(dz3, M)
+        gw = self.grad_buffer(a + "encoder.second_conv.0.weight")
+        half = gw.shape[1] // 2
+        rp = (dz3.shape[0] + 63) // 64 * 64
+        ops.gemm(ops.transpose_to_bf16(dz3, ldo=rp), ops.transpose_to_bf16(f, ldo=rp), None, out=gw[:, half:], res=gw[:, half:],
+                 epi=ops.EPI_RES_F32, cfg=c)
+        rg = (dt.shape[0] + 63) // 64 * 64
+        ops.gemm(ops.transpose_to_bf16(dt, ldo=rg), ops.transpose_to_bf16(g, ldo=rg), None, out=gw[:, :half], res=gw[:, :half],
+                 epi=ops.EPI_RES_F32, cfg=c)
+        self._db(a + "encoder.second_conv.0.bias", dt)
+        dg = ops.gemm(dt, o["w3gT"], None, cfg=c)
+        dfl = ops.gemm(dz3, o["w3lT"], None, cfg=c)
+        df = ops.group_max_bwd(f, dg, M, base=dfl)
+        self._dw(a + "encoder.first_conv.3.weight", df, h1); self._db(a + "encoder.first_conv.3.bias", df)
+        dh1 = ops.gemm(df, o["w2T"], None, cfg=c)
+        k = "encoder.first_conv.1"
+        dz1 = ops.bn_bwd(dh1, z1, m1, v1, m[a + k + ".weight"], m[a + k + ".bias"], self.grad_buffer(a + k + ".weight"),
+                         self.grad_buffer(a + k + ".bias"), self.BN_EPS, relu=True, train=tr)
+        self._dw(a + "encoder.first_conv.0.weight", dz1, patches, cols=3); self._db(a + "encoder.first_conv.0.bias", dz1)

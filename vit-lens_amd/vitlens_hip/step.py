@@ -170,30 +170,23 @@ class TriModalDepthStep:
         return loss
 
 
-class DualAudioStep:
-    """Audio <-> text dual-tower step (reference `train_dual_one_epoch` + ClipLossGeneral, training/train.py:315-470,
-    recipe TRAIN_INFERENCE.md:283-299 with --use_dual_loss --align_to text): text tower frozen, visual tower =
-    AST tokenizer + Perceiver (trainable) -> locked ViT with unlocked class_embedding.  Multi-GPU semantics are the
-    tri-modal step's (packed all-gather, flat gradient all-reduce = mean of per-rank gradients of the global loss)."""
+class _PerceiverLensStep:
+    """Shared plumbing of the steps whose trainable part is a Lens (tokenizer + Perceiver) in front of a locked ViT:
+    fp32 masters of the Perceiver under the reference's parameter names, one flat fp32 gradient buffer (a single
+    all-reduce per step = DDP's mean of per-rank gradients), AdamW, bf16 operand refresh, logit-scale clamp."""
 
-    def __init__(self, sd, tower: TowerCfg, text: TextCfg, lens: LensCfg, device, micro_batch: int = 256, lr: float = 2e-4,
-                 betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2, rank: int = 0, world_size: int = 1,
-                 gemm_cfg: int = -1):
-        from .train import AudioLensTrainer
+    def _init_common(self, sd, device, micro_batch, rank, world_size):
         self.dev, self.mb, self.rank, self.world = torch.device(device), micro_batch, rank, world_size
-        self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg)
-        self.lens = LensEngine(sd, "visual.", tower, lens, device, gemm_cfg=gemm_cfg)
-        self._mk = lambda: AudioLensTrainer(self.lens)
         self.trainers = []
         self.logit_scale = sd["logit_scale"].detach().float().reshape(1).to(device)
-        pe, P = self.lens.perceiver, "visual.perceiver."
-        f32 = lambda k: sd[k].detach().float().to(device).contiguous()
-        self.masters: Dict[str, torch.Tensor] = {"logit_scale": self.logit_scale, "visual.class_embedding": self.lens.vit.cls,
-                                                 "visual.visual_adapter.pos_emb": self.lens.adapter_pos,
-                                                 "visual.visual_adapter.conv1.weight_gemm": self.lens.conv_w.float(),
-                                                 P + "latents": pe.latents}
+        self.masters: Dict[str, torch.Tensor] = {"logit_scale": self.logit_scale}
         self.refresh = []        # (master name, forward bf16 tensor, key path of the transposed copy in trainer.perc.wT)
-        from .engine import _interleave_geglu
+        self.flat_grad, self.grads = None, {}
+
+    def _collect_perceiver(self, sd):
+        pe, P = self.lens.perceiver, "visual.perceiver."
+        f32 = lambda k: sd[k].detach().float().to(self.dev).contiguous()
+        self.masters[P + "latents"] = pe.latents
         for li, lay in enumerate(pe.layers):
             q = f"{P}layers.{li}."
             self._attn(q + "0.", lay["x_attn"], lay["x_norm"], (li, "x"), sd, f32, ctx_norm=lay["x_norm_ctx"])
@@ -202,8 +195,6 @@ class DualAudioStep:
                 r = f"{q}2.{sj}."
                 self._attn(r + "0.", sl["attn"], sl["norm"], (li, "selfs", sj), sd, f32)
                 self._ff(r + "1.", sl["ff"], sl["ff_norm"], (li, "selfs", sj), sd, f32)
-        self.opt = AdamW(self.masters, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
-        self.flat_grad, self.grads = None, {}
 
     def _attn(self, p, a, norm, path, sd, f32, ctx_norm=None):
         self.masters[p + "norm.weight"], self.masters[p + "norm.bias"] = norm
@@ -235,16 +226,30 @@ class DualAudioStep:
             self.trainers.append(t)
         return self.trainers[i]
 
+    def _bind_grads(self, t):
+        t.tower.grads = self.grads; t.perc.grads = self.grads
+
     def _alloc_flat_grads(self):
-        n = sum(v.numel() for v in self.masters.values())
-        self.flat_grad = torch.zeros(n, device=self.dev, dtype=torch.float32)
+        al = lambda n: (n + 3) // 4 * 4                       # every view starts 16-byte aligned
+        self.flat_grad = torch.zeros(sum(al(v.numel()) for v in self.masters.values()), device=self.dev, dtype=torch.float32)
         off = 0
         for k, v in self.masters.items():
-            self.grads[k] = self.flat_grad[off:off + v.numel()].view(v.shape); off += v.numel()
+            self.grads[k] = self.flat_grad[off:off + v.numel()].view(v.shape); off += al(v.numel())
         for t in self.trainers:
-            t.tower.grads = self.grads; t.perc.grads = self.grads
+            self._bind_grads(t)
 
-    def _refresh_operands(self):
+    def _prepare(self, B):
+        mb = min(self.mb, B)
+        assert B % mb == 0, "per-GPU batch must be a multiple of the micro-batch"
+        nmb = B // mb
+        if self.flat_grad is None:
+            for i in range(nmb):
+                self._trainer(i)
+            self._alloc_flat_grads()
+        self.flat_grad.zero_()
+        return mb, nmb
+
+    def _refresh_perceiver(self):
         wT = self.trainers[0].perc.wT
         for name, fwd, path in self.refresh:
             m = self.masters[name]
@@ -253,18 +258,48 @@ class DualAudioStep:
             for k in path[1:-1]:
                 node = node[k]
             ops.transpose_to_bf16(m, ldo=m.shape[0], out=node[path[-1]])
+
+    def _refresh_operands(self):
+        self._refresh_perceiver()
+
+    def optimizer_step(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+            self.opt.step(self.grads, grad_scale=1.0 / self.world)
+        else:
+            self.opt.step(self.grads)
+        self._refresh_operands()
+        ops.clamp_scalar(self.logit_scale, 0.0, math.log(100.0))
+
+
+class DualAudioStep(_PerceiverLensStep):
+    """Audio <-> text dual-tower step (reference `train_dual_one_epoch` + ClipLossGeneral, training/train.py:315-470,
+    recipe TRAIN_INFERENCE.md:283-299 with --use_dual_loss --align_to text): text tower frozen, visual tower =
+    AST tokenizer + Perceiver (trainable) -> locked ViT with unlocked class_embedding.  Multi-GPU semantics are the
+    tri-modal step's (packed all-gather, flat gradient all-reduce = mean of per-rank gradients of the global loss)."""
+
+    def __init__(self, sd, tower: TowerCfg, text: TextCfg, lens: LensCfg, device, micro_batch: int = 256, lr: float = 2e-4,
+                 betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2, rank: int = 0, world_size: int = 1,
+                 gemm_cfg: int = -1):
+        from .train import AudioLensTrainer
+        self._init_common(sd, device, micro_batch, rank, world_size)
+        self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg)
+        self.lens = LensEngine(sd, "visual.", tower, lens, device, gemm_cfg=gemm_cfg)
+        self._mk = lambda: AudioLensTrainer(self.lens)
+        self.masters["visual.class_embedding"] = self.lens.vit.cls
+        self.masters["visual.visual_adapter.pos_emb"] = self.lens.adapter_pos
+        self.masters["visual.visual_adapter.conv1.weight_gemm"] = self.lens.conv_w.float()
+        self._collect_perceiver(sd)
+        self.opt = AdamW(self.masters, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+
+    def _refresh_operands(self):
+        self._refresh_perceiver()
         ops.cast_bf16(self.masters["visual.visual_adapter.conv1.weight_gemm"], out=self.lens.conv_w)
 
     def forward_backward(self, audio: torch.Tensor, texts: torch.Tensor) -> torch.Tensor:
         B = audio.shape[0]
-        mb = min(self.mb, B)
-        assert B % mb == 0
-        nmb = B // mb
-        if self.flat_grad is None:
-            for i in range(nmb):
-                self._trainer(i)
-            self._alloc_flat_grads()
-        self.flat_grad.zero_()
+        mb, nmb = self._prepare(B)
         E = self.lens.tower.embed_dim
         ft = torch.empty(B, E, device=self.dev); fv = torch.empty(B, E, device=self.dev)
         vraw = torch.empty(B, E, device=self.dev); vnorm = torch.empty(B, device=self.dev)
@@ -289,17 +324,79 @@ class DualAudioStep:
         self.grads["logit_scale"] += ds * scale
         return loss
 
-    def optimizer_step(self):
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
-            self.opt.step(self.grads, grad_scale=1.0 / self.world)
-        else:
-            self.opt.step(self.grads)
-        self._refresh_operands()
-        ops.clamp_scalar(self.logit_scale, 0.0, math.log(100.0))
-
     def step(self, audio, texts):
         loss = self.forward_backward(audio, texts)
+        self.optimizer_step()
+        return loss
+
+
+class TriModalPCStep(_PerceiverLensStep):
+    """Point-cloud tri-modal step (reference pc_tri_main.py -> `tri_train_one_epoch` + TriClipLoss; model
+    mm_vit_lens/model_cfg.py:85-110): image and text towers frozen, visual tower = PointBERT tokenizer (FPS -> kNN ->
+    mini-PointNet with BatchNorm) + Perceiver, both trainable, in front of the locked ViT.  BatchNorm uses the batch
+    statistics of each forward call (per micro-batch, per rank - SyncBN off, as the reference's default) and updates the
+    running statistics; `bn_training=False` freezes it at the running statistics (--lock-visual-freeze-bn-stats)."""
+
+    def __init__(self, sd, tower: TowerCfg, text: TextCfg, lens: LensCfg, device, micro_batch: int = 32, lr: float = 2e-4,
+                 betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2, rank: int = 0, world_size: int = 1,
+                 gemm_cfg: int = -1, bn_training: bool = True, unlock_cls: bool = False):
+        from .points import PointTokenizerTrainer
+        from .train import PCLensTrainer
+        self._init_common(sd, device, micro_batch, rank, world_size)
+        self.image = VitEngine(sd, "image.", tower, device, gemm_cfg=gemm_cfg)
+        self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg)
+        self.lens = LensEngine(sd, "visual.", tower, lens, device, gemm_cfg=gemm_cfg)
+        self.tok = PointTokenizerTrainer(sd, "visual.visual_adapter.", lens, device, gemm_cfg=gemm_cfg, bn_training=bn_training)
+        self._mk = lambda: PCLensTrainer(self.lens, self.tok, train_cls=unlock_cls)
+        if unlock_cls:
+            self.masters["visual.class_embedding"] = self.lens.vit.cls
+        self.masters.update(self.tok.masters)
+        self._collect_perceiver(sd)
+        self.opt = AdamW(self.masters, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+
+    def _bind_grads(self, t):
+        t.tower.grads = self.grads; t.perc.grads = self.grads; t.tok.grads = self.grads
+        self.tok.grads = self.grads
+
+    def _refresh_operands(self):
+        self._refresh_perceiver()
+        self.tok.refresh_operands()
+        for t in self.trainers:
+            t.tok.op = self.tok.op
+
+    def forward_backward(self, images, texts, points, fps_start=None) -> torch.Tensor:
+        B = images.shape[0]
+        mb, nmb = self._prepare(B)
+        E = self.image.cfg.embed_dim
+        fi = torch.empty(B, E, device=self.dev); ft = torch.empty(B, E, device=self.dev)
+        fv = torch.empty(B, E, device=self.dev); vraw = torch.empty(B, E, device=self.dev)
+        vnorm = torch.empty(B, device=self.dev)
+        for i in range(nmb):
+            s = slice(i * mb, (i + 1) * mb)
+            ops.l2_normalize(self.image.encode_image(images[s]), out=fi[s])
+            ops.l2_normalize(self.text.encode_text(texts[s]), out=ft[s])
+            vraw[s] = self._trainer(i).forward(points[s], None if fps_start is None else fps_start[s])
+        ops.l2_normalize(vraw, out=fv, norms=vnorm)
+        scale = float(self.logit_scale.exp())
+        if self.world > 1:
+            import torch.distributed as dist
+            allp = torch.empty(self.world * B, 3 * E, device=self.dev)
+            dist.all_gather_into_tensor(allp, torch.cat([fi, ft, fv], dim=1))
+            ai, at, av = [t.contiguous() for t in allp.split(E, dim=1)]
+        else:
+            ai, at, av = fi, ft, fv
+        l1, c1 = pair_forward(ai, av, scale)
+        l2, c2 = pair_forward(at, av, scale)
+        _, dv1, ds1 = pair_backward(c1, need_dx=False)
+        _, dv2, ds2 = pair_backward(c2, need_dx=False)
+        dv = (dv1 + dv2)[self.rank * B:(self.rank + 1) * B].contiguous()
+        dvraw = ops.l2_normalize_bwd(fv, dv, vnorm)
+        for i in range(nmb):
+            self._trainer(i).backward(dvraw[i * mb:(i + 1) * mb].contiguous())
+        self.grads["logit_scale"] += (ds1 + ds2) * scale
+        return l1 + l2
+
+    def step(self, images, texts, points, fps_start=None):
+        loss = self.forward_backward(images, texts, points, fps_start)
         self.optimizer_step()
         return loss

@@ -503,3 +503,31 @@ class AudioLensTrainer:
         ops.gemm(ops.transpose_to_bf16(ddata, ldo=rp), ops.transpose_to_bf16(cols, ldo=rp), None, out=g, res=g,
                  epi=ops.EPI_RES_F32, cfg=self.le.gemm_cfg)
         ops.batch_rowsum(ddata, self.tower.grad_buffer("visual.visual_adapter.pos_emb", self.le.adapter_pos), B, T, D, T, 0)
+
+
+class PCLensTrainer:
+    """`visual.` tower of the point-cloud recipe: PointBERT tokenizer + Perceiver trainable, ViT blocks locked.
+    `tok` is the shared PointTokenizerTrainer (masters, bf16 operands, running statistics); each micro-batch gets
+    a shallow copy that only owns its saved activations."""
+
+    def __init__(self, lens_engine, tok, train_cls: bool = False):
+        import copy
+        self.le = lens_engine
+        self.tower = TowerTrainer(lens_engine.vit, train_blocks=(), train_cls=train_cls, param_prefix="visual.")
+        self.perc = PerceiverTrainer(lens_engine.perceiver, "visual.perceiver.")
+        self.perc.grads = self.tower.grads
+        self.tok = copy.copy(tok)
+        self.tok.ctx = None
+        self.tok.grads = self.tower.grads
+
+    @property
+    def grads(self):
+        return self.tower.grads
+
+    def forward(self, pts: torch.Tensor, fps_start=None) -> torch.Tensor:
+        B = pts.shape[0]
+        ctx = self.tok.forward(pts, fps_start)                    # tokens + pos, bf16 [B*G, C]
+        return self.tower.forward(self.perc.forward(ctx, B), B)
+
+    def backward(self, dfeat: torch.Tensor):
+        self.tok.backward(self.perc.backward(self.tower.backward(dfeat)))
