@@ -1,0 +1,95 @@
+"""GPU: the hot path through the DROP-IN API (open_clip.tri_create_model / TriCLIP.forward / create_loss / tokenize),
+i.e. what a user of the reference calls, against the oracle and the reference-generated golden vectors."""
+import importlib
+import json
+import os
+import sys
+import tempfile
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+import vitlens_oracle as O
+from golden_util import load_npz, split, specs_from_meta
+
+pytestmark = pytest.mark.gpu
+
+CAPTIONS = ["a bird", "a car", "a dog", "a guitar"]          # the reference's example.py prompt nouns
+
+
+def _oc():
+    for k in [k for k in sys.modules if k == "open_clip" or k.startswith("open_clip.")]:
+        f = getattr(sys.modules[k], "__file__", "") or ""
+        if "vit-lens_amd" not in f:
+            del sys.modules[k]
+    oc = importlib.import_module("open_clip")
+    assert "vit-lens_amd" in oc.__file__
+    return oc
+
+
+def cos_matrix(a, b):
+    a = torch.nn.functional.normalize(a.float().cpu(), dim=-1)
+    b = torch.nn.functional.normalize(b.float().cpu(), dim=-1)
+    return a @ b.t()
+
+
+def test_c1_vitb32_image_text_pairs_through_api():
+    """BASELINE config C1: ViT-B/32, 4 image+text pairs -> [4,512] features and softmax(100 * I @ T^T).
+    Weights: the model's own seeded random init (no checkpoint can be fetched), fed unchanged to the oracle."""
+    oc = _oc()
+    from mm_vit_lens.model_cfg import fetch_model_cfg
+    torch.manual_seed(0)
+    model = oc.tri_create_model("ViT-B-32", None, precision="fp32", device="cuda", output_dict=True, args=fetch_model_cfg("image"))
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(11)
+    image = torch.randn(4, 3, 224, 224, generator=g)
+    text = oc.tokenize(CAPTIONS)
+    assert text.shape == (4, 77) and text.dtype == torch.long
+    out = model(image=image.cuda(), text=text.cuda())
+    tower = O.TowerSpec(width=768, layers=12, heads=12, patch=32, image_size=224, embed_dim=512)
+    tspec = O.TextSpec(width=512, heads=8, layers=12, embed_dim=512)
+    ri = O.encode_image(sd, image, tower, normalize=True)
+    rt = O.encode_text(sd, text, tspec, normalize=True)
+    fi, ft = out["image_features"], out["text_features"]
+    assert fi.shape == (4, 512) and ft.shape == (4, 512)
+    assert float((cos_matrix(fi, fi) - cos_matrix(ri, ri)).abs().max()) < 1e-3
+    assert float((cos_matrix(ft, ft) - cos_matrix(rt, rt)).abs().max()) < 2e-3
+    assert float((1 - torch.nn.functional.cosine_similarity(fi.float().cpu(), ri, dim=-1)).max()) < 1e-3
+    assert float((1 - torch.nn.functional.cosine_similarity(ft.float().cpu(), rt, dim=-1)).max()) < 1e-3
+    p = torch.softmax(100.0 * fi.float().cpu() @ ft.float().cpu().t(), dim=-1)
+    pr = torch.softmax(100.0 * ri @ rt.t(), dim=-1)
+    assert float((p - pr).abs().max()) < 2e-2, float((p - pr).abs().max())
+    assert abs(float(out["logit_scale"]) - 1 / 0.07) < 1e-3
+
+
+@pytest.mark.parametrize("modality", ["depth", "audio", "pc"])
+def test_tiny_golden_forward_and_loss_through_api(modality):
+    """tri_create_model + load_state_dict(reference weights) + TriCLIP.forward + create_loss on the reference's tiny
+    golden case: the three feature sets and the TriClipLoss value the reference produced."""
+    oc = _oc()
+    case = load_npz(f"tiny_{modality}.npz")
+    sd, ins, outs, grads, meta = split(case)
+    args = SimpleNamespace(**meta["args"])
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "tiny-lens.json"), "w") as f:
+            json.dump(meta["model_cfg"], f)
+        oc.add_model_config(td)
+        model = oc.tri_create_model("tiny-lens", None, precision="fp32", device="cuda", output_dict=True, args=args)
+    missing = model.load_state_dict(sd, strict=False)
+    assert not [k for k in missing.missing_keys if not k.endswith("num_batches_tracked")], missing.missing_keys
+    model.eval()
+    kw = {"fps_start": ins["fps_start"].cuda()} if modality == "pc" else {}
+    fv = model.encode_visual(ins["visual_x"].cuda(), normalize=True, **kw)
+    out = model(image=ins["image"].cuda(), text=ins["text"].cuda())
+    for got, k in ((out["image_features"], "image_features"), (out["text_features"], "text_features"), (fv, "visual_features")):
+        ref = outs[k]
+        assert float((got.float().cpu() - ref).norm() / ref.norm()) < 3e-2, k
+    largs = SimpleNamespace(local_loss=False, gather_with_grad=False, rank=0, world_size=1, horovod=False, n_tower=3,
+                            use_dual_loss=False, cache_dir=None)
+    loss_fn = oc.create_loss(largs)
+    feats = [t.detach().clone().requires_grad_(True) for t in (out["image_features"], out["text_features"], fv)]
+    loss = loss_fn(feats[0], feats[1], feats[2], out["logit_scale"].detach())
+    assert abs(float(loss) - float(outs["tri_loss"])) < 3e-2
+    loss.backward()
+    assert all(torch.isfinite(t.grad).all() for t in feats)
