@@ -65,6 +65,12 @@ int vl_gemm_bf16(const void* A, const void* W, const float* bias, void* out, con
 int vl_gemm_qkv_bf16(const void* A, const void* Win, const float* bias, void* q, void* k, void* vt,
                      int B, int L, int H, int dh, int Lp, int K, int lda, float qscale, int first,
                      int count, int cfg, hipStream_t stream);
+/* Split-K accumulate for weight-gradient GEMMs (tiny M x N, K = token count): out[M,N] f32 (row stride ldo) +=
+ * alpha * A[M,K] . W[N,K]^T.  The K range is cut into `splits` slices computed by separate workgroups into the
+ * caller's workspace ws (splits*M*N floats) and summed in a fixed order (deterministic, no atomics).
+ * Autograd counterpart of the dW of nn.Linear / 1x1 Conv1d in the trainable Lens. */
+int vl_gemm_splitk_accum_f32(const void* A, const void* W, float* out, int M, int N, int K, int lda, int ldw, long ldo,
+                             float alpha, int splits, float* ws, hipStream_t stream);
 int vl_gemm_set_persist_variant(int v);
 int vl_gemm_set_wide_stores(int on);   /* 16-byte epilogue stores (default on); off = 8-byte stores, for A/B runs */
 /* vl_gemm_bf16 + `out2` (with VL_EPI_BF16/VL_ACT_GELU also stores the pre-activation, bf16, for the

@@ -282,3 +282,18 @@ def test_transpose_to_bf16():
     assert t.shape == (45, 128)
     assert torch.equal(t[:, :70].cpu(), x.cpu().t().bfloat16())
     assert float(t[:, 70:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 8192), (128, 64, 65536), (512, 256, 4096 + 64), (1024, 4096, 2048)])
+def test_gemm_dw_splitk_accumulates(M, N, K):
+    """Weight-gradient GEMM g += dyT @ xT^T: the split-K path (few tiles, long K) and the plain accumulate path give the
+    fp32 product of the bf16 operands added to the existing contents; strided destination views are honoured."""
+    ops = _ops()
+    a = rnd(M, K, seed=31).bfloat16().cuda(); w = rnd(N, K, seed=32).bfloat16().cuda()
+    ref = a.float().cpu() @ w.float().cpu().t()
+    big = torch.ones(M, N + 8, device="cuda")
+    g = big[:, 4:4 + N]
+    ops.gemm_dw(a, w, g)
+    ops.gemm_dw(a, w, g)
+    assert relerr(g, 2 * ref + 1.0) < 2e-5
+    assert bool((big[:, :4] == 1).all()) and bool((big[:, 4 + N:] == 1).all())

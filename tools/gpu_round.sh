@@ -22,9 +22,13 @@ cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $
 cd $GRAFT_REPO_ROOT
 find gpurun_out/prof -name "*stats*" | head; 
 for f in $(find gpurun_out/prof -name "*kernel_stats*.csv" | head -1); do head -30 $f; done
-echo "== pmc =="
+echo "== hbm traffic (PMC, separate passes) =="
 [ -n "$SKIP_PMC" ] && exit 0
-cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc -o gemm -- python $GRAFT_REPO_ROOT/tools/gemm_pmc.py > $GRAFT_REPO_ROOT/gpurun_out/pmc.log 2>&1
-cd $GRAFT_REPO_ROOT; ls gpurun_out/pmc | head
+for c in FETCH_SIZE WRITE_SIZE; do
+  cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log 2>&1
+done
+cd $GRAFT_REPO_ROOT
+python tools/traffic_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE "gemm_nt_persist2_kernel<0>" gpurun_out/hbm_traffic.json 65792,4096,1024
+find gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE -name "*.csv" -size +8M -delete
 # keep only the small summaries
 find gpurun_out/prof -name "*kernel_trace*" -size +20M -delete

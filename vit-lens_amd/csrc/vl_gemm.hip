@@ -48,6 +48,10 @@ struct GemmP {
   int which0;        // first part produced by this GEMM: 0 = q, 1 = k, 2 = v
   float qscale;
   int m_off;         // absolute row of local row 0 (QKV scatter of a row-split launch)
+  // split-K (gemm_nt_kernel only): blockIdx.y owns k-slabs [y*ksplit_len, (y+1)*ksplit_len) and writes its
+  // partial product to out + y*split_stride (f32 elements); ksplit_len == 0 -> whole K, no offset
+  int ksplit_len;
+  long split_stride;
 };
 
 template <int BM, int BN>
@@ -326,7 +330,13 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wid % WAVES_M, wave_n = wid / WAVES_M;
 
-  const int nk = p.K >> 6;
+  int nk = p.K >> 6;
+  size_t kbeg = 0;
+  if (p.ksplit_len) {
+    const int s0 = blockIdx.y * p.ksplit_len;
+    nk = min(p.ksplit_len, nk - s0);
+    kbeg = (size_t)s0 << 6;
+  }
 
   // ---- staging helpers -------------------------------------------------------------------
   // one wave-instruction moves 8 rows x 128 B.  lane -> (row in group = lane>>3, phys chunk = lane&7)
@@ -338,13 +348,13 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
   for (int i = 0; i < AI; ++i) {
     const int row = (i * NW + wid) * 8 + srow;
     int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
-    gA[i] = p.A + (size_t)gm * p.lda + (pch ^ ((row >> 1) & 7)) * 8;
+    gA[i] = p.A + (size_t)gm * p.lda + (pch ^ ((row >> 1) & 7)) * 8 + kbeg;
   }
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
     const int row = (i * NW + wid) * 8 + srow;
     int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
-    gB[i] = p.W + (size_t)gn * p.ldw + (pch ^ ((row >> 1) & 7)) * 8;
+    gB[i] = p.W + (size_t)gn * p.ldw + (pch ^ ((row >> 1) & 7)) * 8 + kbeg;
   }
   [[maybe_unused]] u32x4 rA[AI], rB[BI];
   // LDS-DMA: one instruction per 8-row group, destination = wave-uniform base + lane*16
@@ -414,7 +424,24 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
     __syncthreads();
   }
 
-  { const GemmP pe = reload_params(); store_tile<EPI, MT, NTL>(pe, acc, m0 + wave_m * WTM, n0 + wave_n * WTN, fr, fg); }
+  {
+    GemmP pe = reload_params();
+    if constexpr (EPI == EPI_F32) { if (pe.ksplit_len) pe.out = (float*)pe.out + (size_t)blockIdx.y * pe.split_stride; }
+    store_tile<EPI, MT, NTL>(pe, acc, m0 + wave_m * WTM, n0 + wave_n * WTN, fr, fg);
+  }
+}
+
+// out[m, n] += sum_z ws[z][m, n]   (deterministic second stage of the split-K GEMM)
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, float* __restrict__ out,
+                                                            long ldo) {
+  const int n4 = N >> 2;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)M * n4) return;
+  const long m = i / n4; const int n = (int)(i - m * n4) * 4;
+  f32x4 a = *(const f32x4*)(out + m * ldo + n);
+  const size_t plane = (size_t)M * N;
+  for (int z = 0; z < splits; ++z) a += *(const f32x4*)(ws + z * plane + m * N + n);
+  *(f32x4*)(out + m * ldo + n) = a;
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, bool DMA>
@@ -1162,6 +1189,38 @@ extern "C" int vl_gemm_bf16_ex(const void* A, const void* W, const float* bias, 
     case VL_EPI_DGEGLU: VL_CHECK_ARG(res, "vl_gemm_bf16: pre-activation tensor missing"); VL_CHECK_ARG((ldo & 7) == 0, "vl_gemm_bf16: DGEGLU needs ldo % 8 == 0"); e = run_gemm<EPI_DGEGLU>(p, cfg, stream); break;
     default: return vl_set_error("vl_gemm_bf16: unknown epilogue");
   }
+  if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
+  return 0;
+}
+
+// out[M,N] (f32, row stride ldo) += alpha * A[M,K] . W[N,K]^T with the K range cut into `splits` slices computed by
+// separate workgroups (weight-gradient GEMMs: tiny M x N, K = number of tokens) and summed in a fixed order.
+extern "C" int vl_gemm_splitk_accum_f32(const void* A, const void* W, float* out, int M, int N, int K, int lda, int ldw,
+                                        long ldo, float alpha, int splits, float* ws, hipStream_t stream) {
+  VL_CHECK_ARG(M > 0 && N > 0 && K > 0, "vl_gemm_splitk: empty problem");
+  VL_CHECK_ARG((K & 63) == 0 && (N & 3) == 0 && (lda & 7) == 0 && (ldw & 7) == 0 && (ldo & 3) == 0,
+               "vl_gemm_splitk: K % 64, N % 4, lda/ldw % 8, ldo % 4 required");
+  VL_CHECK_ARG(splits >= 1 && splits <= 1024 && ws, "vl_gemm_splitk: 1 <= splits <= 1024 and a workspace of splits*M*N floats");
+  const int nk = K >> 6;
+  GemmP p{};
+  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.out = ws; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldo = N;
+  p.alpha = alpha; p.res_div = 1;
+  p.ksplit_len = (nk + splits - 1) / splits;
+  const int eff = (nk + p.ksplit_len - 1) / p.ksplit_len;
+  p.split_stride = (long)M * N;
+  using S = Smem<128, 128>;
+  auto kern = gemm_nt_kernel<128, 128, 2, 2, EPI_F32, true>;
+  constexpr int smem = 2 * S::STAGE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  hipLaunchKernelGGL(kern, dim3(tiles, eff), dim3(256), smem, stream, p);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)M * (N >> 2) + 255) / 256)), dim3(256), 0, stream, ws, eff, M, N, out, ldo);
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
   return 0;
 }

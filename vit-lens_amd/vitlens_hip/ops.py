@@ -73,6 +73,25 @@ def gemm(a, w, bias=None, out=None, res=None, epi=EPI_BF16, act=ACT_NONE, alpha=
     return out
 
 
+def gemm_dw(dyt, xt, g, cfg=-1, alpha=1.0):
+    """g += dyt @ xt^T: the weight-gradient GEMM (dyt [N_out, R], xt [K_in, R] bf16 - both already transposed so
+    that the token axis R is the reduction axis; g f32 [N_out, K_in], may be a strided view).  Few output tiles
+    and a long reduction -> split-K over the CUs; otherwise the regular GEMM with the accumulate epilogue."""
+    _chk2d(dyt, "dyt", torch.bfloat16); _chk2d(xt, "xt", torch.bfloat16); _chk2d(g, "g", torch.float32)
+    M, K = dyt.shape
+    N = xt.shape[0]
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    nk = K // 64
+    if K % 64 == 0 and tiles * 2 <= 256 and nk >= 32:
+        splits = max(1, min(512 // tiles, nk // 16))
+        if splits > 1:
+            ws = torch.empty(splits * M * N, device=g.device, dtype=torch.float32)
+            check(_lib.vl_gemm_splitk_accum_f32(_p(dyt), _p(xt), _p(g), M, N, K, dyt.stride(0), xt.stride(0), g.stride(0),
+                                                float(alpha), splits, _p(ws), _stream()))
+            return g
+    return gemm(dyt, xt, None, out=g, res=g, epi=EPI_RES_F32, cfg=cfg, alpha=alpha)
+
+
 def gemm_qkv(a, w, bias, q, k, vt, B, L, H, dh, softmax_scale=None, cfg=-1, first=0, count=3, qt=None, kt=None,
              v=None, raw_scale=None):
     """Packed MHA in-projection with head split: fills q,k [B,H,L,dh] and vt [B,H,dh,Lp].

@@ -166,10 +166,10 @@ class PointTokenizerTrainer:
         rp = (rows + 63) // 64 * 64
         g = self.grad_buffer(name)
         if cols is None:
-            ops.gemm(ops.transpose_to_bf16(dy, ldo=rp), ops.transpose_to_bf16(x, ldo=rp), None, out=g, res=g,
-                     epi=ops.EPI_RES_F32, cfg=self.cfg)
+            ops.gemm_dw(ops.transpose_to_bf16(dy, ldo=rp), ops.transpose_to_bf16(x, ldo=rp), g, cfg=self.cfg)
         else:       # zero-padded input channels: compute the padded product, accumulate the real columns
-            full = ops.gemm(ops.transpose_to_bf16(dy, ldo=rp), ops.transpose_to_bf16(x, ldo=rp), None, epi=ops.EPI_F32, cfg=self.cfg)
+            full = torch.zeros(dy.shape[1], x.shape[1], device=self.device, dtype=torch.float32)
+            ops.gemm_dw(ops.transpose_to_bf16(dy, ldo=rp), ops.transpose_to_bf16(x, ldo=rp), full, cfg=self.cfg)
             ops.axpy(g, full[:, :cols].contiguous(), 1.0)
 
     def _db(self, name, dy):
@@ -200,11 +200,9 @@ class PointTokenizerTrainer:
         gw = self.grad_buffer(a + "encoder.second_conv.0.weight")
         half = gw.shape[1] // 2
         rp = (dz3.shape[0] + 63) // 64 * 64
-        ops.gemm(ops.transpose_to_bf16(dz3, ldo=rp), ops.transpose_to_bf16(f, ldo=rp), None, out=gw[:, half:], res=gw[:, half:],
-                 epi=ops.EPI_RES_F32, cfg=c)
+        ops.gemm_dw(ops.transpose_to_bf16(dz3, ldo=rp), ops.transpose_to_bf16(f, ldo=rp), gw[:, half:], cfg=c)
         rg = (dt.shape[0] + 63) // 64 * 64
-        ops.gemm(ops.transpose_to_bf16(dt, ldo=rg), ops.transpose_to_bf16(g, ldo=rg), None, out=gw[:, :half], res=gw[:, :half],
-                 epi=ops.EPI_RES_F32, cfg=c)
+        ops.gemm_dw(ops.transpose_to_bf16(dt, ldo=rg), ops.transpose_to_bf16(g, ldo=rg), gw[:, :half], cfg=c)
         self._db(a + "encoder.second_conv.0.bias", dt)
         dg = ops.gemm(dt, o["w3gT"], None, cfg=c)
         dfl = ops.gemm(dz3, o["w3lT"], None, cfg=c)

@@ -91,12 +91,12 @@ class TriModalDepthStep:
 
     def _alloc_flat_grads(self):
         """All gradient buffers are views into ONE flat fp32 tensor -> a single all-reduce per step."""
-        n = sum(v.numel() for v in self.masters.values())
-        self.flat_grad = torch.zeros(n, device=self.dev, dtype=torch.float32)
+        al = lambda n: (n + 3) // 4 * 4                       # every view starts 16-byte aligned
+        self.flat_grad = torch.zeros(sum(al(v.numel()) for v in self.masters.values()), device=self.dev, dtype=torch.float32)
         off = 0
         for k, v in self.masters.items():
             self.grads[k] = self.flat_grad[off:off + v.numel()].view(v.shape)
-            off += v.numel()
+            off += al(v.numel())
         for t in self.trainers:
             t.tower.grads = self.grads
         # trainers created later share the dict too

@@ -119,7 +119,7 @@ class TowerTrainer:
         rp = (rows + 63) // 64 * 64
         dyt = ops.transpose_to_bf16(dy, ldo=rp)
         xt = ops.transpose_to_bf16(x, ldo=rp)
-        ops.gemm(dyt, xt, None, out=g, res=g, epi=ops.EPI_RES_F32, cfg=self.eng.gemm_cfg)
+        ops.gemm_dw(dyt, xt, g, cfg=self.eng.gemm_cfg)
 
     def _db(self, name, dy):
         g = self.grad_buffer(name, torch.empty(dy.shape[1]))
@@ -213,8 +213,7 @@ class DepthLensTrainer:
         t = self.tower
         g = t.grad_buffer("visual.visual_adapter.conv1.weight_gemm", torch.empty(D, cols.shape[1]))
         rp = (dtok.shape[0] + 63) // 64 * 64
-        ops.gemm(ops.transpose_to_bf16(dtok, ldo=rp), ops.transpose_to_bf16(cols, ldo=rp), None, out=g, res=g,
-                 epi=ops.EPI_RES_F32, cfg=self.le.gemm_cfg)
+        ops.gemm_dw(ops.transpose_to_bf16(dtok, ldo=rp), ops.transpose_to_bf16(cols, ldo=rp), g, cfg=self.le.gemm_cfg)
         ops.batch_rowsum(t.dxpre, t.grad_buffer("visual.visual_adapter.pos_emb", self.le.adapter_pos), B, T, D, T + 1, 1)
 
 
@@ -359,8 +358,7 @@ class PerceiverTrainer:
     def _dw(self, name, dy, x, rows):
         g = self.grad_buffer(name, (dy.shape[1], x.shape[1]))
         rp = (rows + 63) // 64 * 64
-        ops.gemm(ops.transpose_to_bf16(dy, ldo=rp), ops.transpose_to_bf16(x, ldo=rp), None, out=g, res=g,
-                 epi=ops.EPI_RES_F32, cfg=self.pe.gemm_cfg)
+        ops.gemm_dw(ops.transpose_to_bf16(dy, ldo=rp), ops.transpose_to_bf16(x, ldo=rp), g, cfg=self.pe.gemm_cfg)
 
     def _ln_params(self, name, dy, x, stats, rows, D):
         ops.layernorm_bwd_params(dy, x, stats[0], stats[1], self.grad_buffer(name + ".weight", (D,)),
@@ -500,8 +498,7 @@ class AudioLensTrainer:
         D = ddata.shape[1]
         g = self.tower.grad_buffer("visual.visual_adapter.conv1.weight_gemm", torch.empty(D, cols.shape[1]))
         rp = (ddata.shape[0] + 63) // 64 * 64
-        ops.gemm(ops.transpose_to_bf16(ddata, ldo=rp), ops.transpose_to_bf16(cols, ldo=rp), None, out=g, res=g,
-                 epi=ops.EPI_RES_F32, cfg=self.le.gemm_cfg)
+        ops.gemm_dw(ops.transpose_to_bf16(ddata, ldo=rp), ops.transpose_to_bf16(cols, ldo=rp), g, cfg=self.le.gemm_cfg)
         ops.batch_rowsum(ddata, self.tower.grad_buffer("visual.visual_adapter.pos_emb", self.le.adapter_pos), B, T, D, T, 0)
 
 
