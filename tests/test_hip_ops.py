@@ -27,7 +27,7 @@ def relerr(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, -1])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 9, -1])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 200, 128), (1000, 1028, 1024), (65, 32, 64), (514, 3072, 1024)])
 def test_gemm_f32_out(cfg, M, N, K):
     """Transpose-detecting (asymmetric) operands; fp32 accumulate => rel err <= 1e-5 vs fp32 matmul of
@@ -59,7 +59,7 @@ def test_gemm_persistent_many_tiles_and_row_split(cfg):
     assert relerr(outb, torch.nn.functional.gelu(ref)) < 4e-3
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 4, 5, 6, 7])
+@pytest.mark.parametrize("cfg", [0, 1, 4, 5, 6, 7, 9])
 def test_gemm_identity_asymmetric(cfg):
     """A = I  =>  C == W^T exactly (catches row/col swaps and fragment-layout errors bit-exactly)."""
     ops = _ops()
@@ -70,7 +70,7 @@ def test_gemm_identity_asymmetric(cfg):
     assert torch.equal(out.cpu(), w.float().cpu().t())
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 5, 6, 7])
+@pytest.mark.parametrize("cfg", [0, 1, 5, 6, 7, 9])
 def test_gemm_epilogues(cfg):
     ops = _ops()
     M, N, K = 520, 384, 192
@@ -297,3 +297,59 @@ def test_gemm_dw_splitk_accumulates(M, N, K):
     ops.gemm_dw(a, w, g)
     assert relerr(g, 2 * ref + 1.0) < 2e-5
     assert bool((big[:, :4] == 1).all()) and bool((big[:, 4 + N:] == 1).all())
+
+
+def test_gemm_auto_row_split_carries_every_operand():
+    """cfg=-1 at the bench geometry (M = 257*256 rows): the persistent kernel takes the largest row range whose tile
+    count is a multiple of the CU count and a second launch the remaining rows.  Every per-row operand must follow the
+    split: output, residual, the saved pre-activation copy (out2) and the row-broadcast residual (res_div)."""
+    ops = _ops()
+    relerr = lambda x, y: float((x.float() - y.float()).norm() / y.float().norm())       # stays on the GPU
+    M, N, K = 257 * 256, 1024, 128
+    a = rnd(M, K, seed=41).bfloat16().cuda(); w = rnd(N, K, seed=42, scale=0.1).bfloat16().cuda()
+    bias = rnd(N, seed=43).cuda()
+    acc = (a.float() @ w.float().t() + bias)                                    # on the GPU: 67M elements
+    u = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    out = ops.gemm(a, w, bias, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=-1, out2=u)
+    assert relerr(u, acc) < 4e-3 and bool(torch.isfinite(u.float()).all())
+    assert relerr(out, torch.nn.functional.gelu(acc)) < 4e-3
+    for rows in (slice(0, 256), slice(M - 256, M)):                             # the rows the two launches own
+        assert relerr(u[rows], acc[rows]) < 4e-3
+    res = rnd(M, N, seed=44).cuda(); ref = res + acc
+    ops.gemm(a, w, bias, out=res, res=res, epi=ops.EPI_RES_F32, cfg=-1)
+    assert relerr(res, ref) < 1e-5 and relerr(res[M - 256:], ref[M - 256:]) < 1e-5
+    G = 32
+    t = rnd(M // G, N, seed=45).bfloat16().cuda()
+    o = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(a, w, None, out=o, res=t, res_div=G, epi=ops.EPI_RES_BF16, cfg=-1)
+    ref = a.float() @ w.float().t() + t.float().repeat_interleave(G, 0)
+    assert relerr(o, ref) < 4e-3 and relerr(o[M - 256:], ref[M - 256:]) < 4e-3
+    h = ops.gemm(a, w, bias, epi=ops.EPI_GEGLU, cfg=-1, out2=(hs := torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)))
+    assert relerr(hs, acc) < 4e-3 and relerr(hs[M - 256:], acc[M - 256:]) < 4e-3
+    assert relerr(h, acc[:, 0::2] * torch.nn.functional.gelu(acc[:, 1::2])) < 4e-3
+
+
+@pytest.mark.parametrize("B,cfg", [(256, -1), (3, 9)])
+def test_qkv_scatter_row_split_and_tail_kernel(B, cfg):
+    """QKV scatter (q, k, v^T + the backward's extra layouts q^T, k^T, v) at the bench geometry, where cfg=-1 splits
+    the rows between the persistent kernel and the tail kernel (absolute row offsets drive the head scatter), and on
+    the tail kernel alone."""
+    ops = _ops()
+    rel = lambda x, y: float((x.float() - y.float()).norm() / y.float().norm())
+    L, H, dh = 257, 16, 64
+    D = H * dh
+    x = rnd(B * L, D, seed=51).bfloat16().cuda()
+    w = rnd(3 * D, D, seed=52, scale=D ** -0.5).bfloat16().cuda()
+    bias = rnd(3 * D, seed=53, scale=0.1).cuda()
+    Lp = (L + 7) // 8 * 8
+    q = torch.empty(B, H, L, dh, dtype=torch.bfloat16, device="cuda"); k = torch.empty_like(q); v = torch.empty_like(q)
+    vt = torch.zeros(B, H, dh, Lp, dtype=torch.bfloat16, device="cuda")
+    qt = torch.zeros(B, H, dh, Lp, dtype=torch.bfloat16, device="cuda"); kt = torch.zeros_like(qt)
+    ops.gemm_qkv(x, w, bias, q, k, vt, B, L, H, dh, cfg=cfg, qt=qt, kt=kt, v=v)
+    qkv = x.float() @ w.float().t() + bias
+    qr, kr, vr = [t.reshape(B, L, H, dh).permute(0, 2, 1, 3) for t in qkv.split(D, dim=-1)]
+    scale = dh ** -0.5 * ops.LOG2E
+    for got, ref in ((q, qr * scale), (k, kr), (v, vr), (vt[..., :L].transpose(-1, -2), vr),
+                     (qt[..., :L].transpose(-1, -2), qr * scale), (kt[..., :L].transpose(-1, -2), kr)):
+        assert rel(got, ref) < 4e-3
+        assert rel(got[-1], ref[-1]) < 4e-3                                      # the last sample lives in the tail rows

@@ -13,18 +13,19 @@ typedef uint16_t bf16_t;  // storage type for bf16 in global memory
 
 #define VL_WAVE 64
 
-// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
+// round-to-nearest-even fp32 -> bf16 on the gfx950 conversion unit (v_cvt_pk_bf16_f32: one instruction per PAIR,
+// IEEE NaN handling) instead of ~5 integer ops per element.
+typedef __attribute__((ext_vector_type(2))) float vl_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 vl_bf16x2;
 __device__ __forceinline__ bf16_t f2bf(float f) {
-  unsigned int u = __builtin_bit_cast(unsigned int, f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 __device__ __forceinline__ float bf2f(bf16_t h) {
   return __builtin_bit_cast(float, ((unsigned int)h) << 16);
 }
 __device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
-  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+  const vl_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, vl_bf16x2));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -462,6 +462,63 @@ hipError_t launch(const GemmP& p, hipStream_t s) {
 
 
 // ------------------------------------------------------------------------------------------------
+// Tail kernel for the few rows the persistent launch leaves over (the cls token makes M = B*257, one 256-row tile
+// more than a whole number of rounds).  On 128x128 tiles those rows are 8-32 workgroups that each walk the full K
+// alone (44-136 us with 90 % of the chip idle); here every 32x32 output tile gets its own workgroup and the
+// reduction is split 8 ways over its waves, each streaming its k-slices straight from L2 into MFMA operand
+// registers (no LDS staging: a slice is touched once), partial sums meet in LDS, wave 0 runs the epilogue.
+template <int EPI>
+__global__ void __launch_bounds__(512) gemm_tail_kernel(const GemmP p) {
+  __shared__ float red[7][16][64];
+  const int tiles_n = (p.N + 31) >> 5;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int m0 = tm << 5, n0 = tn << 5;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 31, fg = lane >> 5;
+  int gm = m0 + fr; gm = gm < p.M ? gm : p.M - 1;
+  int gn = n0 + fr; gn = gn < p.N ? gn : p.N - 1;
+  const bf16_t* ap = p.A + (size_t)gm * p.lda + fg * 8;
+  const bf16_t* wp = p.W + (size_t)gn * p.ldw + fg * 8;
+  const int steps = p.K >> 4;
+  f32x16 acc[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+  int s = wid;
+  for (; s + 24 < steps; s += 32) {
+    bf16x8 af[4], wf[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { af[u] = *(const bf16x8*)(ap + (s + 8 * u) * 16); wf[u] = *(const bf16x8*)(wp + (s + 8 * u) * 16); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u], af[u], acc[0][0], 0, 0, 0);
+  }
+  for (; s < steps; s += 8) {
+    const bf16x8 af = *(const bf16x8*)(ap + s * 16), wf = *(const bf16x8*)(wp + s * 16);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, acc[0][0], 0, 0, 0);
+  }
+  if (wid) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wid - 1][r][lane] = acc[0][0][r];
+  }
+  __syncthreads();
+  if (wid == 0) {
+#pragma unroll
+    for (int w = 0; w < 7; ++w)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][0][r] += red[w][r][lane];
+    const GemmP pe = reload_params();
+    store_tile<EPI, 1, 1>(pe, acc, m0, n0, fr, fg);
+  }
+}
+
+template <int EPI>
+hipError_t launch_tail(const GemmP& p, hipStream_t s) {
+  const int tiles = ((p.M + 31) / 32) * ((p.N + 31) / 32);
+  hipLaunchKernelGGL(gemm_tail_kernel<EPI>, dim3(tiles), dim3(512), 0, s, p);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Persistent variant: one workgroup per CU walks its list of output tiles; the (tile, k-step)
 // sequence is flattened so the LDS-DMA of step s+1 -- including the FIRST k-slab of the next tile
 // -- is always in flight while step s computes and while a finished tile is being stored.
@@ -1113,6 +1170,7 @@ hipError_t dispatch(const GemmP& p, int cfg, hipStream_t s) {
   if (cfg == 5) return launch_persist_v<EPI, 2>(p, s);
   if (cfg == 6) return launch_persist3<EPI>(p, s);
   if (cfg == 7) return launch_persist4<EPI>(p, s);
+  if (cfg == 9) return launch_tail<EPI>(p, s);
   switch (cfg & 3) {
     case 0: return launch<256, 256, 2, 4, EPI, true>(p, s);
     case 1: return launch<128, 128, 2, 2, EPI, true>(p, s);
@@ -1150,8 +1208,10 @@ static hipError_t run_gemm(const GemmP& p, int cfg, hipStream_t s) {
   pr.A = p.A + (size_t)rows_main * p.lda;
   constexpr size_t osz = (EPI == EPI_F32 || EPI == EPI_RES_F32) ? 4 : 2;
   if (p.out) pr.out = (unsigned char*)p.out + (size_t)rows_main * p.ldo * osz;
+  // a row-broadcast residual (res_div > 1) is indexed with the absolute row (m + m_off) / res_div: pointer unchanged
   if (p.res && p.res_div <= 1) pr.res = (const unsigned char*)p.res + (size_t)rows_main * p.ldo * osz;
-  return dispatch<EPI>(pr, 1, s);
+  if (p.out2) pr.out2 = (bf16_t*)p.out2 + (size_t)rows_main * p.ldo * (EPI == EPI_GEGLU ? 2 : 1);
+  return pr.M <= 512 ? launch_tail<EPI>(pr, s) : dispatch<EPI>(pr, 1, s);
 }
 
 #define VL_CHECK_ARG(c, msg) do { if (!(c)) return vl_set_error(msg); } while (0)
