@@ -51,8 +51,8 @@ def test_tiny_golden_image_and_text(modality, res_dtype):
     assert float((got - ref).abs().max()) < 5e-3
 
 
-@pytest.mark.parametrize("gemm_cfg", [0, 1])
-def test_vitl14_image_tower_vs_oracle(gemm_cfg):
+@pytest.mark.parametrize("gemm_cfg,res_dtype", [(0, torch.float32), (1, torch.float32), (-1, torch.bfloat16)])
+def test_vitl14_image_tower_vs_oracle(gemm_cfg, res_dtype):
     """Full-size ViT-L/14 (24 x 1024 x 16 heads, 257 tokens), seeded weights from the oracle's own
     initialiser (the 1.2 GB state_dict cannot be a fixture), batch 3: cosine matrix within 1e-3."""
     E = _engine()
@@ -61,10 +61,13 @@ def test_vitl14_image_tower_vs_oracle(gemm_cfg):
     sd = O.init_tower(spec, g, "image.")
     image = torch.randn(3, 3, 224, 224, generator=g)
     ref = O.encode_image(sd, image, spec)
-    eng = E.VitEngine(sd, "image.", E.TowerCfg(), "cuda", gemm_cfg=gemm_cfg)
+    eng = E.VitEngine(sd, "image.", E.TowerCfg(), "cuda", gemm_cfg=gemm_cfg, res_dtype=res_dtype)
     got = eng.encode_image(image.cuda())
     assert got.shape == (3, 768)
-    assert relerr(got, ref) < 2e-2, relerr(got, ref)
+    print("relerr", relerr(got, ref), "cos", float((cos_matrix(got, got) - cos_matrix(ref, ref)).abs().max()))
+    # bf16 residual stream (= the reference's amp_bf16 autocast, whose conv/linear outputs and residual adds are bf16):
+    # 48 extra roundings of the stream -> raw-feature tolerance 4e-2; the cosine criteria stay at 1e-3.
+    assert relerr(got, ref) < (2e-2 if res_dtype == torch.float32 else 4e-2), relerr(got, ref)
     assert float((cos_matrix(got, got) - cos_matrix(ref, ref)).abs().max()) < 1e-3
     assert float((1 - torch.nn.functional.cosine_similarity(got.float().cpu(), ref, dim=-1)).max()) < 1e-3
 

@@ -7,8 +7,10 @@ echo "== rocminfo ==" > gpurun_out/env.log
 rocminfo 2>/dev/null | grep -E "Marketing Name|gfx|Compute Unit|Max Clock" | head -12 >> gpurun_out/env.log
 nproc >> gpurun_out/env.log; lscpu | grep -E "Model name|^CPU\(s\)" >> gpurun_out/env.log
 echo "== pytest gpu ==" 
-timeout 900 python -m pytest tests -m gpu -q -n 4 -p no:cacheprovider 2>&1 | tail -80 > gpurun_out/pytest_gpu.log
-tail -40 gpurun_out/pytest_gpu.log
+if [ -z "$SKIP_TESTS" ]; then
+timeout 1200 python -m pytest tests -m gpu -q -n 4 -p no:cacheprovider ${PYTEST_K:+-k "$PYTEST_K"} 2>&1 | tail -80 > gpurun_out/pytest_gpu.log
+tail -40 gpurun_out/pytest_gpu.log | cut -c1-300
+fi
 echo "== kernel bench =="
 if [ -z "$SKIP_KB" ]; then timeout 600 python tools/kernel_bench.py ${KB_ARGS:---quick} > gpurun_out/kernel_bench.log 2>&1; tail -40 gpurun_out/kernel_bench.log; fi
 echo "== bench =="
