@@ -419,3 +419,94 @@ def test_pc_tri_modal_step_vs_reference_grads(bn_train):
     st.optimizer_step()
     l2 = st.step(*args); l3 = st.step(*args)
     assert torch.isfinite(l3) and float(l3) < float(loss) + 1e-3, (float(loss), float(l2), float(l3))
+
+
+# ------------------------------------------------------------------------------------------------ two ranks on one GPU
+class _ThreadComm:
+    """In-process stand-in for TorchComm: `world` threads (one per rank, sharing the GPU and its default stream) meet at
+    a barrier; semantics of all_gather_into_tensor (rank-major) and all_reduce(SUM)."""
+
+    def __init__(self, world):
+        import threading
+        self.world, self.slots, self.barrier = world, [None] * world, threading.Barrier(world)
+        self.local = threading.local()
+
+    def bind(self, rank):
+        self.local.rank = rank
+
+    def all_gather(self, out, inp):
+        self.slots[self.local.rank] = inp
+        self.barrier.wait()
+        out.copy_(torch.cat(self.slots, dim=0))
+        self.barrier.wait()
+
+    def all_reduce_sum(self, t):
+        self.slots[self.local.rank] = t
+        self.barrier.wait()
+        total = sum(s.clone() for s in self.slots)
+        self.barrier.wait()
+        t.copy_(total)
+        self.barrier.wait()
+
+
+@pytest.mark.parametrize("recipe", ["depth_tri", "audio_dual"])
+def test_two_rank_step_equals_global_batch_step(recipe):
+    """The N>1 code path of the fused steps on real kernels: two ranks (threads, 2 samples each, packed all-gather +
+    flat gradient all-reduce through an in-process communicator) against ONE rank on the 4-sample global batch.
+    Every rank must see the global loss; the per-rank gradients must add up to the global-batch gradient (logit_scale:
+    every rank holds the full derivative), which is what DDP's mean over ranks scales by 1/W in the reference."""
+    import threading
+    from vitlens_hip import engine as E, step as ST
+    name = "tiny_depth.npz" if recipe == "depth_tri" else "tiny_audio.npz"
+    sd, ins, outs, grads, meta = split(load_npz(name))
+    tower, text, lens = specs_from_meta(meta)
+    tc = E.TowerCfg(width=tower.width, layers=tower.layers, heads=tower.heads, patch=tower.patch,
+                    image_size=tower.image_size, embed_dim=tower.embed_dim)
+    xc = E.TextCfg(context_length=text.context_length, vocab_size=text.vocab_size, width=text.width, heads=text.heads,
+                   layers=text.layers, embed_dim=text.embed_dim)
+    lc = E.LensCfg(**{k: getattr(lens, k) for k in E.LensCfg.__dataclass_fields__ if hasattr(lens, k)})
+
+    def make(rank, world, comm=None):
+        if recipe == "depth_tri":
+            return ST.TriModalDepthStep(sd, tc, xc, "cuda", micro_batch=2, unlock_first_n=1, rank=rank, world_size=world, comm=comm)
+        return ST.DualAudioStep(sd, tc, xc, lc, "cuda", micro_batch=2, rank=rank, world_size=world, comm=comm)
+
+    def batch(sl):
+        if recipe == "depth_tri":
+            return ins["image"][sl].cuda(), ins["text"][sl].cuda(), ins["visual_x"][sl].cuda()
+        return ins["visual_x"][sl].cuda(), ins["text"][sl].cuda()
+
+    one = make(0, 1)
+    loss1 = float(one.forward_backward(*batch(slice(0, 4))))
+    g1 = {k: v.clone() for k, v in one.grads.items()}
+    W = 2
+    comm = _ThreadComm(W)
+    steps = [make(r, W, comm) for r in range(W)]
+    res, errs = [None] * W, []
+
+    def run(r):
+        try:
+            torch.cuda.set_device(0)
+            comm.bind(r)
+            loss = float(steps[r].forward_backward(*batch(slice(2 * r, 2 * r + 2))))
+            local = {k: v.clone() for k, v in steps[r].grads.items()}
+            steps[r].optimizer_step()
+            res[r] = (loss, local)
+        except Exception as e:                      # surface worker failures instead of dead-locking the barrier
+            errs.append(e); comm.barrier.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+    [t.start() for t in th]; [t.join(timeout=300) for t in th]
+    assert not errs, errs
+    for r in range(W):
+        assert abs(res[r][0] - loss1) < 2e-3, (res[r][0], loss1)
+    n = 0
+    for k, g in g1.items():
+        tot = res[0][1][k] + res[1][1][k]
+        ref = g * (W if k == "logit_scale" else 1)
+        if float(ref.abs().max()) < 1e-6:
+            continue
+        assert relerr(tot, ref) < 3e-2, (k, relerr(tot, ref))
+        n += 1
+    assert n >= 10, n
+    for k in steps[0].masters:                       # both replicas took the same optimizer step
+        assert torch.equal(steps[0].masters[k], steps[1].masters[k]), k

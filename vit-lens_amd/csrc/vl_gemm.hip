@@ -189,17 +189,21 @@ __device__ __forceinline__ void store_tile_wide(const GemmP& p, f32x16 (&acc)[MT
 template <int EPI, int MT, int NTL>
 __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL], int mrow0, int ncol0, int fr, int fg) {
   if constexpr (EPI == EPI_BF16 || EPI == EPI_DGELU || EPI == EPI_QKV) {
-    if ((p.N & 15) == 0 && p.wide) { store_tile_wide<EPI, MT, NTL>(p, acc, mrow0, ncol0, fr, fg); return; }
+    if ((p.N & 15) == 0 && p.wide == 1) { store_tile_wide<EPI, MT, NTL>(p, acc, mrow0, ncol0, fr, fg); return; }
   }
   // rows OUTER: a lane writes the 8 column groups of one row back to back, so the 128-byte lines of that row
   // are completed while still in the write-combining window (columns-outer order cost the fc GEMM 40 %).
   // (pointer fields are copied to locals: selecting among struct members by index forces the struct to scratch)
   [[maybe_unused]] bf16_t* const pq = p.q; [[maybe_unused]] bf16_t* const pk = p.k; [[maybe_unused]] bf16_t* const pv = p.v;
   [[maybe_unused]] bf16_t* const pqt = p.qt; [[maybe_unused]] bf16_t* const pkt = p.kt; [[maybe_unused]] bf16_t* const pvt = p.vt;
+  // profiling modes of vl_gemm_set_wide_stores (results are WRONG in both): 2 = no epilogue at all,
+  // 3 = full epilogue arithmetic and store issue, but every row folded onto rows 0..255 (stores stay in L2)
+  if (p.wide == 2) return;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int m = mrow0 + i * 32 + fr;
+    int m = mrow0 + i * 32 + fr;
     if (m >= p.M) continue;
+    if (p.wide == 3) m &= 255;
     [[maybe_unused]] int qb = 0, ql = 0, vz = 0;
     if constexpr (EPI == EPI_QKV) {
       const int ma = m + p.m_off; qb = ma / p.L; ql = ma - qb * p.L;
@@ -301,6 +305,158 @@ __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL
             o[e] = pack2bf(v[e] * gelu_erf(g), v[e] * a * gelu_erf_grad(g));
           }
           *(u32x4*)((bf16_t*)p.out + (size_t)m * p.ldo + 2 * n) = o;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue through a wave-private LDS transpose (persistent kernel).  In the accumulator layout a lane owns one
+// output ROW, so a direct store instruction touches 32 different 128-byte lines with 16 bytes each: the store
+// path then issues ~7 B/clk/CU and the epilogue of a 256x256 tile takes ~20k cycles - as long as two thirds of
+// the K=1024 main loop (measured: 0.66 ms with, 0.45 ms without epilogue; folding the stores onto L2-resident
+// rows changed little, so it is issue, not HBM).  Here each 32x32 fp32 block of the wave's sub-tile goes through
+// a 4 KB LDS slab (XOR-swizzled 16-byte chunks, conflict-free both ways) and comes back with 8 consecutive lanes
+// on one row: every global access of the epilogue - output, residual, saved pre-activation - is a run of whole
+// 64/128-byte segments, and the bias is loaded once per column block instead of once per row.
+// The transposed attention layouts (q^T, k^T, v^T: token index contiguous) are row-per-lane friendly and keep the
+// direct path.  GEGLU epilogues (Perceiver feed-forward only) fall back to store_tile.
+template <int EPI, int MT, int NTL>
+__device__ __forceinline__ void store_tile_lds(const GemmP& p, f32x16 (&acc)[MT][NTL], int mrow0, int ncol0, int fr, int fg,
+                                               int lane, unsigned char* wl) {
+  if constexpr (EPI == EPI_GEGLU || EPI == EPI_DGEGLU) {
+    store_tile<EPI, MT, NTL>(p, acc, mrow0, ncol0, fr, fg);
+    return;
+  } else {
+    if (p.wide >= 1) { store_tile<EPI, MT, NTL>(p, acc, mrow0, ncol0, fr, fg); return; }    // A/B + profiling modes
+    const int rsub = lane >> 3, c = lane & 7;
+    unsigned char* const wr = wl + fr * 128;
+    const int wsw = (fr >> 1) & 7;
+    [[maybe_unused]] bf16_t* const pq = p.q; [[maybe_unused]] bf16_t* const pk = p.k; [[maybe_unused]] bf16_t* const pv = p.v;
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+      const int n = ncol0 + j * 32 + c * 4;
+      const bool col_ok = n < p.N;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && col_ok) bv = *(const f32x4*)(p.bias + n);
+      // QKV: column -> (part, head, offset) once per column block
+      [[maybe_unused]] bf16_t* rowp = nullptr; [[maybe_unused]] int hh = 0, dd = 0; [[maybe_unused]] float qs = 1.f;
+      if constexpr (EPI == EPI_QKV) {
+        const int D = p.H << p.dh_shift;
+        const int nn = col_ok ? n : 0;
+        const int wq = (nn >= D) + (nn >= 2 * D);
+        const int cc = nn - wq * D;
+        const int which = wq + p.which0;
+        hh = cc >> p.dh_shift; dd = cc & ((1 << p.dh_shift) - 1);
+        rowp = which == 0 ? pq : (which == 1 ? pk : pv);
+        qs = which == 0 ? p.qscale : 1.f;
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 t = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+          *(f32x4*)(wr + (((q * 2 + fg) ^ wsw) << 4)) = t;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int mb = mrow0 + i * 32;
+        [[maybe_unused]] int sb = 0, sl = 0;
+        if constexpr (EPI == EPI_QKV) {
+          int vz = 0;
+          asm volatile("" : "+v"(vz));        // per-lane opaque zero: keeps the division in VGPRs (SGPR pressure, see store_tile)
+          const int ma = mb + p.m_off + vz; sb = ma / p.L; sl = ma - sb * p.L;
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int r = pass * 8 + rsub;
+          const int m = mb + r;
+          f32x4 v = *(const f32x4*)(wl + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+          if (m >= p.M || !col_ok) continue;
+          v = v * p.alpha + bv;
+          if constexpr (EPI == EPI_BF16) {
+            if (p.act == 1) {
+              if (p.out2) {
+                u32x2 o2; o2[0] = pack2bf(v[0], v[1]); o2[1] = pack2bf(v[2], v[3]);
+                *(u32x2*)((bf16_t*)p.out2 + (size_t)m * p.ldo + n) = o2;
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            } else if (p.act == 2) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+            *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
+          } else if constexpr (EPI == EPI_F32) {
+            *(f32x4*)((float*)p.out + (size_t)m * p.ldo + n) = v;
+          } else if constexpr (EPI == EPI_RES_F32) {
+            const f32x4 rr = *(const f32x4*)((const float*)p.res + (size_t)m * p.ldo + n);
+            *(f32x4*)((float*)p.out + (size_t)m * p.ldo + n) = v + rr;
+          } else if constexpr (EPI == EPI_RES_BF16) {
+            const u32x2 rr = *(const u32x2*)((const bf16_t*)p.res + (size_t)((m + p.m_off) / p.res_div) * p.ldo + n);
+            v[0] += bf2f((bf16_t)(rr[0] & 0xffff)); v[1] += bf2f((bf16_t)(rr[0] >> 16));
+            v[2] += bf2f((bf16_t)(rr[1] & 0xffff)); v[3] += bf2f((bf16_t)(rr[1] >> 16));
+            if (p.act == 2) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+            *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
+          } else if constexpr (EPI == EPI_DGELU) {
+            const u32x2 rr = *(const u32x2*)((const bf16_t*)p.res + (size_t)m * p.ldo + n);
+            v[0] *= gelu_erf_grad(bf2f((bf16_t)(rr[0] & 0xffff))); v[1] *= gelu_erf_grad(bf2f((bf16_t)(rr[0] >> 16)));
+            v[2] *= gelu_erf_grad(bf2f((bf16_t)(rr[1] & 0xffff))); v[3] *= gelu_erf_grad(bf2f((bf16_t)(rr[1] >> 16)));
+            u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+            *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
+          } else if constexpr (EPI == EPI_QKV) {
+            if (rowp) {
+              int qb = sb, ql = sl + r;
+              while (ql >= p.L) { ql -= p.L; ++qb; }
+              v = v * qs;
+              u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+              *(u32x2*)(rowp + ((((size_t)qb * p.H + hh) * p.L + ql) << p.dh_shift) + dd) = o;
+            }
+          }
+        }
+        asm volatile("" ::: "memory");
+      }
+    }
+    // transposed attention operands straight from the accumulator layout (lanes = consecutive tokens = contiguous)
+    if constexpr (EPI == EPI_QKV) {
+      if (p.qt || p.kt || p.vt) {
+        [[maybe_unused]] bf16_t* const pqt = p.qt; [[maybe_unused]] bf16_t* const pkt = p.kt; [[maybe_unused]] bf16_t* const pvt = p.vt;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int m = mrow0 + i * 32 + fr;
+          if (m >= p.M) continue;
+          int vz = 0;
+          const int ma = m + p.m_off; const int qb = ma / p.L; const int ql = ma - qb * p.L;
+          asm volatile("" : "+v"(vz));
+#pragma unroll
+          for (int j = 0; j < NTL; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int n = ncol0 + j * 32 + q * 8 + fg * 4;
+              if (n >= p.N) continue;
+              const int D = p.H << p.dh_shift;
+              const int nv = n + vz;
+              const int wq = (nv >= D) + (nv >= 2 * D);
+              const int cc = nv - wq * D;
+              const int which = wq + p.which0;
+              bf16_t* colp = which == 0 ? pqt : (which == 1 ? pkt : pvt);
+              if (!colp) continue;
+              const int h2 = cc >> p.dh_shift, d2 = cc & ((1 << p.dh_shift) - 1);
+              const size_t col_off = ((((size_t)qb * p.H + h2) << p.dh_shift) + d2) * p.Lp + ql;
+              f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+              if (p.bias) bq = *(const f32x4*)(p.bias + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float t = (acc[i][j][q * 4 + e] * p.alpha + bq[e]) * (which == 0 ? p.qscale : 1.f);
+                colp[col_off + (size_t)e * p.Lp] = f2bf(t);
+              }
+            }
+          }
         }
       }
     }
@@ -799,7 +955,10 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
     __builtin_amdgcn_sched_barrier(0);
 
     if (kt + 1 == nk) {
-      { const GemmP pe = reload_params(); store_tile<EPI, MT, NTL>(pe, acc, cur_m0 + wave_m * WTM, cur_n0 + wave_n * WTN, fr, fg); }
+      {
+        const GemmP pe = reload_params();
+        store_tile_lds<EPI, MT, NTL>(pe, acc, cur_m0 + wave_m * WTM, cur_n0 + wave_n * WTN, fr, fg, lane, smem + 2 * S::STAGE + wid * 4096);
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -827,7 +986,7 @@ static int num_cus() {
 }
 
 static int g_wide_stores = 0;   // measured (profiles/r01e_kernel_bench_wide.log): the 16-byte exchange stores are 5-7 % SLOWER than the 8-byte path on fc/out
-extern "C" int vl_gemm_set_wide_stores(int on) { g_wide_stores = on ? 1 : 0; return 0; }
+extern "C" int vl_gemm_set_wide_stores(int on) { g_wide_stores = (on >= 0 && on <= 3) ? on : 0; return 0; }   // 2, 3: profiling modes (see store_tile)
 static int g_persist_variant = 2;   // 1 = plain persistent loop, 2 = hand-scheduled k-step, 3 = two 256x128 workgroups per CU
 extern "C" int vl_gemm_set_persist_variant(int v) { g_persist_variant = (v >= 1 && v <= 4) ? v : 2; return 0; }
 
@@ -836,7 +995,7 @@ hipError_t launch_persist_v(const GemmP& p, hipStream_t s) {
   using S = Smem<256, 256>;
   const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   auto kern = (VAR == 1) ? gemm_nt_persist_kernel<256, 256, 2, 4, EPI> : gemm_nt_persist2_kernel<256, 256, 2, 4, EPI>;
-  constexpr int smem = 2 * S::STAGE;
+  constexpr int smem = 2 * S::STAGE + (VAR == 2 ? 8 * 4096 : 0);      // + one 4 KB epilogue-transpose slab per wave = 160 KB
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);

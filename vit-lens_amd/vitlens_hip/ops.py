@@ -383,8 +383,10 @@ def group_sum(x, M):
     return out
 
 
-def set_wide_stores(on: bool):
-    _lib.vl_gemm_set_wide_stores(1 if on else 0)
+def set_wide_stores(on):
+    """0 = 8-byte epilogue stores (default), 1 = 16-byte exchange stores; 2 / 3 = profiling modes with WRONG results
+    (no epilogue / epilogue with all stores folded onto 256 rows), see csrc/vl_gemm.hip:store_tile."""
+    _lib.vl_gemm_set_wide_stores(int(on))
 
 
 def set_persist_variant(v: int):

@@ -22,6 +22,19 @@ from .engine import LensCfg, LensEngine, TextCfg, TextEngine, TowerCfg, VitEngin
 from .train import AdamW, DepthLensTrainer
 
 
+class TorchComm:
+    """The two collectives of a step on `torch.distributed` (backend "nccl" = RCCL over xGMI, one process per GPU).
+    A step takes any object with these two methods (the tests drive two ranks on one GPU through an in-process one)."""
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(out, inp)
+
+    def all_reduce_sum(self, t: torch.Tensor):
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 # ------------------------------------------------------------------------------------------------ loss core
 def pair_forward(x, y, scale: float, label_off: int = 0, w_row: float = 0.5, w_col: float = 0.5):
     """loss contribution w_row*CE(scale*x y^T) + w_col*CE(columns); returns (loss[1] tensor, ctx)."""
@@ -49,8 +62,9 @@ def pair_backward(ctx, g: float = 1.0, need_dx=True, need_dy=True):
 class TriModalDepthStep:
     def __init__(self, sd: Dict[str, torch.Tensor], tower: TowerCfg, text: TextCfg, device, micro_batch: int = 256,
                  unlock_first_n: int = 4, lr: float = 5e-4, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2,
-                 rank: int = 0, world_size: int = 1, gemm_cfg: int = -1):
+                 rank: int = 0, world_size: int = 1, gemm_cfg: int = -1, comm=None):
         self.dev, self.mb, self.rank, self.world = torch.device(device), micro_batch, rank, world_size
+        self.comm = comm or TorchComm()
         self.image = VitEngine(sd, "image.", tower, device, gemm_cfg=gemm_cfg)
         self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg)
         self.lens = LensEngine(sd, "visual.", tower, LensCfg(modality="depth", perceiver_identity=True), device, gemm_cfg=gemm_cfg)
@@ -99,8 +113,6 @@ class TriModalDepthStep:
             off += al(v.numel())
         for t in self.trainers:
             t.tower.grads = self.grads
-        # trainers created later share the dict too
-        DepthLensTrainer._shared_grads = self.grads
 
     def _refresh_operands(self):
         eng = self.lens.vit
@@ -118,8 +130,7 @@ class TriModalDepthStep:
 
     def optimizer_step(self):
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)   # DDP: mean of per-rank gradients
+            self.comm.all_reduce_sum(self.flat_grad)                # DDP: mean of per-rank gradients
             self.opt.step(self.grads, grad_scale=1.0 / self.world)
         else:
             self.opt.step(self.grads)
@@ -148,10 +159,9 @@ class TriModalDepthStep:
         ops.l2_normalize(vraw, out=fv, norms=vnorm)
         scale = float(self.logit_scale.exp())
         if self.world > 1:
-            import torch.distributed as dist
             packed = torch.cat([fi, ft, fv], dim=1)
             allp = torch.empty(self.world * B, 3 * E, device=self.dev)
-            dist.all_gather_into_tensor(allp, packed)             # ONE exchange: [b, 3*768] per rank over xGMI
+            self.comm.all_gather(allp, packed)                    # ONE exchange: [b, 3*768] per rank over xGMI
             ai, at, av = [t.contiguous() for t in allp.split(E, dim=1)]
         else:
             ai, at, av = fi, ft, fv
@@ -175,8 +185,9 @@ class _PerceiverLensStep:
     fp32 masters of the Perceiver under the reference's parameter names, one flat fp32 gradient buffer (a single
     all-reduce per step = DDP's mean of per-rank gradients), AdamW, bf16 operand refresh, logit-scale clamp."""
 
-    def _init_common(self, sd, device, micro_batch, rank, world_size):
+    def _init_common(self, sd, device, micro_batch, rank, world_size, comm=None):
         self.dev, self.mb, self.rank, self.world = torch.device(device), micro_batch, rank, world_size
+        self.comm = comm or TorchComm()
         self.trainers = []
         self.logit_scale = sd["logit_scale"].detach().float().reshape(1).to(device)
         self.masters: Dict[str, torch.Tensor] = {"logit_scale": self.logit_scale}
@@ -264,8 +275,7 @@ class _PerceiverLensStep:
 
     def optimizer_step(self):
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+            self.comm.all_reduce_sum(self.flat_grad)
             self.opt.step(self.grads, grad_scale=1.0 / self.world)
         else:
             self.opt.step(self.grads)
@@ -281,9 +291,9 @@ class DualAudioStep(_PerceiverLensStep):
 
     def __init__(self, sd, tower: TowerCfg, text: TextCfg, lens: LensCfg, device, micro_batch: int = 256, lr: float = 2e-4,
                  betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2, rank: int = 0, world_size: int = 1,
-                 gemm_cfg: int = -1):
+                 gemm_cfg: int = -1, comm=None):
         from .train import AudioLensTrainer
-        self._init_common(sd, device, micro_batch, rank, world_size)
+        self._init_common(sd, device, micro_batch, rank, world_size, comm)
         self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg)
         self.lens = LensEngine(sd, "visual.", tower, lens, device, gemm_cfg=gemm_cfg)
         self._mk = lambda: AudioLensTrainer(self.lens)
@@ -310,9 +320,8 @@ class DualAudioStep(_PerceiverLensStep):
         ops.l2_normalize(vraw, out=fv, norms=vnorm)
         scale = float(self.logit_scale.exp())
         if self.world > 1:
-            import torch.distributed as dist
             allp = torch.empty(self.world * B, 2 * E, device=self.dev)
-            dist.all_gather_into_tensor(allp, torch.cat([fv, ft], dim=1))
+            self.comm.all_gather(allp, torch.cat([fv, ft], dim=1))
             av, at = [t.contiguous() for t in allp.split(E, dim=1)]
         else:
             av, at = fv, ft
@@ -339,10 +348,10 @@ class TriModalPCStep(_PerceiverLensStep):
 
     def __init__(self, sd, tower: TowerCfg, text: TextCfg, lens: LensCfg, device, micro_batch: int = 32, lr: float = 2e-4,
                  betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2, rank: int = 0, world_size: int = 1,
-                 gemm_cfg: int = -1, bn_training: bool = True, unlock_cls: bool = False):
+                 gemm_cfg: int = -1, bn_training: bool = True, unlock_cls: bool = False, comm=None):
         from .points import PointTokenizerTrainer
         from .train import PCLensTrainer
-        self._init_common(sd, device, micro_batch, rank, world_size)
+        self._init_common(sd, device, micro_batch, rank, world_size, comm)
         self.image = VitEngine(sd, "image.", tower, device, gemm_cfg=gemm_cfg)
         self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg)
         self.lens = LensEngine(sd, "visual.", tower, lens, device, gemm_cfg=gemm_cfg)
@@ -379,9 +388,8 @@ class TriModalPCStep(_PerceiverLensStep):
         ops.l2_normalize(vraw, out=fv, norms=vnorm)
         scale = float(self.logit_scale.exp())
         if self.world > 1:
-            import torch.distributed as dist
             allp = torch.empty(self.world * B, 3 * E, device=self.dev)
-            dist.all_gather_into_tensor(allp, torch.cat([fi, ft, fv], dim=1))
+            self.comm.all_gather(allp, torch.cat([fi, ft, fv], dim=1))
             ai, at, av = [t.contiguous() for t in allp.split(E, dim=1)]
         else:
             ai, at, av = fi, ft, fv
