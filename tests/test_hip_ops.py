@@ -318,6 +318,9 @@ def test_gemm_auto_row_split_carries_every_operand():
     res = rnd(M, N, seed=44).cuda(); ref = res + acc
     ops.gemm(a, w, bias, out=res, res=res, epi=ops.EPI_RES_F32, cfg=-1)
     assert relerr(res, ref) < 1e-5 and relerr(res[M - 256:], ref[M - 256:]) < 1e-5
+    rb = rnd(M, N, seed=46).bfloat16().cuda(); refb = rb.float() + acc        # bf16 residual stream, in place (res_div = 1)
+    ops.gemm(a, w, bias, out=rb, res=rb, epi=ops.EPI_RES_BF16, cfg=-1)
+    assert relerr(rb, refb) < 4e-3 and relerr(rb[M - 256:], refb[M - 256:]) < 4e-3
     G = 32
     t = rnd(M // G, N, seed=45).bfloat16().cuda()
     o = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)

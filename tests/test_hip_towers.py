@@ -102,3 +102,29 @@ def test_batch_invariance_full_size():
     a = eng.encode_image(image[:4]).clone()
     b = eng.encode_image(image[4:]).clone()
     assert torch.equal(full, torch.cat([a, b]))
+
+
+@pytest.mark.parametrize("res_dtype", [torch.float32, torch.bfloat16])
+def test_bench_geometry_tail_rows_match_small_batch(res_dtype):
+    """At the bench batch (256 images -> M = 257*256 rows) the GEMMs split their rows between the persistent kernel and
+    the tail kernel; the LAST image lives in the tail rows.  Its features must equal those of a small batch (which runs
+    on 128x128 tiles only) up to fp32 summation order - for both residual dtypes (a double-offset residual pointer in
+    the tail launch once made the bf16 stream of that image read out of bounds)."""
+    E = _engine()
+    spec = O.TowerSpec()
+    g = torch.Generator().manual_seed(6)
+    sd = O.init_tower(spec, g, "image.")
+    eng = E.VitEngine(sd, "image.", E.TowerCfg(), "cuda", res_dtype=res_dtype)
+    image = torch.randn(256, 3, 224, 224, generator=g).cuda()
+    junk = torch.full((64 << 20,), float("nan"), device="cuda")          # poison recycled memory around the workspaces
+    del junk
+    full = eng.encode_image(image).clone()
+    small = eng.encode_image(image[-4:]).clone()
+    first = eng.encode_image(image[:4]).clone()
+    assert bool(torch.isfinite(full).all())
+    # not bit-exact: the kernels sum K in different orders, and an fp32 ulp in x can flip the bf16 rounding of LN(x)
+    tol = 5e-3 if res_dtype == torch.float32 else 2e-2
+    assert relerr(full[-4:], small) < tol, relerr(full[-4:], small)
+    assert relerr(full[:4], first) < tol, relerr(full[:4], first)
+    cs = torch.nn.functional.cosine_similarity(full[-4:].float(), small.float(), dim=-1)
+    assert float((1 - cs).max()) < 1e-4

@@ -448,6 +448,60 @@ class _ThreadComm:
         t.copy_(total)
         self.barrier.wait()
 
+    def reduce_scatter_sum(self, out, inp):
+        r, b = self.local.rank, out.shape[0]
+        self.slots[r] = inp
+        self.barrier.wait()
+        out.copy_(sum(s[r * b:(r + 1) * b] for s in self.slots))
+        self.barrier.wait()
+
+
+def _run_ranks(world, fn):
+    """fn(rank, comm) on `world` threads sharing the GPU; returns the per-rank results, re-raises worker errors."""
+    import threading
+    comm = _ThreadComm(world)
+    res, errs = [None] * world, []
+
+    def run(r):
+        try:
+            torch.cuda.set_device(0)
+            comm.bind(r)
+            res[r] = fn(r, comm)
+        except Exception as e:
+            errs.append(e); comm.barrier.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join(timeout=300) for t in th]
+    assert not errs, errs
+    return res
+
+
+@pytest.mark.parametrize("world", [4])        # the world-2 fixture has 6 global rows; the logits GEMM wants N % 4 == 0
+@pytest.mark.parametrize("local_loss,gather_with_grad", [(False, False), (False, True), (True, False), (True, True)])
+def test_distributed_contrastive_pair_vs_reference_ranks(world, local_loss, gather_with_grad):
+    """ClipLossGeneral across ranks, all four (local_loss, gather_with_grad) modes: the loss each rank reports and the
+    gradients that arrive at its local features (incl. the reduce-scatter of a differentiable gather) against what the
+    REFERENCE computed per rank on gloo (tests/golden/gather_w{2,4}.npz)."""
+    from vitlens_hip import step as ST
+    z = {k: torch.from_numpy(v) for k, v in load_npz(f"gather_w{world}.npz").items()}
+    scale = 14.285714
+    tag = f"dual_ll{int(local_loss)}_gg{int(gather_with_grad)}"
+
+    def fn(r, comm):
+        xl, yl = z[f"in/x{r}"].cuda(), z[f"in/y{r}"].cuda()
+        b, E = xl.shape
+        allp = torch.empty(world * b, 2 * E, device="cuda")
+        comm.all_gather(allp, torch.cat([xl, yl], dim=1))
+        ax, ay = [t.contiguous() for t in allp.split(E, dim=1)]
+        loss, dx, dy, ds = ST.pair_loss_and_grads(comm, r, world, xl, yl, ax, ay, scale, local_loss=local_loss,
+                                                  gather_with_grad=gather_with_grad)
+        return float(loss), dx.cpu(), dy.cpu(), float(ds)
+    for r, (loss, dx, dy, ds) in enumerate(_run_ranks(world, fn)):
+        assert abs(loss - float(z[f"rank{r}/{tag}_loss"])) < 2e-3, (r, loss)
+        for got, ref in ((dx, z[f"rank{r}/{tag}_gx"]), (dy, z[f"rank{r}/{tag}_gy"])):
+            assert float((got - ref).norm() / ref.norm()) < 4e-2, (r, float((got - ref).norm() / ref.norm()))
+        ref_s = float(z[f"rank{r}/{tag}_gls"])
+        assert abs(ds - ref_s) < 2e-2 * max(1.0, abs(ref_s)), (r, ds, ref_s)
+
 
 @pytest.mark.parametrize("recipe", ["depth_tri", "audio_dual"])
 def test_two_rank_step_equals_global_batch_step(recipe):

@@ -1367,8 +1367,10 @@ static hipError_t run_gemm(const GemmP& p, int cfg, hipStream_t s) {
   pr.A = p.A + (size_t)rows_main * p.lda;
   constexpr size_t osz = (EPI == EPI_F32 || EPI == EPI_RES_F32) ? 4 : 2;
   if (p.out) pr.out = (unsigned char*)p.out + (size_t)rows_main * p.ldo * osz;
-  // a row-broadcast residual (res_div > 1) is indexed with the absolute row (m + m_off) / res_div: pointer unchanged
-  if (p.res && p.res_div <= 1) pr.res = (const unsigned char*)p.res + (size_t)rows_main * p.ldo * osz;
+  // EPI_RES_BF16 indexes its (possibly row-broadcast) residual with the ABSOLUTE row (m + m_off) / res_div: the
+  // pointer must stay put there (offsetting it as well read rows_main rows past the end - found by the c3 bench);
+  // every other epilogue indexes res with the local row.
+  if (p.res && EPI != EPI_RES_BF16) pr.res = (const unsigned char*)p.res + (size_t)rows_main * p.ldo * osz;
   if (p.out2) pr.out2 = (bf16_t*)p.out2 + (size_t)rows_main * p.ldo * (EPI == EPI_GEGLU ? 2 : 1);
   return pr.M <= 512 ? launch_tail<EPI>(pr, s) : dispatch<EPI>(pr, 1, s);
 }

@@ -34,6 +34,11 @@ class TorchComm:
         import torch.distributed as dist
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
+    def reduce_scatter_sum(self, out: torch.Tensor, inp: torch.Tensor):
+        """out [b, E] = this rank's slice of the sum over ranks of inp [W*b, E] (backward of a gather WITH grad)."""
+        import torch.distributed as dist
+        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM)
+
 
 # ------------------------------------------------------------------------------------------------ loss core
 def pair_forward(x, y, scale: float, label_off: int = 0, w_row: float = 0.5, w_col: float = 0.5):
@@ -59,14 +64,55 @@ def pair_backward(ctx, g: float = 1.0, need_dx=True, need_dy=True):
     return dx, dy, dscale
 
 
+def pair_loss_and_grads(comm, rank: int, world: int, xl, yl, ax, ay, scale: float, local_loss: bool = False,
+                        gather_with_grad: bool = False, need_x: bool = True, need_y: bool = True):
+    """One (x, y) pair of ClipLossGeneral / TriClipLoss over the global batch (loss.py:116-138, 293-308) as rank `rank`
+    computes it, and the gradients that arrive at THIS rank's features.
+
+    xl, yl: local unit features [b, E]; ax, ay: their rank-major gathers [W*b, E] (= xl, yl at world 1).
+      local_loss=False: full B_glob x B_glob logits on every rank (rows and columns CE).
+      local_loss=True : b x B_glob logits for the rank's own rows of both directions, labels offset by rank*b.
+      gather_with_grad=False: peers are constants; the own slot of the gather is differentiable unless local_loss
+                              (gather_features re-inserts the local tensor only then, loss.py:71-74).
+      gather_with_grad=True : the gather is differentiable everywhere -> backward = reduce-scatter (sum over ranks).
+    Returns (loss[1], dxl | None, dyl | None, dscale[1])."""
+    b = xl.shape[0]
+    if world > 1 and local_loss:
+        l1, c1 = pair_forward(xl, ay, scale, label_off=rank * b, w_row=0.5, w_col=0.0)
+        l2, c2 = pair_forward(yl, ax, scale, label_off=rank * b, w_row=0.5, w_col=0.0)
+        dxl, d_ay, ds1 = pair_backward(c1, need_dx=need_x, need_dy=need_y and gather_with_grad)
+        dyl, d_ax, ds2 = pair_backward(c2, need_dx=need_y, need_dy=need_x and gather_with_grad)
+        loss, ds = l1 + l2, ds1 + ds2
+    else:
+        loss, c = pair_forward(ax, ay, scale)
+        d_ax, d_ay, ds = pair_backward(c, need_dx=need_x, need_dy=need_y)
+        dxl = dyl = None
+
+    def fold(dl, d_all):
+        if d_all is None:
+            return dl
+        if world == 1:
+            g = d_all
+        elif gather_with_grad:
+            g = torch.empty(b, d_all.shape[1], device=d_all.device, dtype=d_all.dtype)
+            comm.reduce_scatter_sum(g, d_all.contiguous())
+        else:
+            g = d_all[rank * b:(rank + 1) * b].contiguous()
+        return g if dl is None else dl + g
+    return loss, (fold(dxl, d_ax) if need_x else None), (fold(dyl, d_ay) if need_y else None), ds
+
+
 class TriModalDepthStep:
     def __init__(self, sd: Dict[str, torch.Tensor], tower: TowerCfg, text: TextCfg, device, micro_batch: int = 256,
                  unlock_first_n: int = 4, lr: float = 5e-4, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2,
-                 rank: int = 0, world_size: int = 1, gemm_cfg: int = -1, comm=None):
+                 rank: int = 0, world_size: int = 1, gemm_cfg: int = -1, comm=None, frozen_res_dtype=torch.float32,
+                 local_loss: bool = False, gather_with_grad: bool = False):
         self.dev, self.mb, self.rank, self.world = torch.device(device), micro_batch, rank, world_size
         self.comm = comm or TorchComm()
-        self.image = VitEngine(sd, "image.", tower, device, gemm_cfg=gemm_cfg)
-        self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg)
+        self.local_loss, self.gather_with_grad = local_loss, gather_with_grad
+        # frozen towers: forward only; their residual stream may be kept in bf16 (= the reference's autocast)
+        self.image = VitEngine(sd, "image.", tower, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
+        self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
         self.lens = LensEngine(sd, "visual.", tower, LensCfg(modality="depth", perceiver_identity=True), device, gemm_cfg=gemm_cfg)
         self.trainers = []            # one activation store per micro-batch (created lazily)
         self.unlock_first_n = unlock_first_n
@@ -165,14 +211,11 @@ class TriModalDepthStep:
             ai, at, av = [t.contiguous() for t in allp.split(E, dim=1)]
         else:
             ai, at, av = fi, ft, fv
-        l1, c1 = pair_forward(ai, av, scale)
-        l2, c2 = pair_forward(at, av, scale)
+        kw = dict(local_loss=self.local_loss, gather_with_grad=self.gather_with_grad, need_x=False)
+        l1, _, dv1, ds1 = pair_loss_and_grads(self.comm, self.rank, self.world, fi, fv, ai, av, scale, **kw)
+        l2, _, dv2, ds2 = pair_loss_and_grads(self.comm, self.rank, self.world, ft, fv, at, av, scale, **kw)
         loss = l1 + l2
-        _, dv1, ds1 = pair_backward(c1, need_dx=False)
-        _, dv2, ds2 = pair_backward(c2, need_dx=False)
-        dv = dv1 + dv2                                            # d loss / d all_visual  [W*B, E]
-        dv_local = dv[self.rank * B:(self.rank + 1) * B].contiguous()   # peers carry no grad (loss.py:71-74)
-        dvraw = ops.l2_normalize_bwd(fv, dv_local, vnorm)
+        dvraw = ops.l2_normalize_bwd(fv, dv1 + dv2, vnorm)
         for i in range(nmb):
             self._trainer(i).backward(dvraw[i * mb:(i + 1) * mb].contiguous())
         # logit_scale is exp()'d in forward (model.py:619): d/d(log-scale) = dscale * scale
@@ -185,9 +228,10 @@ class _PerceiverLensStep:
     fp32 masters of the Perceiver under the reference's parameter names, one flat fp32 gradient buffer (a single
     all-reduce per step = DDP's mean of per-rank gradients), AdamW, bf16 operand refresh, logit-scale clamp."""
 
-    def _init_common(self, sd, device, micro_batch, rank, world_size, comm=None):
+    def _init_common(self, sd, device, micro_batch, rank, world_size, comm=None, local_loss=False, gather_with_grad=False):
         self.dev, self.mb, self.rank, self.world = torch.device(device), micro_batch, rank, world_size
         self.comm = comm or TorchComm()
+        self.local_loss, self.gather_with_grad = local_loss, gather_with_grad
         self.trainers = []
         self.logit_scale = sd["logit_scale"].detach().float().reshape(1).to(device)
         self.masters: Dict[str, torch.Tensor] = {"logit_scale": self.logit_scale}
@@ -291,10 +335,11 @@ class DualAudioStep(_PerceiverLensStep):
 
     def __init__(self, sd, tower: TowerCfg, text: TextCfg, lens: LensCfg, device, micro_batch: int = 256, lr: float = 2e-4,
                  betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2, rank: int = 0, world_size: int = 1,
-                 gemm_cfg: int = -1, comm=None):
+                 gemm_cfg: int = -1, comm=None, frozen_res_dtype=torch.float32, local_loss: bool = False,
+                 gather_with_grad: bool = False):
         from .train import AudioLensTrainer
-        self._init_common(sd, device, micro_batch, rank, world_size, comm)
-        self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg)
+        self._init_common(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad)
+        self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
         self.lens = LensEngine(sd, "visual.", tower, lens, device, gemm_cfg=gemm_cfg)
         self._mk = lambda: AudioLensTrainer(self.lens)
         self.masters["visual.class_embedding"] = self.lens.vit.cls
@@ -325,9 +370,9 @@ class DualAudioStep(_PerceiverLensStep):
             av, at = [t.contiguous() for t in allp.split(E, dim=1)]
         else:
             av, at = fv, ft
-        loss, c = pair_forward(av, at, scale)                       # ClipLossGeneral(x=visual, y=text)
-        dv, _, ds = pair_backward(c, need_dy=False)
-        dvraw = ops.l2_normalize_bwd(fv, dv[self.rank * B:(self.rank + 1) * B].contiguous(), vnorm)
+        loss, dv, _, ds = pair_loss_and_grads(self.comm, self.rank, self.world, fv, ft, av, at, scale,    # ClipLossGeneral(x=visual, y=text)
+                                              local_loss=self.local_loss, gather_with_grad=self.gather_with_grad, need_y=False)
+        dvraw = ops.l2_normalize_bwd(fv, dv, vnorm)
         for i in range(nmb):
             self._trainer(i).backward(dvraw[i * mb:(i + 1) * mb].contiguous())
         self.grads["logit_scale"] += ds * scale
@@ -348,12 +393,13 @@ class TriModalPCStep(_PerceiverLensStep):
 
     def __init__(self, sd, tower: TowerCfg, text: TextCfg, lens: LensCfg, device, micro_batch: int = 32, lr: float = 2e-4,
                  betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2, rank: int = 0, world_size: int = 1,
-                 gemm_cfg: int = -1, bn_training: bool = True, unlock_cls: bool = False, comm=None):
+                 gemm_cfg: int = -1, bn_training: bool = True, unlock_cls: bool = False, comm=None,
+                 frozen_res_dtype=torch.float32, local_loss: bool = False, gather_with_grad: bool = False):
         from .points import PointTokenizerTrainer
         from .train import PCLensTrainer
-        self._init_common(sd, device, micro_batch, rank, world_size, comm)
-        self.image = VitEngine(sd, "image.", tower, device, gemm_cfg=gemm_cfg)
-        self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg)
+        self._init_common(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad)
+        self.image = VitEngine(sd, "image.", tower, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
+        self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
         self.lens = LensEngine(sd, "visual.", tower, lens, device, gemm_cfg=gemm_cfg)
         self.tok = PointTokenizerTrainer(sd, "visual.visual_adapter.", lens, device, gemm_cfg=gemm_cfg, bn_training=bn_training)
         self._mk = lambda: PCLensTrainer(self.lens, self.tok, train_cls=unlock_cls)
@@ -393,12 +439,10 @@ class TriModalPCStep(_PerceiverLensStep):
             ai, at, av = [t.contiguous() for t in allp.split(E, dim=1)]
         else:
             ai, at, av = fi, ft, fv
-        l1, c1 = pair_forward(ai, av, scale)
-        l2, c2 = pair_forward(at, av, scale)
-        _, dv1, ds1 = pair_backward(c1, need_dx=False)
-        _, dv2, ds2 = pair_backward(c2, need_dx=False)
-        dv = (dv1 + dv2)[self.rank * B:(self.rank + 1) * B].contiguous()
-        dvraw = ops.l2_normalize_bwd(fv, dv, vnorm)
+        kw = dict(local_loss=self.local_loss, gather_with_grad=self.gather_with_grad, need_x=False)
+        l1, _, dv1, ds1 = pair_loss_and_grads(self.comm, self.rank, self.world, fi, fv, ai, av, scale, **kw)
+        l2, _, dv2, ds2 = pair_loss_and_grads(self.comm, self.rank, self.world, ft, fv, at, av, scale, **kw)
+        dvraw = ops.l2_normalize_bwd(fv, dv1 + dv2, vnorm)
         for i in range(nmb):
             self._trainer(i).backward(dvraw[i * mb:(i + 1) * mb].contiguous())
         self.grads["logit_scale"] += (ds1 + ds2) * scale
