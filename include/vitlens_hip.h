@@ -12,7 +12,8 @@
  *   - all matrices are row-major; "bf16" is a 16-bit brain-float bit pattern (uint16_t)
  *   - every function is stream-ordered and non-blocking on `stream` (a hipStream_t)
  *   - return value: 0 on success, non-zero on failure; vl_last_error() gives the message
- *   - no exceptions cross the ABI; no global mutable state except the last-error string
+ *   - no exceptions cross the ABI; no global mutable state except the last-error string, the one-time
+ *     hipFuncSetAttribute flags and the two tuning switches vl_gemm_set_persist_variant / vl_gemm_set_wide_stores
  */
 #ifndef VITLENS_HIP_H
 #define VITLENS_HIP_H
@@ -47,7 +48,9 @@ const char* vl_last_error(void);
 int vl_version(void);
 
 /* C[M,N] = A[M,K] · W[N,K]^T with fused epilogue.  A, W bf16.  K % 64 == 0, N % 4 == 0.
- * cfg: -1 auto | 0: 256x256 tile LDS-DMA | 1: 128x128 LDS-DMA | 2/3: same, register staging.
+ * cfg: -1 auto (persistent 256x256 kernel on the whole rounds of row tiles + tail kernel on the leftover rows;
+ *      128x128 tiles for small problems) | 0: 256x256 tile LDS-DMA | 1: 128x128 LDS-DMA | 2/3: same, register
+ *      staging | 4/5: persistent kernels | 6/7: experimental persistent variants | 9: tail kernel.
  * Replaces nn.Linear / out_proj / mlp.c_fc(+GELU) / mlp.c_proj(+residual)
  * (open_clip/transformer.py:226-234,268-271), Perceiver to_q/to_kv/to_out/FeedForward
  * (open_clip/perceiver.py:85-123), pooled @ proj (transformer.py:786-787) and
