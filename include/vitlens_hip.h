@@ -74,6 +74,9 @@ int vl_gemm_qkv_bf16(const void* A, const void* Win, const float* bias, void* q,
  * Autograd counterpart of the dW of nn.Linear / 1x1 Conv1d in the trainable Lens. */
 int vl_gemm_splitk_accum_f32(const void* A, const void* W, float* out, int M, int N, int K, int lda, int ldw, long ldo,
                              float alpha, int splits, float* ws, hipStream_t stream);
+/* Phase offset of the persistent GEMM kernel: workgroup phase (slot & 3) starts phase*units sleep units (~1 us each)
+ * late so that the HBM-bound epilogues of the phase groups do not coincide.  0 = off. */
+int vl_gemm_set_stagger(int units);
 int vl_gemm_set_persist_variant(int v);
 int vl_gemm_set_wide_stores(int on);   /* 16-byte epilogue stores (default on); off = 8-byte stores, for A/B runs */
 /* vl_gemm_bf16 + `out2` (with VL_EPI_BF16/VL_ACT_GELU also stores the pre-activation, bf16, for the

@@ -30,7 +30,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log 2>&1
 done
 cd $GRAFT_REPO_ROOT
-python tools/traffic_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE "gemm_nt_persist2_kernel<0>" gpurun_out/hbm_traffic.json 65792,4096,1024
+python tools/traffic_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE "gemm_nt_persist2_kernel<256, 256, 2, 4, 0>" gpurun_out/hbm_traffic.json 65792,4096,1024
 find gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE -name "*.csv" -size +8M -delete
 # keep only the small summaries
 find gpurun_out/prof -name "*kernel_trace*" -size +20M -delete

@@ -52,6 +52,10 @@ struct GemmP {
   // partial product to out + y*split_stride (f32 elements); ksplit_len == 0 -> whole K, no offset
   int ksplit_len;
   long split_stride;
+  // persistent kernel: workgroups of phase (slot & 3) start phase*stagger sleep units (~1 us each) late, so that the
+  // epilogues of the four phase groups - HBM-bound write/read bursts during which the matrix pipes idle - do not
+  // coincide
+  int stagger;
 };
 
 template <int BM, int BN>
@@ -329,44 +333,56 @@ __device__ __forceinline__ void store_tile_lds(const GemmP& p, f32x16 (&acc)[MT]
     store_tile<EPI, MT, NTL>(p, acc, mrow0, ncol0, fr, fg);
     return;
   } else {
-    if (p.wide >= 1) { store_tile<EPI, MT, NTL>(p, acc, mrow0, ncol0, fr, fg); return; }    // A/B + profiling modes
+    if (p.wide >= 1 && p.wide != 4) { store_tile<EPI, MT, NTL>(p, acc, mrow0, ncol0, fr, fg); return; }    // A/B + profiling modes
+    const bool do_store = p.wide != 4;       // profiling mode 4: transpose + arithmetic, no global stores (results WRONG)
     const int rsub = lane >> 3, c = lane & 7;
     unsigned char* const wr = wl + fr * 128;
     const int wsw = (fr >> 1) & 7;
     [[maybe_unused]] bf16_t* const pq = p.q; [[maybe_unused]] bf16_t* const pk = p.k; [[maybe_unused]] bf16_t* const pv = p.v;
+    // per-column-block constants (bias, QKV destination) first; then ROW blocks outermost so that the two 64-byte
+    // halves of a bf16 output line (j = 0, 1) are written back to back - with the column block outermost they were
+    // four row blocks apart and WRITE_SIZE rose to 1.5x the output bytes (partial lines evicted before completion).
+    int nj[NTL]; bool okj[NTL]; f32x4 bvj[NTL];
+    [[maybe_unused]] bf16_t* rowpj[NTL]; [[maybe_unused]] int hhj[NTL], ddj[NTL]; [[maybe_unused]] float qsj[NTL];
 #pragma unroll
     for (int j = 0; j < NTL; ++j) {
-      const int n = ncol0 + j * 32 + c * 4;
-      const bool col_ok = n < p.N;
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias && col_ok) bv = *(const f32x4*)(p.bias + n);
-      // QKV: column -> (part, head, offset) once per column block
-      [[maybe_unused]] bf16_t* rowp = nullptr; [[maybe_unused]] int hh = 0, dd = 0; [[maybe_unused]] float qs = 1.f;
+      nj[j] = ncol0 + j * 32 + c * 4;
+      okj[j] = nj[j] < p.N;
+      bvj[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias && okj[j]) bvj[j] = *(const f32x4*)(p.bias + nj[j]);
       if constexpr (EPI == EPI_QKV) {
         const int D = p.H << p.dh_shift;
-        const int nn = col_ok ? n : 0;
+        const int nn = okj[j] ? nj[j] : 0;
         const int wq = (nn >= D) + (nn >= 2 * D);
         const int cc = nn - wq * D;
         const int which = wq + p.which0;
-        hh = cc >> p.dh_shift; dd = cc & ((1 << p.dh_shift) - 1);
-        rowp = which == 0 ? pq : (which == 1 ? pk : pv);
-        qs = which == 0 ? p.qscale : 1.f;
+        hhj[j] = cc >> p.dh_shift; ddj[j] = cc & ((1 << p.dh_shift) - 1);
+        rowpj[j] = which == 0 ? pq : (which == 1 ? pk : pv);
+        qsj[j] = which == 0 ? p.qscale : 1.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int mb = mrow0 + i * 32;
+      [[maybe_unused]] int sb = 0, sl = 0;
+      if constexpr (EPI == EPI_QKV) {
+        int vz = 0;
+        asm volatile("" : "+v"(vz));        // per-lane opaque zero: keeps the division in VGPRs (SGPR pressure, see store_tile)
+        const int ma = mb + p.m_off + vz; sb = ma / p.L; sl = ma - sb * p.L;
       }
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
+      for (int j = 0; j < NTL; ++j) {
+        const int n = nj[j];
+        const bool col_ok = okj[j];
+        const f32x4 bv = bvj[j];
+        [[maybe_unused]] bf16_t* rowp = nullptr; [[maybe_unused]] int hh = 0, dd = 0; [[maybe_unused]] float qs = 1.f;
+        if constexpr (EPI == EPI_QKV) { rowp = rowpj[j]; hh = hhj[j]; dd = ddj[j]; qs = qsj[j]; }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 t = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
           *(f32x4*)(wr + (((q * 2 + fg) ^ wsw) << 4)) = t;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int mb = mrow0 + i * 32;
-        [[maybe_unused]] int sb = 0, sl = 0;
-        if constexpr (EPI == EPI_QKV) {
-          int vz = 0;
-          asm volatile("" : "+v"(vz));        // per-lane opaque zero: keeps the division in VGPRs (SGPR pressure, see store_tile)
-          const int ma = mb + p.m_off + vz; sb = ma / p.L; sl = ma - sb * p.L;
-        }
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
           const int r = pass * 8 + rsub;
@@ -374,6 +390,7 @@ __device__ __forceinline__ void store_tile_lds(const GemmP& p, f32x16 (&acc)[MT]
           f32x4 v = *(const f32x4*)(wl + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
           if (m >= p.M || !col_ok) continue;
           v = v * p.alpha + bv;
+          if (!do_store) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
           if constexpr (EPI == EPI_BF16) {
             if (p.act == 1) {
               if (p.out2) {
@@ -848,6 +865,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
   const int G = gridDim.x;
   const int slot = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
   if (slot >= ntiles) return;
+  for (int w = (slot & 3) * p.stagger; w > 0; --w) __builtin_amdgcn_s_sleep(32);       // phase offset (~1 us per unit)
   const int my_tiles = (ntiles - slot + G - 1) / G;
   const int nk = p.K >> 6;
   const int total = my_tiles * nk;
@@ -985,8 +1003,10 @@ static int num_cus() {
   return g_num_cus;
 }
 
+static int g_stagger = 0;       // sleep units per phase step of the persistent kernel (0 = all workgroups start together)
 static int g_wide_stores = 0;   // measured (profiles/r01e_kernel_bench_wide.log): the 16-byte exchange stores are 5-7 % SLOWER than the 8-byte path on fc/out
-extern "C" int vl_gemm_set_wide_stores(int on) { g_wide_stores = (on >= 0 && on <= 3) ? on : 0; return 0; }   // 2, 3: profiling modes (see store_tile)
+extern "C" int vl_gemm_set_stagger(int units) { g_stagger = (units >= 0 && units <= 64) ? units : 0; return 0; }
+extern "C" int vl_gemm_set_wide_stores(int on) { g_wide_stores = (on >= 0 && on <= 4) ? on : 0; return 0; }   // 2, 3: profiling modes (see store_tile)
 static int g_persist_variant = 2;   // 1 = plain persistent loop, 2 = hand-scheduled k-step, 3 = two 256x128 workgroups per CU
 extern "C" int vl_gemm_set_persist_variant(int v) { g_persist_variant = (v >= 1 && v <= 4) ? v : 2; return 0; }
 
@@ -1398,7 +1418,7 @@ extern "C" int vl_gemm_bf16_ex(const void* A, const void* W, const float* bias, 
   VL_CHECK_ARG((ldo & 3) == 0, "vl_gemm_bf16: ldo must be a multiple of 4");
   GemmP p{};
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = bias; p.out = out; p.res = res; p.out2 = out2;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.alpha = alpha; p.act = act; p.res_div = res_div; p.wide = g_wide_stores;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.alpha = alpha; p.act = act; p.res_div = res_div; p.wide = g_wide_stores; p.stagger = g_stagger;
   hipError_t e;
   switch (epi) {
     case VL_EPI_BF16: e = run_gemm<EPI_BF16>(p, cfg, stream); break;
@@ -1466,7 +1486,7 @@ extern "C" int vl_gemm_qkv_bf16_ex(const void* A, const void* W, const float* bi
   VL_CHECK_ARG(Lp >= L, "vl_gemm_qkv_bf16: Lp < L");
   GemmP p{};
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = bias;
-  p.M = B * L; p.N = count * H * dh; p.K = K; p.which0 = first; p.res_div = 1; p.wide = g_wide_stores; p.lda = lda; p.ldw = K; p.ldo = 0; p.alpha = 1.f;
+  p.M = B * L; p.N = count * H * dh; p.K = K; p.which0 = first; p.res_div = 1; p.wide = g_wide_stores; p.stagger = g_stagger; p.lda = lda; p.ldw = K; p.ldo = 0; p.alpha = 1.f;
   p.q = (bf16_t*)q; p.k = (bf16_t*)k; p.vt = (bf16_t*)vt; p.qt = (bf16_t*)qt; p.kt = (bf16_t*)kt; p.v = (bf16_t*)v; p.L = L; p.H = H; p.dh = dh; p.Lp = Lp; p.qscale = qscale; p.dh_shift = __builtin_ctz((unsigned)dh);
   hipError_t e = run_gemm<EPI_QKV>(p, cfg, stream);
   if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));

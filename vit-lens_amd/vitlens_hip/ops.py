@@ -389,5 +389,10 @@ def set_wide_stores(on):
     _lib.vl_gemm_set_wide_stores(int(on))
 
 
+def set_stagger(units: int):
+    """Phase offset (sleep units of ~1 us) between the four workgroup phase groups of the persistent GEMM; 0 = off."""
+    _lib.vl_gemm_set_stagger(int(units))
+
+
 def set_persist_variant(v: int):
     _lib.vl_gemm_set_persist_variant(int(v))
