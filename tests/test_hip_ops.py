@@ -89,6 +89,15 @@ def test_gemm_epilogues(cfg):
     resb = rnd(M, N, seed=8).bfloat16().cuda(); resb0 = resb.float().cpu()
     ops.gemm(a, w, bias, out=resb, res=resb, epi=ops.EPI_RES_BF16, cfg=cfg)
     assert relerr(resb, resb0 + acc) < 4e-3
+    # dX through GELU: out = acc * gelu'(u), u = saved pre-activation (bf16)
+    u = rnd(M, N, seed=9, scale=1.5).bfloat16().cuda()
+    out = ops.gemm(a, w, None, res=u, epi=ops.EPI_DGELU, cfg=cfg, out=torch.empty(M, N, device="cuda", dtype=torch.bfloat16))
+    uf = u.float().cpu().requires_grad_(True)
+    torch.nn.functional.gelu(uf).sum().backward()
+    assert relerr(out, (acc - bias.cpu()) * uf.grad) < 4e-3
+    # ReLU with a pre-activation-free bf16 residual epilogue
+    out = ops.gemm(a, w, bias, epi=ops.EPI_BF16, act=ops.ACT_RELU, cfg=cfg)
+    assert relerr(out, torch.relu(acc)) < 4e-3
     # GEGLU with interleaved (a, gate) rows
     out = ops.gemm(a, w, bias, epi=ops.EPI_GEGLU, cfg=cfg)
     ref = acc[:, 0::2] * torch.nn.functional.gelu(acc[:, 1::2])
