@@ -13,7 +13,7 @@
  *   - every function is stream-ordered and non-blocking on `stream` (a hipStream_t)
  *   - return value: 0 on success, non-zero on failure; vl_last_error() gives the message
  *   - no exceptions cross the ABI; no global mutable state except the last-error string, the one-time
- *     hipFuncSetAttribute flags and the two tuning switches vl_gemm_set_persist_variant / vl_gemm_set_wide_stores
+ *     hipFuncSetAttribute flags and the two tuning switches vl_gemm_set_stagger / vl_gemm_set_wide_stores
  */
 #ifndef VITLENS_HIP_H
 #define VITLENS_HIP_H
@@ -50,7 +50,7 @@ int vl_version(void);
 /* C[M,N] = A[M,K] · W[N,K]^T with fused epilogue.  A, W bf16.  K % 64 == 0, N % 4 == 0.
  * cfg: -1 auto (persistent 256x256 kernel on the whole rounds of row tiles + tail kernel on the leftover rows;
  *      128x128 tiles for small problems) | 0: 256x256 tile LDS-DMA | 1: 128x128 LDS-DMA | 2/3: same, register
- *      staging | 4/5: persistent kernels | 6/7: experimental persistent variants | 9: tail kernel.
+ *      staging | 5 (4 = alias): persistent kernel | 9: tail kernel.
  * Replaces nn.Linear / out_proj / mlp.c_fc(+GELU) / mlp.c_proj(+residual)
  * (open_clip/transformer.py:226-234,268-271), Perceiver to_q/to_kv/to_out/FeedForward
  * (open_clip/perceiver.py:85-123), pooled @ proj (transformer.py:786-787) and
@@ -77,7 +77,6 @@ int vl_gemm_splitk_accum_f32(const void* A, const void* W, float* out, int M, in
 /* Phase offset of the persistent GEMM kernel: workgroup phase (slot & 3) starts phase*units sleep units (~1 us each)
  * late so that the HBM-bound epilogues of the phase groups do not coincide.  0 = off. */
 int vl_gemm_set_stagger(int units);
-int vl_gemm_set_persist_variant(int v);
 int vl_gemm_set_wide_stores(int on);   /* 16-byte epilogue stores (default on); off = 8-byte stores, for A/B runs */
 /* vl_gemm_bf16 + `out2` (with VL_EPI_BF16/VL_ACT_GELU also stores the pre-activation, bf16, for the
  * backward) + `res_div` (VL_EPI_RES_BF16: residual row = m / res_div, i.e. one row broadcast over a group:

@@ -699,149 +699,7 @@ hipError_t launch_tail(const GemmP& p, hipStream_t s) {
 // Tile order: groups of GN consecutive N-tiles, M fastest inside a group, and each XCD owns a
 // contiguous run of G/8 tiles per round -> the 4 weight slabs of a group stay resident in that
 // XCD's L2 across rounds while activation tiles stream through once per group.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
-__global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
-    gemm_nt_persist_kernel(const GemmP p) {
-  constexpr int NW = WAVES_M * WAVES_N;
-  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
-  constexpr int MT = WTM / 32, NTL = WTN / 32;
-  constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW);
-  constexpr int GN = 4;
-  using S = Smem<BM, BN>;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int tiles_m = (p.M + BM - 1) / BM;
-  const int ntiles = tiles_m * tiles_n;
-  const int G = gridDim.x;                                   // multiple of 8
-  const int slot = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-  if (slot >= ntiles) return;
-  const int my_tiles = (ntiles - slot + G - 1) / G;
-  const int nk = p.K >> 6;
-  const int total = my_tiles * nk;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_m = wid % WAVES_M, wave_n = wid / WAVES_M;
-  const int srow = lane >> 3, pch = lane & 7;
-  const int fr = lane & 31, fg = lane >> 5;
-  const int fsw = (fr >> 1) & 7;
-
-  auto tile_origin = [&](int ti, int& m0, int& n0) {
-    const int v = ti * G + slot;
-    const int gsz = GN * tiles_m;
-    const int gid = v / gsz, rem = v - gid * gsz;
-    const int first_n = gid * GN;
-    const int gn = min(tiles_n - first_n, GN);
-    const int tm = rem / gn;
-    m0 = tm * BM; n0 = (first_n + (rem - tm * gn)) * BN;
-  };
-
-  const bf16_t* gA[AI]; const bf16_t* gB[BI];
-  auto set_sources = [&](int m0, int n0) {
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const int row = (i * NW + wid) * 8 + srow;
-      int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
-      gA[i] = p.A + (size_t)gm * p.lda + (pch ^ ((row >> 1) & 7)) * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const int row = (i * NW + wid) * 8 + srow;
-      int gn_ = n0 + row; gn_ = gn_ < p.N ? gn_ : p.N - 1;
-      gB[i] = p.W + (size_t)gn_ * p.ldw + (pch ^ ((row >> 1) & 7)) * 8;
-    }
-  };
-  auto stage_dma = [&](int kt, int buf) {
-    unsigned char* sA = smem + buf * S::STAGE;
-    unsigned char* sB = sA + S::A_BYTES;
-    const int k0 = kt << 6;
-#pragma unroll
-    for (int i = 0; i < AI; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA[i] + k0),
-                                       (__attribute__((address_space(3))) void*)(sA + (i * NW + wid) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < BI; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB[i] + k0),
-                                       (__attribute__((address_space(3))) void*)(sB + (i * NW + wid) * 1024), 16, 0, 0);
-  };
-
-  f32x16 acc[MT][NTL];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NTL; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  int cur_m0, cur_n0;
-  tile_origin(0, cur_m0, cur_n0);
-  set_sources(cur_m0, cur_n0);
-  stage_dma(0, 0);
-  __syncthreads();
-
-  int kt = 0, ti = 0;
-  for (int s = 0; s < total; ++s) {
-    const int buf = s & 1;
-    // ---- issue the DMA of step s+1 (possibly the first k-slab of the next tile) ----
-    if (s + 1 < total) {
-      if (kt + 1 == nk) {
-        int nm0, nn0;
-        tile_origin(ti + 1, nm0, nn0);
-        set_sources(nm0, nn0);
-        stage_dma(0, buf ^ 1);
-      } else {
-        stage_dma(kt + 1, buf ^ 1);
-      }
-    }
-    // ---- 4 k-substeps with register double-buffered fragments ----
-    const unsigned char* sA = smem + buf * S::STAGE + (wave_m * WTM + fr) * 128;
-    const unsigned char* sB = smem + buf * S::STAGE + S::A_BYTES + (wave_n * WTN + fr) * 128;
-    bf16x8 af[2][MT], wf[2][NTL];
-    {
-      const int off = ((0 * 2 + fg) ^ fsw) * 16;
-#pragma unroll
-      for (int i = 0; i < MT; ++i) af[0][i] = *(const bf16x8*)(sA + i * 32 * 128 + off);
-#pragma unroll
-      for (int j = 0; j < NTL; ++j) wf[0][j] = *(const bf16x8*)(sB + j * 32 * 128 + off);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int c = kk & 1;
-      if (kk < 3) {
-        const int off = (((kk + 1) * 2 + fg) ^ fsw) * 16;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[c ^ 1][i] = *(const bf16x8*)(sA + i * 32 * 128 + off);
-#pragma unroll
-        for (int j = 0; j < NTL; ++j) wf[c ^ 1][j] = *(const bf16x8*)(sB + j * 32 * 128 + off);
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NTL; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][j], af[c][i], acc[i][j], 0, 0, 0);
-    }
-    // ---- tile finished: store and reset (the next tile's first slab is already in flight) ----
-    if (kt + 1 == nk) {
-      { const GemmP pe = reload_params(); store_tile<EPI, MT, NTL>(pe, acc, cur_m0 + wave_m * WTM, cur_n0 + wave_n * WTN, fr, fg); }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NTL; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-      kt = 0; ++ti;
-      if (s + 1 < total) tile_origin(ti, cur_m0, cur_n0);
-    } else {
-      ++kt;
-    }
-    __syncthreads();
-  }
-}
-
-
-// Persistent kernel, hand-scheduled k-step: the 8 LDS-DMA instructions of the next step and the 6
+// Hand-scheduled k-step: the 8 LDS-DMA instructions of the next step and the 6
 // fragment reads of the next 16-wide k-substep are issued ahead of the MFMAs of the current
 // substep (sched_barrier fences pin the phases), so neither DMA issue cost nor ds_read latency sits
 // in front of the matrix pipe.  The k-step body is one branch-free basic block: source pointers of
@@ -1007,348 +865,30 @@ static int g_stagger = 0;       // sleep units per phase step of the persistent 
 static int g_wide_stores = 0;   // measured (profiles/r01e_kernel_bench_wide.log): the 16-byte exchange stores are 5-7 % SLOWER than the 8-byte path on fc/out
 extern "C" int vl_gemm_set_stagger(int units) { g_stagger = (units >= 0 && units <= 64) ? units : 0; return 0; }
 extern "C" int vl_gemm_set_wide_stores(int on) { g_wide_stores = (on >= 0 && on <= 4) ? on : 0; return 0; }   // 2, 3: profiling modes (see store_tile)
-static int g_persist_variant = 2;   // 1 = plain persistent loop, 2 = hand-scheduled k-step, 3 = two 256x128 workgroups per CU
-extern "C" int vl_gemm_set_persist_variant(int v) { g_persist_variant = (v >= 1 && v <= 4) ? v : 2; return 0; }
-
-template <int EPI, int VAR>
-hipError_t launch_persist_v(const GemmP& p, hipStream_t s) {
-  using S = Smem<256, 256>;
-  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-  auto kern = (VAR == 1) ? gemm_nt_persist_kernel<256, 256, 2, 4, EPI> : gemm_nt_persist2_kernel<256, 256, 2, 4, EPI>;
-  constexpr int smem = 2 * S::STAGE + (VAR == 2 ? 8 * 4096 : 0);      // + one 4 KB epilogue-transpose slab per wave = 160 KB
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  int G = num_cus() & ~7;
-  if (tiles < G) G = (tiles + 7) & ~7;
-  hipLaunchKernelGGL(kern, dim3(G), dim3(512), smem, s, p);
-  return hipGetLastError();
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// Two-workgroups-per-CU variant: 256 x 128 tile, 4 waves (2 x 2, 128 x 64 accumulators each -- same
-// LDS-read : MFMA ratio as the 8-wave kernel), BK = 32 so two stages cost 48 KB and TWO workgroups are
-// resident per CU.  Each SIMD then hosts one wave of each workgroup; the workgroups have independent
-// barriers and drift apart, so the matrix pipe is fed by one while the other sits in its barrier /
-// LDS-DMA wait (the single-workgroup kernel idles the pipe ~45 % of the time there).
-template <int EPI>
-__global__ void __launch_bounds__(256, 2)
-    gemm_nt_persist3_kernel(const GemmP p) {
-  constexpr int BM = 256, BN = 128, NW = 4, WTM = 128, WTN = 64, MT = 4, NTL = 2;
-  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;     // 64-byte rows (BK = 32)
-  constexpr int GN = 8;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int tiles_m = (p.M + BM - 1) / BM;
-  const int ntiles = tiles_m * tiles_n;
-  const int G = gridDim.x;
-  const int slot = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-  if (slot >= ntiles) return;
-  const int my_tiles = (ntiles - slot + G - 1) / G;
-  const int nk = p.K >> 5;
-  const int total = my_tiles * nk;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_m = wid & 1, wave_n = wid >> 1;
-  const int srow = lane >> 2, pch = lane & 3;        // one DMA instruction = 16 rows x 64 B
-  const int fr = lane & 31, fg = lane >> 5;
-  const int fsw = (fr >> 2) & 3;                     // 4 rows per 256-byte bank row, 4 chunks per row
-
-  auto tile_origin = [&](int ti, int& m0, int& n0) {
-    const int v = ti * G + slot;
-    const int gsz = GN * tiles_m;
-    const int gid = v / gsz, rem = v - gid * gsz;
-    const int first_n = gid * GN;
-    const int gn = min(tiles_n - first_n, GN);
-    const int tm = rem / gn;
-    m0 = tm * BM; n0 = (first_n + (rem - tm * gn)) * BN;
-  };
-  // 16 A row-groups + 8 W row-groups of 16 rows per stage; 4 waves -> 4 + 2 DMA instructions per wave
-  const bf16_t* src[6];
-  auto set_sources = [&](int m0, int n0, int k0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (i * NW + wid) * 16 + srow;
-      int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
-      src[i] = p.A + (size_t)gm * p.lda + (pch ^ ((row >> 2) & 3)) * 8 + k0;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = (i * NW + wid) * 16 + srow;
-      int gn_ = n0 + row; gn_ = gn_ < p.N ? gn_ : p.N - 1;
-      src[4 + i] = p.W + (size_t)gn_ * p.ldw + (pch ^ ((row >> 2) & 3)) * 8 + k0;
-    }
-  };
-  auto dma = [&](int i, unsigned char* stage_base) {
-    unsigned char* dst = stage_base + (i < 4 ? (i * NW + wid) * 1024 : A_BYTES + ((i - 4) * NW + wid) * 1024);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-  };
-
-  f32x16 acc[MT][NTL];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NTL; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  int cur_m0, cur_n0, nxt_m0, nxt_n0;
-  tile_origin(0, cur_m0, cur_n0);
-  nxt_m0 = cur_m0; nxt_n0 = cur_n0;
-  set_sources(cur_m0, cur_n0, 0);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) dma(i, smem);
-  int kt = 0, ti = 0, lkt = 0, lti = 0;
-  auto advance_load = [&]() {
-    ++lkt;
-    if (lkt == nk) { lkt = 0; ++lti; if (lti < my_tiles) tile_origin(lti, nxt_m0, nxt_n0); else { lti = my_tiles - 1; } }
-    set_sources(nxt_m0, nxt_n0, lkt << 5);
-  };
-  advance_load();
-  __syncthreads();
-
-  for (int s = 0; s < total; ++s) {
-    unsigned char* cur = smem + (s & 1) * STAGE;
-    unsigned char* oth = smem + ((s & 1) ^ 1) * STAGE;
-    const unsigned char* sA = cur + (wave_m * WTM + fr) * 64;
-    const unsigned char* sB = cur + A_BYTES + (wave_n * WTN + fr) * 64;
-    bf16x8 af[2][MT], wf[2][NTL];
-    auto ldfrag = [&](int kk, int c) {
-      const int off = ((kk * 2 + fg) ^ fsw) * 16;
-#pragma unroll
-      for (int j = 0; j < NTL; ++j) wf[c][j] = *(const bf16x8*)(sB + j * 32 * 64 + off);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) af[c][i] = *(const bf16x8*)(sA + i * 32 * 64 + off);
-    };
-    auto mma = [&](int c) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NTL; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][j], af[c][i], acc[i][j], 0, 0, 0);
-    };
-    ldfrag(0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    dma(0, oth); dma(1, oth); dma(2, oth); dma(3, oth); dma(4, oth); dma(5, oth);
-    ldfrag(1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(1);
-    __builtin_amdgcn_sched_barrier(0);
-
-    if (kt + 1 == nk) {
-      { const GemmP pe = reload_params(); store_tile<EPI, MT, NTL>(pe, acc, cur_m0 + wave_m * WTM, cur_n0 + wave_n * WTN, fr, fg); }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NTL; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-      kt = 0; ++ti;
-      if (ti < my_tiles) tile_origin(ti, cur_m0, cur_n0);
-    } else {
-      ++kt;
-    }
-    advance_load();
-    __syncthreads();
-  }
-}
-
-template <int EPI>
-hipError_t launch_persist3(const GemmP& p, hipStream_t s) {
-  const int tiles = ((p.M + 255) / 256) * ((p.N + 127) / 128);
-  auto kern = gemm_nt_persist3_kernel<EPI>;
-  constexpr int smem = 2 * (256 * 64 + 128 * 64);
-  int G = 2 * (num_cus() & ~7);
-  if (tiles < G) G = (tiles + 7) & ~7;
-  hipLaunchKernelGGL(kern, dim3(G), dim3(256), smem, s, p);
-  return hipGetLastError();
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// Deep-pipeline variant.  Measured on the kernels above: global->LDS throughput per CU follows
-// Little's law -- one 64 KB k-slab in flight over a ~1.8 us loaded L2/MALL latency = ~35 GB/s per CU,
-// which is exactly what they sustain (1.17 PFLOP/s at 8192^3), and the variants that move MORE bytes per
-// flop (256x128, 128x128 tiles) are slower in proportion.  So: same 256x256 / 8-wave tile, but BK = 32
-// slabs in a 5-slot LDS ring (5 x 32 KB = all 160 KB) with the LDS-DMA running FOUR slabs (128 KB) ahead,
-// retired by counted `s_waitcnt vmcnt(12)` (never 0 in the loop) and a raw s_barrier per slab.
-template <int EPI>
-__global__ void __launch_bounds__(512)
-    gemm_nt_persist4_kernel(const GemmP p) {
-  constexpr int BM = 256, BN = 256, NW = 8, WTM = 128, WTN = 64, MT = 4, NTL = 2, NS = 5;
-  constexpr int A_BYTES = BM * 64, STAGE = (BM + BN) * 64;       // 64-byte rows (BK = 32), 32 KB per slot
-  constexpr int GN = 4;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int tiles_m = (p.M + BM - 1) / BM;
-  const int ntiles = tiles_m * tiles_n;
-  const int G = gridDim.x;
-  const int slot = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-  if (slot >= ntiles) return;
-  const int my_tiles = (ntiles - slot + G - 1) / G;
-  const int nk = p.K >> 5;
-  const int total = my_tiles * nk;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_m = wid % 2, wave_n = wid / 2;
-  const int srow = lane >> 2, pch = lane & 3;        // one DMA instruction = 16 rows x 64 B
-  const int fr = lane & 31, fg = lane >> 5;
-  const int fsw = (fr >> 2) & 3;
-
-  auto tile_origin = [&](int ti, int& m0, int& n0) {
-    const int v = ti * G + slot;
-    const int gsz = GN * tiles_m;
-    const int gid = v / gsz, rem = v - gid * gsz;
-    const int first_n = gid * GN;
-    const int gn = min(tiles_n - first_n, GN);
-    const int tm = rem / gn;
-    m0 = tm * BM; n0 = (first_n + (rem - tm * gn)) * BN;
-  };
-  // per slab: 16 A + 16 W row-groups of 16 rows; wave w moves groups {w, w+8} of each -> 4 DMA instr / slab
-  const bf16_t* src[4];
-  int lm0, ln0, lkt = 0, lti = 0;                    // position of the NEXT slab to be requested
-  tile_origin(0, lm0, ln0);
-  auto set_sources = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = (i * NW + wid) * 16 + srow;
-      const int sw = (pch ^ ((row >> 2) & 3)) * 8 + (lkt << 5);
-      int gm = lm0 + row; gm = gm < p.M ? gm : p.M - 1;
-      int gn_ = ln0 + row; gn_ = gn_ < p.N ? gn_ : p.N - 1;
-      src[i] = p.A + (size_t)gm * p.lda + sw;
-      src[2 + i] = p.W + (size_t)gn_ * p.ldw + sw;
-    }
-  };
-  auto advance_load = [&]() {
-    ++lkt;
-    if (lkt == nk) { lkt = 0; ++lti; if (lti < my_tiles) tile_origin(lti, lm0, ln0); else lti = my_tiles - 1; }
-    set_sources();
-  };
-  auto issue = [&](int ring_slot) {
-    unsigned char* base = smem + ring_slot * STAGE;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
-                                       (__attribute__((address_space(3))) void*)(base + (i * NW + wid) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[2 + i],
-                                       (__attribute__((address_space(3))) void*)(base + A_BYTES + (i * NW + wid) * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x16 acc[MT][NTL];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NTL; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // prologue: request slabs 0..3 (past the end of this workgroup's work the last slab is re-requested:
-  // every wave always has exactly 4 groups of 4 DMA instructions in flight, which is what vmcnt(12) counts on)
-  set_sources();
-#pragma unroll
-  for (int i = 0; i < NS - 1; ++i) { issue(i); advance_load(); }
-
-  int cur_m0, cur_n0, kt = 0, ti = 0, rs = 0;        // rs = ring slot of the slab being computed
-  tile_origin(0, cur_m0, cur_n0);
-  for (int s = 0; s < total; ++s) {
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");          // this wave's share of slab s has landed
-    __builtin_amdgcn_s_barrier();                               // ...everyone's has; slot (rs+4)%5 is free again
-    {
-      int free_slot = rs + (NS - 1); if (free_slot >= NS) free_slot -= NS;
-      issue(free_slot);                                         // slab s+4
-    }
-    const unsigned char* sA = smem + rs * STAGE + (wave_m * WTM + fr) * 64;
-    const unsigned char* sB = smem + rs * STAGE + A_BYTES + (wave_n * WTN + fr) * 64;
-    bf16x8 af[2][MT], wf[2][NTL];
-    auto ldfrag = [&](int kk, int c) {
-      const int off = ((kk * 2 + fg) ^ fsw) * 16;
-#pragma unroll
-      for (int j = 0; j < NTL; ++j) wf[c][j] = *(const bf16x8*)(sB + j * 32 * 64 + off);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) af[c][i] = *(const bf16x8*)(sA + i * 32 * 64 + off);
-    };
-    auto mma = [&](int c) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NTL; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][j], af[c][i], acc[i][j], 0, 0, 0);
-    };
-    ldfrag(0, 0);
-    ldfrag(1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(1);
-    __builtin_amdgcn_sched_barrier(0);
-
-    if (kt + 1 == nk) {
-      { const GemmP pe = reload_params(); store_tile<EPI, MT, NTL>(pe, acc, cur_m0 + wave_m * WTM, cur_n0 + wave_n * WTN, fr, fg); }
-      // stores and loads share vmcnt and may retire out of order w.r.t. each other: with both kinds
-      // outstanding a counted wait no longer identifies the oldest slab -> drain once per tile
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NTL; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-      kt = 0; ++ti;
-      if (ti < my_tiles) tile_origin(ti, cur_m0, cur_n0);
-    } else {
-      ++kt;
-    }
-    advance_load();
-    rs = rs + 1 == NS ? 0 : rs + 1;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // retire the tail re-requests before the LDS is released
-}
-
-template <int EPI>
-hipError_t launch_persist4(const GemmP& p, hipStream_t s) {
-  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-  auto kern = gemm_nt_persist4_kernel<EPI>;
-  constexpr int smem = 5 * 512 * 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  int G = num_cus() & ~7;
-  if (tiles < G) G = (tiles + 7) & ~7;
-  hipLaunchKernelGGL(kern, dim3(G), dim3(512), smem, s, p);
-  return hipGetLastError();
-}
 
 template <int EPI>
 hipError_t launch_persist(const GemmP& p, hipStream_t s) {
-  if (g_persist_variant == 3) return launch_persist3<EPI>(p, s);
-  if (g_persist_variant == 4) return launch_persist4<EPI>(p, s);
-  return g_persist_variant == 1 ? launch_persist_v<EPI, 1>(p, s) : launch_persist_v<EPI, 2>(p, s);
+  using S = Smem<256, 256>;
+  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  auto kern = gemm_nt_persist2_kernel<256, 256, 2, 4, EPI>;
+  constexpr int smem = 2 * S::STAGE + 8 * 4096;      // + one 4 KB epilogue-transpose slab per wave = 160 KB
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  int G = num_cus() & ~7;
+  if (tiles < G) G = (tiles + 7) & ~7;
+  hipLaunchKernelGGL(kern, dim3(G), dim3(512), smem, s, p);
+  return hipGetLastError();
 }
+
 
 template <int EPI>
 hipError_t dispatch(const GemmP& p, int cfg, hipStream_t s) {
   // cfg bit0: 0 = 256x256 tile (8 waves), 1 = 128x128 tile (4 waves); bit1: 1 = register staging
-  if (cfg == 4) return launch_persist_v<EPI, 1>(p, s);
-  if (cfg == 5) return launch_persist_v<EPI, 2>(p, s);
-  if (cfg == 6) return launch_persist3<EPI>(p, s);
-  if (cfg == 7) return launch_persist4<EPI>(p, s);
+  if (cfg == 4 || cfg == 5) return launch_persist<EPI>(p, s);       // 4: historical alias
   if (cfg == 9) return launch_tail<EPI>(p, s);
   switch (cfg & 3) {
     case 0: return launch<256, 256, 2, 4, EPI, true>(p, s);
@@ -1371,9 +911,8 @@ static int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } retu
 template <int EPI>
 static hipError_t run_gemm(const GemmP& p, int cfg, hipStream_t s) {
   if (cfg >= 0) return dispatch<EPI>(p, cfg, s);
-  const bool two_wg = g_persist_variant == 3;
-  const int G = (num_cus() & ~7) * (two_wg ? 2 : 1);
-  const int tiles_n = two_wg ? (p.N + 127) / 128 : (p.N + 255) / 256, full_m = p.M / 256;
+  const int G = num_cus() & ~7;
+  const int tiles_n = (p.N + 255) / 256, full_m = p.M / 256;
   if ((long)full_m * tiles_n < G) return dispatch<EPI>(p, 1, s);
   const int step = G / gcd_i(G, tiles_n);
   const int main_m = (full_m / step) * step;

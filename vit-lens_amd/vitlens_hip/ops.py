@@ -394,5 +394,3 @@ def set_stagger(units: int):
     _lib.vl_gemm_set_stagger(int(units))
 
 
-def set_persist_variant(v: int):
-    _lib.vl_gemm_set_persist_variant(int(v))
