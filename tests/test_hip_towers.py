@@ -123,7 +123,7 @@ def test_bench_geometry_tail_rows_match_small_batch(res_dtype):
     first = eng.encode_image(image[:4]).clone()
     assert bool(torch.isfinite(full).all())
     # not bit-exact: the kernels sum K in different orders, and an fp32 ulp in x can flip the bf16 rounding of LN(x)
-    tol = 5e-3 if res_dtype == torch.float32 else 2e-2
+    tol = 1e-2 if res_dtype == torch.float32 else 2e-2
     assert relerr(full[-4:], small) < tol, relerr(full[-4:], small)
     assert relerr(full[:4], first) < tol, relerr(full[:4], first)
     cs = torch.nn.functional.cosine_similarity(full[-4:].float(), small.float(), dim=-1)

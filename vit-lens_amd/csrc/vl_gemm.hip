@@ -315,6 +315,115 @@ __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL
   }
 }
 
+// bf16-output epilogues through the LDS transpose with 16-byte global accesses.  A wave-store instruction costs the
+// store path ~73 clk whatever its width (measured: 128 KB of dwordx2 stores per tile drain at ~7 B/clk/CU), so the
+// number of store instructions is what the epilogue pays for.  The values are therefore packed to bf16 BEFORE the
+// transpose (slab = 32 rows x 64 columns bf16 = the same 4 KB) and come back as 8 consecutive columns per lane:
+// 8 lanes write one whole 128-byte line with a single dwordx4 each - half the store instructions of the fp32
+// transpose.  Arithmetic that needs another tensor of the output's shape (bf16 residual, saved pre-activation for
+// dGELU, GELU when the pre-activation is also kept) runs after the read-back on the bf16-rounded values, with
+// coalesced 16-byte loads - the same rounding points as the reference's autocast (bf16 linear output, then the add /
+// activation); bias, alpha, the q scale and GELU-without-save are applied in fp32 before packing.
+template <int EPI, int MT>
+__device__ __forceinline__ void store_tile_lds16(const GemmP& p, f32x16 (&acc)[MT][2], int mrow0, int ncol0, int fr, int fg,
+                                                 int lane, unsigned char* wl) {
+  const int rsub = lane >> 3, c = lane & 7;
+  unsigned char* const wr = wl + fr * 128 + fg * 8;
+  const int wsw = (fr >> 1) & 7;
+  const int n8 = ncol0 + c * 8;
+  const bool col_ok = n8 < p.N;
+  const bool gelu_pre = (EPI == EPI_BF16) && p.act == 1 && !p.out2;
+  // per-lane destination of the read-back chunk (QKV: column -> part, head, offset)
+  [[maybe_unused]] bf16_t* rowp = nullptr; [[maybe_unused]] int hh = 0, dd = 0;
+  if constexpr (EPI == EPI_QKV) {
+    // (pointer fields copied to locals first: selecting among struct members by index forces the struct to scratch)
+    bf16_t* const pq = p.q; bf16_t* const pk = p.k; bf16_t* const pv = p.v;
+    const int D = p.H << p.dh_shift;
+    const int nn = col_ok ? n8 : 0;
+    const int wq = (nn >= D) + (nn >= 2 * D);
+    const int cc = nn - wq * D;
+    const int which = wq + p.which0;
+    hh = cc >> p.dh_shift; dd = cc & ((1 << p.dh_shift) - 1);
+    rowp = which == 0 ? pq : (which == 1 ? pk : pv);
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = ncol0 + j * 32 + q * 8 + fg * 4;
+        f32x4 v = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+        v = v * p.alpha;
+        if (p.bias && n < p.N) v = v + *(const f32x4*)(p.bias + n);
+        if constexpr (EPI == EPI_QKV) {
+          const int D = p.H << p.dh_shift;
+          if (p.which0 == 0 && n < D) v = v * p.qscale;
+        }
+        if constexpr (EPI == EPI_BF16) {
+          if (gelu_pre) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+          } else if (p.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+        }
+        u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+        *(u32x2*)(wr + (((j * 4 + q) ^ wsw) << 4)) = o;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int mb = mrow0 + i * 32;
+    [[maybe_unused]] int sb = 0, sl = 0;
+    if constexpr (EPI == EPI_QKV) {
+      int vz = 0;
+      asm volatile("" : "+v"(vz));
+      const int ma = mb + p.m_off + vz; sb = ma / p.L; sl = ma - sb * p.L;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int r = pass * 8 + rsub;
+      const int m = mb + r;
+      u32x4 w = *(const u32x4*)(wl + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+      if (m >= p.M || !col_ok) continue;
+      if constexpr (EPI == EPI_BF16) {
+        if (p.act == 1 && p.out2) {
+          *(u32x4*)((bf16_t*)p.out2 + (size_t)m * p.ldo + n8) = w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            w[e] = pack2bf(gelu_erf(bf2f((bf16_t)(w[e] & 0xffff))), gelu_erf(bf2f((bf16_t)(w[e] >> 16))));
+        }
+        *(u32x4*)((bf16_t*)p.out + (size_t)m * p.ldo + n8) = w;
+      } else if constexpr (EPI == EPI_RES_BF16) {
+        const u32x4 rr = *(const u32x4*)((const bf16_t*)p.res + (size_t)((m + p.m_off) / p.res_div) * p.ldo + n8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float lo = bf2f((bf16_t)(w[e] & 0xffff)) + bf2f((bf16_t)(rr[e] & 0xffff));
+          float hi = bf2f((bf16_t)(w[e] >> 16)) + bf2f((bf16_t)(rr[e] >> 16));
+          if (p.act == 2) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+          w[e] = pack2bf(lo, hi);
+        }
+        *(u32x4*)((bf16_t*)p.out + (size_t)m * p.ldo + n8) = w;
+      } else if constexpr (EPI == EPI_DGELU) {
+        const u32x4 rr = *(const u32x4*)((const bf16_t*)p.res + (size_t)m * p.ldo + n8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          w[e] = pack2bf(bf2f((bf16_t)(w[e] & 0xffff)) * gelu_erf_grad(bf2f((bf16_t)(rr[e] & 0xffff))),
+                         bf2f((bf16_t)(w[e] >> 16)) * gelu_erf_grad(bf2f((bf16_t)(rr[e] >> 16))));
+        *(u32x4*)((bf16_t*)p.out + (size_t)m * p.ldo + n8) = w;
+      } else if constexpr (EPI == EPI_QKV) {
+        if (rowp) {
+          int qb = sb, ql = sl + r;
+          while (ql >= p.L) { ql -= p.L; ++qb; }
+          *(u32x4*)(rowp + ((((size_t)qb * p.H + hh) * p.L + ql) << p.dh_shift) + dd) = w;
+        }
+      }
+    }
+    asm volatile("" ::: "memory");
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Epilogue through a wave-private LDS transpose (persistent kernel).  In the accumulator layout a lane owns one
 // output ROW, so a direct store instruction touches 32 different 128-byte lines with 16 bytes each: the store
@@ -335,6 +444,17 @@ __device__ __forceinline__ void store_tile_lds(const GemmP& p, f32x16 (&acc)[MT]
   } else {
     if (p.wide >= 1 && p.wide != 4) { store_tile<EPI, MT, NTL>(p, acc, mrow0, ncol0, fr, fg); return; }    // A/B + profiling modes
     const bool do_store = p.wide != 4;       // profiling mode 4: transpose + arithmetic, no global stores (results WRONG)
+    [[maybe_unused]] bool done16 = false;
+    if constexpr ((EPI == EPI_BF16 || EPI == EPI_RES_BF16 || EPI == EPI_DGELU || EPI == EPI_QKV) && NTL == 2) {
+      // bf16 outputs: 16-byte path when rows stay 16-byte aligned (QKV destinations are [.., dh] rows with dh % 8 == 0)
+      const bool al = EPI == EPI_QKV ? (p.dh_shift >= 3) : ((p.ldo & 7) == 0);
+      if (do_store && p.wide == 0 && (p.N & 7) == 0 && al) {
+        store_tile_lds16<EPI, MT>(p, acc, mrow0, ncol0, fr, fg, lane, wl);
+        if constexpr (EPI != EPI_QKV) return;
+        done16 = true;
+      }
+    }
+    if (!done16) {
     const int rsub = lane >> 3, c = lane & 7;
     unsigned char* const wr = wl + fr * 128;
     const int wsw = (fr >> 1) & 7;
@@ -439,6 +559,7 @@ __device__ __forceinline__ void store_tile_lds(const GemmP& p, f32x16 (&acc)[MT]
         asm volatile("" ::: "memory");
       }
     }
+    }   // !done16
     // transposed attention operands straight from the accumulator layout (lanes = consecutive tokens = contiguous)
     if constexpr (EPI == EPI_QKV) {
       if (p.qt || p.kt || p.vt) {
