@@ -50,7 +50,7 @@ int vl_version(void);
 /* C[M,N] = A[M,K] · W[N,K]^T with fused epilogue.  A, W bf16.  K % 64 == 0, N % 4 == 0.
  * cfg: -1 auto (persistent 256x256 kernel on the whole rounds of row tiles + tail kernel on the leftover rows;
  *      128x128 tiles for small problems) | 0: 256x256 tile LDS-DMA | 1: 128x128 LDS-DMA | 2/3: same, register
- *      staging | 5 (4 = alias): persistent kernel | 9: tail kernel.
+ *      staging | 5 (4 = alias): persistent kernel | 6: the same on 256x128 tiles (experiment) | 9: tail kernel.
  * Replaces nn.Linear / out_proj / mlp.c_fc(+GELU) / mlp.c_proj(+residual)
  * (open_clip/transformer.py:226-234,268-271), Perceiver to_q/to_kv/to_out/FeedForward
  * (open_clip/perceiver.py:85-123), pooled @ proj (transformer.py:786-787) and

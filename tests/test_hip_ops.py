@@ -27,7 +27,7 @@ def relerr(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 5, 9, -1])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 5, 6, 9, -1])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 200, 128), (1000, 1028, 1024), (65, 32, 64), (514, 3072, 1024)])
 def test_gemm_f32_out(cfg, M, N, K):
     """Transpose-detecting (asymmetric) operands; fp32 accumulate => rel err <= 1e-5 vs fp32 matmul of
@@ -41,7 +41,7 @@ def test_gemm_f32_out(cfg, M, N, K):
     assert relerr(out, ref) < 1e-5, (relerr(out, ref), maxerr(out, ref))
 
 
-@pytest.mark.parametrize("cfg", [5, -1])
+@pytest.mark.parametrize("cfg", [5, 6, -1])
 def test_gemm_persistent_many_tiles_and_row_split(cfg):
     """Persistent kernels: several tiles per workgroup, tile switch inside the flattened k-loop, and (auto)
     the split into a CU-balanced persistent launch + a 128x128 remainder launch on the last rows."""
@@ -70,7 +70,7 @@ def test_gemm_identity_asymmetric(cfg):
     assert torch.equal(out.cpu(), w.float().cpu().t())
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 5, 9])
+@pytest.mark.parametrize("cfg", [0, 1, 5, 6, 9])
 def test_gemm_epilogues(cfg):
     ops = _ops()
     M, N, K = 520, 384, 192

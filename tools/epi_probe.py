@@ -32,7 +32,7 @@ def main():
         row = []
         for mode in (0, 4, 2):
             ops.set_wide_stores(mode)
-            row.append(timeit(lambda: ops.gemm(a, w, bias, out=out, res=res, epi=epi, act=act, cfg=5)))
+            row.append(timeit(lambda: ops.gemm(a, w, bias, out=out, res=res, epi=epi, act=act, cfg=int(os.environ.get('GEMM_CFG', 5)))))
         ops.set_wide_stores(0)
         fl = 2.0 * M * N * K
         print(f"{name:13s} normal {row[0]:.3f} ms ({fl / row[0] / 1e9:.0f} TF/s) | transpose+math, no stores {row[1]:.3f} ms | no epilogue {row[2]:.3f} ms ({fl / row[2] / 1e9:.0f} TF/s)", flush=True)

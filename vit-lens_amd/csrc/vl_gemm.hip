@@ -833,7 +833,9 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MT = WTM / 32, NTL = WTN / 32;
   constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW);
-  static_assert(AI == 4 && BI == 4 && MT == 4 && NTL == 2, "schedule written for the 256x256 / 8-wave tile");
+  static_assert(NW == 8 && AI == 4 && (BI == 4 || BI == 2) && NTL == 2 && (MT == 4 || MT == 2),
+                "schedule written for 8 waves on a 256x256 (2x4 waves) or 256x128 (4x2 waves) tile");
+  constexpr int NU = AI + BI;          // 1 KB LDS-DMA units per wave per k-step
   constexpr int GN = 4;
   using S = Smem<BM, BN>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -866,21 +868,26 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
     const int tm = rem / gn;
     m0 = tm * BM; n0 = (first_n + (rem - tm * gn)) * BN;
   };
-  // src[0..3] = A row groups, src[4..7] = W row groups; pointers already include the k offset
-  const bf16_t* src[8];
+  // src[0..AI) = A row groups, src[AI..NU) = W row groups; pointers already include the k offset
+  const bf16_t* src[NU];
   auto set_sources = [&](int m0, int n0, int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AI; ++i) {
       const int row = (i * NW + wid) * 8 + srow;
       const int sw = (pch ^ ((row >> 1) & 7)) * 8;
       int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
-      int gn_ = n0 + row; gn_ = gn_ < p.N ? gn_ : p.N - 1;
       src[i] = p.A + (size_t)gm * p.lda + sw + k0;
-      src[4 + i] = p.W + (size_t)gn_ * p.ldw + sw + k0;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int row = (i * NW + wid) * 8 + srow;
+      const int sw = (pch ^ ((row >> 1) & 7)) * 8;
+      int gn_ = n0 + row; gn_ = gn_ < p.N ? gn_ : p.N - 1;
+      src[AI + i] = p.W + (size_t)gn_ * p.ldw + sw + k0;
     }
   };
   auto dma = [&](int i, unsigned char* stage_base) {
-    unsigned char* dst = stage_base + (i < 4 ? 0 : S::A_BYTES) + ((i & 3) * NW + wid) * 1024;
+    unsigned char* dst = stage_base + (i < AI ? 0 : S::A_BYTES) + ((i < AI ? i : i - AI) * NW + wid) * 1024;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
@@ -898,7 +905,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
   nxt_m0 = cur_m0; nxt_n0 = cur_n0;
   set_sources(cur_m0, cur_n0, 0);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) dma(i, smem);
+  for (int i = 0; i < NU; ++i) dma(i, smem);
   // sources for the DMA issued during step 0 (= data of step 1)
   int kt = 0, ti = 0;          // position of the step being computed
   int lkt = 0, lti = 0;        // position of the step whose data the in-loop DMA loads (s+1)
@@ -934,12 +941,14 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
     // half of the next step's DMA) ahead of its own MFMAs and the waits land one phase later.
     ldfrag(0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    dma(0, oth); dma(1, oth); dma(2, oth); dma(3, oth);
+#pragma unroll
+    for (int i = 0; i < NU / 2; ++i) dma(i, oth);
     ldfrag(1, 1);
     __builtin_amdgcn_sched_barrier(0);
     mma(0);
     __builtin_amdgcn_sched_barrier(0);
-    dma(4, oth); dma(5, oth); dma(6, oth); dma(7, oth);
+#pragma unroll
+    for (int i = NU / 2; i < NU; ++i) dma(i, oth);
     ldfrag(2, 0);
     __builtin_amdgcn_sched_barrier(0);
     mma(1);
@@ -987,12 +996,13 @@ static int g_wide_stores = 0;   // measured (profiles/r01e_kernel_bench_wide.log
 extern "C" int vl_gemm_set_stagger(int units) { g_stagger = (units >= 0 && units <= 64) ? units : 0; return 0; }
 extern "C" int vl_gemm_set_wide_stores(int on) { g_wide_stores = (on >= 0 && on <= 4) ? on : 0; return 0; }   // 2, 3: profiling modes (see store_tile)
 
-template <int EPI>
+template <int EPI, int BN = 256>
 hipError_t launch_persist(const GemmP& p, hipStream_t s) {
-  using S = Smem<256, 256>;
-  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-  auto kern = gemm_nt_persist2_kernel<256, 256, 2, 4, EPI>;
-  constexpr int smem = 2 * S::STAGE + 8 * 4096;      // + one 4 KB epilogue-transpose slab per wave = 160 KB
+  // BN = 256: 2x4 waves of 128x64 (default); BN = 128: 4x2 waves of 64x64 (cfg 6, measured for the round-2 design)
+  using S = Smem<256, BN>;
+  const int tiles = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
+  auto kern = gemm_nt_persist2_kernel<256, BN, (BN == 256 ? 2 : 4), (BN == 256 ? 4 : 2), EPI>;
+  constexpr int smem = 2 * S::STAGE + 8 * 4096;      // + one 4 KB epilogue-transpose slab per wave (160 KB at BN = 256)
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -1005,11 +1015,11 @@ hipError_t launch_persist(const GemmP& p, hipStream_t s) {
   return hipGetLastError();
 }
 
-
 template <int EPI>
 hipError_t dispatch(const GemmP& p, int cfg, hipStream_t s) {
   // cfg bit0: 0 = 256x256 tile (8 waves), 1 = 128x128 tile (4 waves); bit1: 1 = register staging
   if (cfg == 4 || cfg == 5) return launch_persist<EPI>(p, s);       // 4: historical alias
+  if (cfg == 6) return launch_persist<EPI, 128>(p, s);              // 256x128 tiles (experiment)
   if (cfg == 9) return launch_tail<EPI>(p, s);
   switch (cfg & 3) {
     case 0: return launch<256, 256, 2, 4, EPI, true>(p, s);
