@@ -51,16 +51,26 @@ def test_tiny_golden_image_and_text(modality, res_dtype):
     assert float((got - ref).abs().max()) < 5e-3
 
 
+_VITL = {}
+
+
+def _vitl_case():
+    """Seeded ViT-L/14 weights, 3 images and the oracle's features (the CPU forward takes ~1 min: computed once)."""
+    if not _VITL:
+        spec = O.TowerSpec()
+        g = torch.Generator().manual_seed(1234)
+        sd = O.init_tower(spec, g, "image.")
+        image = torch.randn(3, 3, 224, 224, generator=g)
+        _VITL["case"] = (sd, image, O.encode_image(sd, image, spec))
+    return _VITL["case"]
+
+
 @pytest.mark.parametrize("gemm_cfg,res_dtype", [(0, torch.float32), (1, torch.float32), (-1, torch.bfloat16)])
 def test_vitl14_image_tower_vs_oracle(gemm_cfg, res_dtype):
     """Full-size ViT-L/14 (24 x 1024 x 16 heads, 257 tokens), seeded weights from the oracle's own
     initialiser (the 1.2 GB state_dict cannot be a fixture), batch 3: cosine matrix within 1e-3."""
     E = _engine()
-    spec = O.TowerSpec()
-    g = torch.Generator().manual_seed(1234)
-    sd = O.init_tower(spec, g, "image.")
-    image = torch.randn(3, 3, 224, 224, generator=g)
-    ref = O.encode_image(sd, image, spec)
+    sd, image, ref = _vitl_case()
     eng = E.VitEngine(sd, "image.", E.TowerCfg(), "cuda", gemm_cfg=gemm_cfg, res_dtype=res_dtype)
     got = eng.encode_image(image.cuda())
     assert got.shape == (3, 768)
