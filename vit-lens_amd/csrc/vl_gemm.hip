@@ -324,9 +324,10 @@ __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL
 // dGELU, GELU when the pre-activation is also kept) runs after the read-back on the bf16-rounded values, with
 // coalesced 16-byte loads - the same rounding points as the reference's autocast (bf16 linear output, then the add /
 // activation); bias, alpha, the q scale and GELU-without-save are applied in fp32 before packing.
-template <int EPI, int MT>
-__device__ __forceinline__ void store_tile_lds16(const GemmP& p, f32x16 (&acc)[MT][2], int mrow0, int ncol0, int fr, int fg,
+template <int EPI, int MT, int NTL>
+__device__ __forceinline__ void store_tile_lds16(const GemmP& p, f32x16 (&acc)[MT][NTL], int j0, int mrow0, int ncol0, int fr, int fg,
                                                  int lane, unsigned char* wl) {
+  // handles the 64 columns of column blocks j0, j0+1 (ncol0 = first column of block j0)
   const int rsub = lane >> 3, c = lane & 7;
   unsigned char* const wr = wl + fr * 128 + fg * 8;
   const int wsw = (fr >> 1) & 7;
@@ -353,7 +354,7 @@ __device__ __forceinline__ void store_tile_lds16(const GemmP& p, f32x16 (&acc)[M
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = ncol0 + j * 32 + q * 8 + fg * 4;
-        f32x4 v = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+        f32x4 v = {acc[i][j0 + j][q * 4 + 0], acc[i][j0 + j][q * 4 + 1], acc[i][j0 + j][q * 4 + 2], acc[i][j0 + j][q * 4 + 3]};
         v = v * p.alpha;
         if (p.bias && n < p.N) v = v + *(const f32x4*)(p.bias + n);
         if constexpr (EPI == EPI_QKV) {
@@ -445,11 +446,13 @@ __device__ __forceinline__ void store_tile_lds(const GemmP& p, f32x16 (&acc)[MT]
     if (p.wide >= 1 && p.wide != 4) { store_tile<EPI, MT, NTL>(p, acc, mrow0, ncol0, fr, fg); return; }    // A/B + profiling modes
     const bool do_store = p.wide != 4;       // profiling mode 4: transpose + arithmetic, no global stores (results WRONG)
     [[maybe_unused]] bool done16 = false;
-    if constexpr ((EPI == EPI_BF16 || EPI == EPI_RES_BF16 || EPI == EPI_DGELU || EPI == EPI_QKV) && NTL == 2) {
+    if constexpr ((EPI == EPI_BF16 || EPI == EPI_RES_BF16 || EPI == EPI_DGELU || EPI == EPI_QKV) && (NTL & 1) == 0) {
       // bf16 outputs: 16-byte path when rows stay 16-byte aligned (QKV destinations are [.., dh] rows with dh % 8 == 0)
       const bool al = EPI == EPI_QKV ? (p.dh_shift >= 3) : ((p.ldo & 7) == 0);
       if (do_store && p.wide == 0 && (p.N & 7) == 0 && al) {
-        store_tile_lds16<EPI, MT>(p, acc, mrow0, ncol0, fr, fg, lane, wl);
+#pragma unroll
+        for (int j0 = 0; j0 < NTL; j0 += 2)
+          store_tile_lds16<EPI, MT, NTL>(p, acc, j0, mrow0, ncol0 + j0 * 32, fr, fg, lane, wl);
         if constexpr (EPI != EPI_QKV) return;
         done16 = true;
       }
@@ -833,8 +836,9 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MT = WTM / 32, NTL = WTN / 32;
   constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW);
-  static_assert(NW == 8 && AI == 4 && (BI == 4 || BI == 2) && NTL == 2 && (MT == 4 || MT == 2),
-                "schedule written for 8 waves on a 256x256 (2x4 waves) or 256x128 (4x2 waves) tile");
+  static_assert((NW == 8 && AI == 4 && (BI == 4 || BI == 2) && NTL == 2 && (MT == 4 || MT == 2)) ||
+                    (NW == 4 && AI == 8 && BI == 8 && MT == 4 && NTL == 4),
+                "schedule written for 8 waves on a 256x256 (2x4) / 256x128 (4x2) tile, or 4 waves (2x2, one per SIMD) on 256x256");
   constexpr int NU = AI + BI;          // 1 KB LDS-DMA units per wave per k-step
   constexpr int GN = 4;
   using S = Smem<BM, BN>;
@@ -963,7 +967,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
     if (kt + 1 == nk) {
       {
         const GemmP pe = reload_params();
-        store_tile_lds<EPI, MT, NTL>(pe, acc, cur_m0 + wave_m * WTM, cur_n0 + wave_n * WTN, fr, fg, lane, smem + 2 * S::STAGE + wid * 4096);
+        store_tile_lds<EPI, MT, NTL>(pe, acc, cur_m0 + wave_m * WTM, cur_n0 + wave_n * WTN, fr, fg, lane, smem + 2 * S::STAGE + wid * (32768 / NW));
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -996,13 +1000,16 @@ static int g_wide_stores = 0;   // measured (profiles/r01e_kernel_bench_wide.log
 extern "C" int vl_gemm_set_stagger(int units) { g_stagger = (units >= 0 && units <= 64) ? units : 0; return 0; }
 extern "C" int vl_gemm_set_wide_stores(int on) { g_wide_stores = (on >= 0 && on <= 4) ? on : 0; return 0; }   // 2, 3: profiling modes (see store_tile)
 
-template <int EPI, int BN = 256>
+template <int EPI, int BN = 256, int NWAVES = 8>
 hipError_t launch_persist(const GemmP& p, hipStream_t s) {
-  // BN = 256: 2x4 waves of 128x64 (default); BN = 128: 4x2 waves of 64x64 (cfg 6, measured for the round-2 design)
+  // BN = 256, 8 waves: 2x4 waves of 128x64 (default).  BN = 128: 4x2 waves of 64x64 (cfg 6, measured for the round-2
+  // epilogue design).  NWAVES = 4 (128x128 per wave, one wave per SIMD, accumulators in AGPRs) compiles but spills
+  // 100-490 VGPRs in the epilogues as written: not instantiated until its register budget is reworked.
   using S = Smem<256, BN>;
+  constexpr int WM = NWAVES == 4 ? 2 : (BN == 256 ? 2 : 4), WN = NWAVES / WM;
   const int tiles = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
-  auto kern = gemm_nt_persist2_kernel<256, BN, (BN == 256 ? 2 : 4), (BN == 256 ? 4 : 2), EPI>;
-  constexpr int smem = 2 * S::STAGE + 8 * 4096;      // + one 4 KB epilogue-transpose slab per wave (160 KB at BN = 256)
+  auto kern = gemm_nt_persist2_kernel<256, BN, WM, WN, EPI>;
+  constexpr int smem = 2 * S::STAGE + 8 * 4096;      // + 32 KB of epilogue-transpose slabs (160 KB at BN = 256)
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -1011,7 +1018,7 @@ hipError_t launch_persist(const GemmP& p, hipStream_t s) {
   }
   int G = num_cus() & ~7;
   if (tiles < G) G = (tiles + 7) & ~7;
-  hipLaunchKernelGGL(kern, dim3(G), dim3(512), smem, s, p);
+  hipLaunchKernelGGL(kern, dim3(G), dim3(NWAVES * 64), smem, s, p);
   return hipGetLastError();
 }
 
