@@ -93,3 +93,29 @@ def test_tiny_golden_forward_and_loss_through_api(modality):
     assert abs(float(loss) - float(outs["tri_loss"])) < 3e-2
     loss.backward()
     assert all(torch.isfinite(t.grad).all() for t in feats)
+
+
+def test_vitlens_encode_api_at_full_size():
+    """mm_vit_lens.ViTLens.encode (vitlens.py:170-189): {modality: inputs} -> {modality: unit-norm [B,768]} on ViT-L
+    models built by the drop-in factory (seeded random init); image/text through one shared model, depth through its
+    Lens tower; the image features are checked against the oracle on the model's own state_dict, audio clips are
+    averaged as the reference does."""
+    _oc()
+    from mm_vit_lens import ViTLens
+    from open_clip import ModalityType
+    torch.manual_seed(0)
+    vl = ViTLens(modality_loaded=[ModalityType.IMAGE, ModalityType.TEXT, ModalityType.DEPTH], device="cuda")
+    g = torch.Generator().manual_seed(3)
+    image = torch.randn(2, 3, 224, 224, generator=g); depth = torch.randn(2, 1, 224, 224, generator=g)
+    out = vl.encode({ModalityType.IMAGE: image, ModalityType.TEXT: CAPTIONS[:2], ModalityType.DEPTH: depth})
+    for m in (ModalityType.IMAGE, ModalityType.TEXT, ModalityType.DEPTH):
+        assert out[m].shape == (2, 768)
+        assert float((out[m].float().norm(dim=-1) - 1).abs().max()) < 1e-3
+    sd = {k: v.detach().float().cpu() for k, v in vl.vitlens[ModalityType.IMAGE].state_dict().items()}
+    ref = O.encode_image(sd, image, O.TowerSpec(), normalize=True)
+    cs = torch.nn.functional.cosine_similarity(out[ModalityType.IMAGE].float().cpu(), ref, dim=-1)
+    assert float((1 - cs).max()) < 1e-3
+    sdd = {k: v.detach().float().cpu() for k, v in vl.vitlens[ModalityType.DEPTH].state_dict().items()}
+    refd = O.encode_visual(sdd, depth, O.TowerSpec(), O.LensSpec(modality="depth", perceiver_identity=True), normalize=True)
+    cs = torch.nn.functional.cosine_similarity(out[ModalityType.DEPTH].float().cpu(), refd, dim=-1)
+    assert float((1 - cs).max()) < 1e-3
