@@ -219,7 +219,8 @@ class VisionTransformer(nn.Module):
                 audio_target_length=_g(a, "audio_target_length", 512), pc_num_group=_g(a, "pc_num_group", 512),
                 pc_group_size=_g(a, "pc_group_size", 32), pc_encoder_dims=_g(a, "pc_encoder_dims", 256),
                 pc_trans_dim=_g(a, "pc_trans_dim", 384), use_orig_pos=not _g(a, "disable_orig_pos", False),
-                disable_adapter_pos=bool(_g(a, "disable_visual_adapter_pos", False)))
+                disable_adapter_pos=bool(_g(a, "disable_visual_adapter_pos", False)),
+                weight_tie_layers=bool(_g(a, "perceiver_weight_tie_layers", False)))
         return tower, lens
 
     def engine(self):

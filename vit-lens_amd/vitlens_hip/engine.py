@@ -206,6 +206,8 @@ class LensCfg:
     pc_trans_dim: int = 384
     use_orig_pos: bool = True
     disable_adapter_pos: bool = False
+    weight_tie_layers: bool = False    # perceiver.py:249-254: layers >= 1 share one set of modules (forward works from the
+                                       # duplicated state_dict keys; TRAINING a tied Lens is refused, see step.py)
 
 
 def _interleave_geglu(w: torch.Tensor, b: torch.Tensor):

@@ -240,6 +240,9 @@ class _PerceiverLensStep:
 
     def _collect_perceiver(self, sd):
         pe, P = self.lens.perceiver, "visual.perceiver."
+        if getattr(self.lens.lens, "weight_tie_layers", False) and len(pe.layers) > 1:
+            # tied layers share parameters (perceiver.py:249-254): their gradients would have to be summed into one master
+            raise NotImplementedError("training a Perceiver with perceiver_weight_tie_layers=True is not implemented")
         f32 = lambda k: sd[k].detach().float().to(self.dev).contiguous()
         self.masters[P + "latents"] = pe.latents
         for li, lay in enumerate(pe.layers):
