@@ -1,0 +1,45 @@
+"""CPU: host-side pieces of bench.py that do not need a GPU - synthetic inputs have the documented shape/semantics
+(SURVEY 8d), the seeded weights carry the reference's parameter names, and the traffic summary is wired."""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_synthetic_text_has_eot_at_argmax():
+    import bench
+    g = torch.Generator().manual_seed(0)
+    t = bench.synth_text(16, g)
+    assert t.shape == (16, 77) and t.dtype == torch.long
+    assert bool((t[:, 0] == 49406).all())                       # SOT
+    eot = t.argmax(dim=-1)                                        # encode_text pools at argmax (model.py:538)
+    assert bool((t[torch.arange(16), eot] == 49407).all())
+    assert bool(((eot >= 5) & (eot <= 21)).all())
+    for i in range(16):
+        assert bool((t[i, eot[i] + 1:] == 0).all())             # zero padding after EOT
+
+
+def test_seeded_weights_have_reference_names_and_shapes():
+    import bench
+    sd = bench.seeded_tri_weights()
+    for k, shape in (("image.conv1.weight", (1024, 3, 14, 14)), ("image.positional_embedding", (257, 1024)),
+                     ("image.proj", (1024, 768)), ("visual.visual_adapter.conv1.weight", (1024, 1, 14, 14)),
+                     ("visual.visual_adapter.pos_emb", (256, 1024)), ("token_embedding.weight", (49408, 768)),
+                     ("text_projection", (768, 768)), ("transformer.resblocks.11.mlp.c_fc.weight", (3072, 768)),
+                     ("visual.transformer.resblocks.23.attn.in_proj_weight", (3072, 1024)), ("logit_scale", ())):
+        assert tuple(sd[k].shape) == shape, k
+    assert "visual.conv1.weight" not in sd                       # the Lens tower has no RGB patch embedding of its own
+
+
+def test_committed_hbm_traffic_summary_matches_the_dominant_gemm():
+    import bench
+    t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    assert t["shape"] == [65792, 4096, 1024] and "persist2" in t["kernel"]
+    got = bench.hbm_traffic({"M": 65792, "N": 4096, "K": 1024})
+    algorithmic = 2 * (65792 * 1024 + 4096 * 1024 + 65792 * 4096)
+    assert got is not None and algorithmic <= got <= 3 * algorithmic
+    assert bench.hbm_traffic({"M": 1, "N": 2, "K": 3}) is None
