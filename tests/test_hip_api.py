@@ -119,3 +119,18 @@ def test_vitlens_encode_api_at_full_size():
     refd = O.encode_visual(sdd, depth, O.TowerSpec(), O.LensSpec(modality="depth", perceiver_identity=True), normalize=True)
     cs = torch.nn.functional.cosine_similarity(out[ModalityType.DEPTH].float().cpu(), refd, dim=-1)
     assert float((1 - cs).max()) < 1e-3
+
+
+def test_zero_shot_logits_and_accuracy_on_gpu():
+    """Scoring step of zero-shot evaluation: logit_scale * features @ classifier on the HIP GEMM (hi/lo bf16 split) vs
+    fp32 torch, with a class count that is not a multiple of 4, and top-k counting on the result."""
+    oc = _oc()
+    g = torch.Generator().manual_seed(9)
+    feats = torch.nn.functional.normalize(torch.randn(37, 768, generator=g), dim=-1)
+    w = torch.nn.functional.normalize(torch.randn(10, 768, generator=g), dim=-1).t().contiguous()       # [E, C=10]
+    got = oc.zero_shot_logits(feats.cuda(), w.cuda(), logit_scale=100.0)
+    ref = 100.0 * feats @ w
+    assert got.shape == (37, 10)
+    assert float((got.cpu() - ref).abs().max()) < 2e-3
+    tgt = ref.argmax(dim=1)
+    assert oc.accuracy(got.cpu(), tgt, topk=(1, 5)) == [37.0, 37.0]
