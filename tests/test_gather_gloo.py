@@ -110,3 +110,44 @@ def test_step_communicator_on_gloo():
     mp.spawn(_comm_worker, args=(2, 29727, ret), nprocs=2, join=True)
     for r in range(2):
         assert ret[r] == [], (r, ret[r])
+
+
+def _utils_worker(rank, world, port, ret):
+    sys.path.insert(0, os.path.join(ROOT, "vit-lens_amd"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from open_clip import utils as U
+    errs = []
+    a = torch.full((3,), float(rank + 1)); b = torch.full((2, 2), 10.0 * (rank + 1))
+    U.scaled_all_reduce([a, b])
+    tot = sum(range(1, world + 1)) / world
+    if not (torch.allclose(a, torch.full((3,), tot)) and torch.allclose(b, torch.full((2, 2), 10.0 * tot))):
+        errs.append("scaled_all_reduce")
+    c = torch.full((2,), float(rank + 1)); U.scaled_all_reduce([c], is_scale=False)
+    if not torch.allclose(c, torch.full((2,), float(sum(range(1, world + 1))))):
+        errs.append("all_reduce unscaled")
+    g = U.concat_all_gather(torch.full((2, 3), float(rank)))
+    if g.shape != (2 * world, 3) or not all(bool((g[2 * r:2 * r + 2] == r).all()) for r in range(world)):
+        errs.append("concat_all_gather")
+    q = torch.full((rank + 1, 2), float(rank))                     # ragged first dimension
+    allq = U.all_gather(q)
+    exp = torch.cat([torch.full((r + 1, 2), float(r)) for r in range(world)])
+    if not torch.equal(allq, exp):
+        errs.append("all_gather ragged")
+    others = U.all_gather(q, exclude_self=True)
+    exp = torch.cat([torch.full((r + 1, 2), float(r)) for r in range(world) if r != rank])
+    if not torch.equal(others, exp):
+        errs.append("all_gather exclude_self")
+    if U.get_world_size() != world or U.get_rank() != rank or U.is_main_process() != (rank == 0):
+        errs.append("rank helpers")
+    ret[rank] = errs
+    dist.destroy_process_group()
+
+
+def test_eval_collectives_on_gloo():
+    """scaled_all_reduce / concat_all_gather / ragged all_gather of the evaluation path (utils.py:134-175, 295-330)."""
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_utils_worker, args=(3, 29729, ret), nprocs=3, join=True)
+    for r in range(3):
+        assert ret[r] == [], (r, ret[r])
