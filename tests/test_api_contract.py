@@ -28,7 +28,11 @@ with tempfile.TemporaryDirectory() as td:
         model.lock_visual_tower(unlock_trans_first_n_layers=1, unlock_cls=(m == "audio"))
         out[m] = {"keys": {k: list(v.shape) for k, v in model.state_dict().items()},
                   "trainable": sorted(n for n, p in model.named_parameters() if p.requires_grad),
+                  "trainable_groups": {},
                   "args": {k: v for k, v in G.tiny_args(m).items() if isinstance(v, (int, float, str, bool, type(None)))}}
+        for k in (1, 2, 3):       # grouped (LiT) unlock from the tail, + positional embedding
+            model.lock_visual_tower(unlocked_groups=k, unlock_pos_emb=True)
+            out[m]["trainable_groups"][str(k)] = sorted(n for n, p in model.named_parameters() if p.requires_grad and n.startswith("visual."))
 print("JSON" + json.dumps(out))
 '''
 
@@ -60,6 +64,10 @@ def test_state_dict_and_lock_recipes_match_reference():
             model.lock_visual_tower(unlock_trans_first_n_layers=1, unlock_cls=(m == "audio"))
             tr = sorted(n for n, p in model.named_parameters() if p.requires_grad)
             assert tr == ref[m]["trainable"], (m, set(tr) ^ set(ref[m]["trainable"]))
+            for k in (1, 2, 3):
+                model.lock_visual_tower(unlocked_groups=k, unlock_pos_emb=True)
+                tr = sorted(n for n, p in model.named_parameters() if p.requires_grad and n.startswith("visual."))
+                assert tr == ref[m]["trainable_groups"][str(k)], (m, k, set(tr) ^ set(ref[m]["trainable_groups"][str(k)]))
 
 
 def test_public_surface():

@@ -179,11 +179,23 @@ class VisionTransformer(nn.Module):
     def lock(self, unlocked_groups=0, freeze_bn_stats=False, unlock_cls=False, unlock_pos_emb=False,
              unlock_trans_first_n_layers=None):
         """VisionTransformer.lock, open_clip/transformer.py:553-627."""
-        if unlocked_groups != 0:
-            raise NotImplementedError("unlocked_groups != 0 is not used by the hot-path recipes")
         for p in self.parameters():
             p.requires_grad = False
         on = []
+        if unlocked_groups != 0:
+            # LiT-style grouped unlock (transformer.py:565-597): [stem] + one group per block but the last +
+            # [last block, ln_post] + [proj]; the first k groups with exp_args.unlock_from_head, else the last k.
+            # (requires_grad bookkeeping only: the fused HIP trainers implement the recipes of SURVEY 8-a15 - adapter,
+            # Perceiver, cls/pos, first-n blocks - and do not produce ln_pre / ln_post / proj gradients yet.)
+            L = self.cfg.layers
+            stem = ("conv1.", "class_embedding", "positional_embedding", "ln_pre.")
+            groups = [stem] + [(f"transformer.resblocks.{i}.",) for i in range(L - 1)]
+            groups += [(f"transformer.resblocks.{L - 1}.", "ln_post."), ("proj",)]
+            picked = groups[:unlocked_groups] if _g(self.cfg.exp_args, "unlock_from_head", False) else groups[-unlocked_groups:]
+            prefixes = tuple(x for grp in picked for x in grp)
+            for n, p in self.named_parameters():
+                if n.startswith(prefixes):
+                    on.append(p)
         for n, p in self.named_parameters():
             if n.startswith("perceiver.") or n.startswith("visual_adapter."):
                 on.append(p)
