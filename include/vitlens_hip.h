@@ -12,8 +12,9 @@
  *   - all matrices are row-major; "bf16" is a 16-bit brain-float bit pattern (uint16_t)
  *   - every function is stream-ordered and non-blocking on `stream` (a hipStream_t)
  *   - return value: 0 on success, non-zero on failure; vl_last_error() gives the message
- *   - no exceptions cross the ABI; no global mutable state except the last-error string, the one-time
- *     hipFuncSetAttribute flags and the two tuning switches vl_gemm_set_stagger / vl_gemm_set_wide_stores
+ *   - no exceptions cross the ABI; no global mutable state except the thread-local last-error string; one-time
+ *     initialisation (hipFuncSetAttribute, CU count) is done through C++11 function-local statics (thread-safe);
+ *     entry points are re-entrant per stream
  */
 #ifndef VITLENS_HIP_H
 #define VITLENS_HIP_H
@@ -50,7 +51,10 @@ int vl_version(void);
 /* C[M,N] = A[M,K] · W[N,K]^T with fused epilogue.  A, W bf16.  K % 64 == 0, N % 4 == 0.
  * cfg: -1 auto (persistent 256x256 kernel on the whole rounds of row tiles + tail kernel on the leftover rows;
  *      128x128 tiles for small problems) | 0: 256x256 tile LDS-DMA | 1: 128x128 LDS-DMA | 2/3: same, register
- *      staging | 5 (4 = alias): persistent kernel | 6: the same on 256x128 tiles (experiment) | 9: tail kernel.
+ *      staging | 5 (4 = alias): round-1 persistent kernel | 6: the same on 256x128 tiles | 8: round-2 persistent kernel
+ *      (vl_gemm_park.hip: staggered LDS-DMA issue, barrier in front of the last k-substep, burst of non-temporal stores;
+ *      bf16-output epilogues, M % 256 == N % 256 == 0, K >= 512; what "auto" uses for the whole rounds of row tiles when
+ *      it applies) | 9: tail kernel.
  * Replaces nn.Linear / out_proj / mlp.c_fc(+GELU) / mlp.c_proj(+residual)
  * (open_clip/transformer.py:226-234,268-271), Perceiver to_q/to_kv/to_out/FeedForward
  * (open_clip/perceiver.py:85-123), pooled @ proj (transformer.py:786-787) and
@@ -74,10 +78,6 @@ int vl_gemm_qkv_bf16(const void* A, const void* Win, const float* bias, void* q,
  * Autograd counterpart of the dW of nn.Linear / 1x1 Conv1d in the trainable Lens. */
 int vl_gemm_splitk_accum_f32(const void* A, const void* W, float* out, int M, int N, int K, int lda, int ldw, long ldo,
                              float alpha, int splits, float* ws, hipStream_t stream);
-/* Phase offset of the persistent GEMM kernel: workgroup phase (slot & 3) starts phase*units sleep units (~1 us each)
- * late so that the HBM-bound epilogues of the phase groups do not coincide.  0 = off. */
-int vl_gemm_set_stagger(int units);
-int vl_gemm_set_wide_stores(int on);   /* 16-byte epilogue stores (default on); off = 8-byte stores, for A/B runs */
 /* vl_gemm_bf16 + `out2` (with VL_EPI_BF16/VL_ACT_GELU also stores the pre-activation, bf16, for the
  * backward) + `res_div` (VL_EPI_RES_BF16: residual row = m / res_div, i.e. one row broadcast over a group:
  * the PointNet concat([global, local]) conv of dvae.py:207-210 split into two GEMMs). */

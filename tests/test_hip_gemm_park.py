@@ -1,0 +1,131 @@
+"""GPU parity of the persistent GEMMs with the store-hidden ("parked") epilogue (vl_gemm_park.hip: cfg=8 eight waves - what
+cfg=-1 uses for whole rounds of tiles -, cfg=pcfg four waves) against fp32 PyTorch on
+the same bf16 operands, and against the 8-wave kernel (cfg=5).  Every case has several tiles per workgroup or per wave
+position so the tile hand-over (DMA prefetch across the tile boundary, epilogue operands, store burst) is exercised."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=[8])
+def pcfg(request):
+    return request.param
+
+
+def _ops():
+    from vitlens_hip import ops
+    return ops
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def relerr(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_p4_identity_is_bit_exact(pcfg):
+    """A = [I; 2I; ...] (K = 512): C rows are W^T scaled by powers of two -> exact in bf16; catches any row/column/chunk mix-up
+    of the LDS transpose and of the parked-store addressing."""
+    ops = _ops()
+    K, N, reps = 512, 768, 6
+    eye = torch.eye(K)
+    a = torch.cat([eye * (2.0 ** r) for r in range(reps)], 0).bfloat16().cuda()              # [3072, 512]
+    w = ((torch.arange(N * K).reshape(N, K) * 7 % 251) - 125).float().bfloat16().cuda()
+    out = ops.gemm(a, w, None, epi=ops.EPI_BF16, cfg=pcfg)
+    ref = torch.cat([w.float().cpu().t() * (2.0 ** r) for r in range(reps)], 0)
+    assert torch.equal(out.float().cpu(), ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(256 * 40, 4096, 512), (256 * 3, 512, 512), (256 * 257, 256, 768), (2048, 4096, 576)])
+def test_p4_bf16_epilogues(M, N, K, pcfg):
+    ops = _ops()
+    a = rnd(M, K, seed=1).bfloat16().cuda(); w = rnd(N, K, seed=2, scale=K ** -0.5).bfloat16().cuda()
+    bias = rnd(N, seed=3).cuda()
+    acc = a.float() @ w.float().t() + bias
+    # plain, GELU, ReLU, no bias
+    assert relerr(ops.gemm(a, w, bias, epi=ops.EPI_BF16, cfg=pcfg), acc) < 4e-3
+    assert relerr(ops.gemm(a, w, None, epi=ops.EPI_BF16, cfg=pcfg, alpha=0.5), 0.5 * (acc - bias)) < 4e-3
+    out = ops.gemm(a, w, bias, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=pcfg)
+    ref = torch.nn.functional.gelu(acc)
+    assert relerr(out, ref) < 4e-3 and bool(((out.float() - ref).abs() <= ref.abs() * 2.0 ** -7 + 2e-3).all())
+    assert relerr(ops.gemm(a, w, bias, epi=ops.EPI_BF16, act=ops.ACT_RELU, cfg=pcfg), torch.relu(acc)) < 4e-3
+    # GELU with the saved pre-activation (training forward)
+    u = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    out = ops.gemm(a, w, bias, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=pcfg, out2=u)
+    assert relerr(u, acc) < 4e-3 and relerr(out, torch.nn.functional.gelu(u.float())) < 4e-3
+    # same results as the 8-wave kernel up to the bf16 rounding point of the GELU (fp32 vs bf16-rounded pre-activation)
+    old = ops.gemm(a, w, bias, epi=ops.EPI_BF16, cfg=5)
+    assert torch.equal(old, ops.gemm(a, w, bias, epi=ops.EPI_BF16, cfg=pcfg))
+
+
+@pytest.mark.parametrize("M,N,K", [(256 * 40, 1024, 1024), (256 * 5, 768, 3072), (256 * 257, 256, 512)])
+def test_p4_residual_and_dgelu(M, N, K, pcfg):
+    ops = _ops()
+    a = rnd(M, K, seed=4).bfloat16().cuda(); w = rnd(N, K, seed=5, scale=K ** -0.5).bfloat16().cuda()
+    bias = rnd(N, seed=6).cuda()
+    acc = a.float() @ w.float().t()
+    # bf16 residual, out of place and in place (x += ...), bit-identical to the 8-wave kernel
+    res = rnd(M, N, seed=7).bfloat16().cuda()
+    o1 = ops.gemm(a, w, bias, res=res, epi=ops.EPI_RES_BF16, cfg=pcfg)
+    assert relerr(o1, res.float() + acc + bias) < 4e-3
+    assert torch.equal(o1, ops.gemm(a, w, bias, res=res, epi=ops.EPI_RES_BF16, cfg=5))
+    x = res.clone()
+    ops.gemm(a, w, bias, out=x, res=x, epi=ops.EPI_RES_BF16, cfg=pcfg)
+    assert torch.equal(x, o1)
+    # dX through GELU
+    u = rnd(M, N, seed=9, scale=1.5).bfloat16().cuda()
+    out = ops.gemm(a, w, None, res=u, epi=ops.EPI_DGELU, cfg=pcfg, out=torch.empty(M, N, device="cuda", dtype=torch.bfloat16))
+    uf = u.float().requires_grad_(True)
+    torch.nn.functional.gelu(uf).sum().backward()
+    assert relerr(out, acc * uf.grad) < 4e-3
+    assert torch.equal(out, ops.gemm(a, w, None, res=u, epi=ops.EPI_DGELU, cfg=5, out=torch.empty_like(out)))
+
+
+@pytest.mark.parametrize("B,L,H,dh,extra", [(256, 257, 16, 64, True), (256, 257, 16, 64, False), (40, 64, 12, 64, True), (512, 77, 12, 64, False)])
+def test_p4_qkv_scatter_matches_8wave_kernel(B, L, H, dh, extra, pcfg):
+    """QKV head scatter (q pre-scaled, k, v^T, and the backward's q^T, k^T, v): rows that are whole 256-row tiles go through
+    p4 (cfg=-1 splits, cfg=pcfg needs B*L % 256 == 0), outputs must equal the 8-wave kernel's bit for bit."""
+    ops = _ops()
+    D = H * dh
+    M = B * L
+    x = rnd(M, D, seed=11).bfloat16().cuda(); w = rnd(3 * D, D, seed=12, scale=D ** -0.5).bfloat16().cuda()
+    bias = rnd(3 * D, seed=13).cuda()
+    Lp = (L + 7) // 8 * 8
+
+    def run(cfg):
+        q = torch.full((B, H, L, dh), float("nan"), device="cuda", dtype=torch.bfloat16); k = q.clone(); v = q.clone()
+        vt = torch.zeros(B, H, dh, Lp, device="cuda", dtype=torch.bfloat16); qt = vt.clone(); kt = vt.clone()
+        if extra:
+            ops.gemm_qkv(x, w, bias, q, k, vt, B, L, H, dh, cfg=cfg, qt=qt, kt=kt, v=v)
+        else:
+            ops.gemm_qkv(x, w, bias, q, k, vt, B, L, H, dh, cfg=cfg)
+        return (q, k, vt) + ((qt, kt, v) if extra else ())
+    cfg_new = pcfg if M % 256 == 0 else -1
+    new, old = run(cfg_new), run(5)
+    for a_, b_ in zip(new, old):
+        assert torch.equal(a_, b_)
+    # and against fp32 math
+    y = x.float() @ w.float().t() + bias
+    qref = (y[:, :D] * (dh ** -0.5 * 1.4426950408889634)).view(B, L, H, dh).permute(0, 2, 1, 3)
+    assert relerr(new[0], qref) < 4e-3
+    vref = y[:, 2 * D:].view(B, L, H, dh).permute(0, 2, 3, 1)
+    assert relerr(new[2][..., :L], vref) < 4e-3
+
+
+def test_p4_is_what_auto_dispatch_uses_at_bench_geometry():
+    """cfg=-1 at M = 257*256: whole rounds on p4 + tail kernel; every row must be written (NaN-poisoned outputs)."""
+    ops = _ops()
+    M, N, K = 257 * 256, 1024, 1024
+    a = rnd(M, K, seed=21).bfloat16().cuda(); w = rnd(N, K, seed=22, scale=K ** -0.5).bfloat16().cuda()
+    bias = rnd(N, seed=23).cuda()
+    res = rnd(M, N, seed=24).bfloat16().cuda()
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ops.gemm(a, w, bias, out=out, res=res, epi=ops.EPI_RES_BF16, cfg=-1)
+    ref = res.float() + a.float() @ w.float().t() + bias
+    assert bool(torch.isfinite(out).all()) and relerr(out, ref) < 4e-3
+    assert relerr(out[-600:], ref[-600:]) < 4e-3 and relerr(out[:256], ref[:256]) < 4e-3

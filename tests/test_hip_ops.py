@@ -104,23 +104,6 @@ def test_gemm_epilogues(cfg):
     assert out.shape == (M, N // 2) and relerr(out, ref) < 4e-3
 
 
-@pytest.mark.parametrize("cfg", [0, 5])
-def test_gemm_wide_store_option_bit_identical(cfg):
-    """vl_gemm_set_wide_stores(1) switches the bf16 epilogues to the lane-exchange 16-byte stores; the values
-    written must be bit-identical to the default 8-byte path (the option is off by default: measured slower)."""
-    ops = _ops()
-    M, N, K = 777, 512, 128
-    a = rnd(M, K, seed=14).bfloat16().cuda(); w = rnd(N, K, seed=15, scale=0.1).bfloat16().cuda()
-    bias = rnd(N, seed=16).cuda()
-    base = ops.gemm(a, w, bias, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg)
-    try:
-        ops.set_wide_stores(True)
-        wide = ops.gemm(a, w, bias, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg)
-    finally:
-        ops.set_wide_stores(False)
-    assert torch.equal(base, wide)
-
-
 def test_gelu_erf_accuracy():
     """The A&S erf used in the epilogue: |gelu_hip - gelu_exact| <= 1e-6 before bf16 rounding; checked
     through the f32 path by feeding x through an identity GEMM is not possible (GELU is bf16-out only),

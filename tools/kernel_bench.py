@@ -30,26 +30,37 @@ def main():
     T = 257 * 256
     shapes = [("qkv", T, 3072, 1024), ("out", T, 1024, 1024), ("fc", T, 4096, 1024), ("proj", T, 1024, 4096),
               ("sq8k", 8192, 8192, 8192)]
+    cfgs = [int(c) for c in os.environ.get("KB_CFGS", "5,8").split(",")]
     for name, M, N, K in shapes:
         a = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
         bias = torch.randn(N, device="cuda")
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-        resf = torch.randn(M, N, device="cuda")
-        for cfg in (5, -1):
-            for epi, act, label in ((ops.EPI_BF16, 0, "bf16"), (ops.EPI_BF16, 1, "bf16+gelu"), (ops.EPI_RES_F32, 0, "res_f32")):
-                if quick and (label == "bf16+gelu" and name not in ("fc",)):
-                    continue
-                if quick and name.startswith("sq") and label != "bf16":
-                    continue
-                if label == "res_f32":
-                    fn = lambda: ops.gemm(a, w, bias, out=resf, res=resf, epi=epi, cfg=cfg)
-                else:
-                    fn = lambda: ops.gemm(a, w, bias, out=out, epi=epi, act=act, cfg=cfg)
-                med, mn = timeit(fn)
-                tf = 2.0 * M * N * K / (med * 1e-3) / 1e12
-                res["gemm"].append({"shape": name, "M": M, "N": N, "K": K, "cfg": cfg, "epi": label, "ms": med, "min_ms": mn, "tflops": tf})
-                print(f"gemm {name:5s} cfg{cfg} {label:10s} {med:8.3f} ms  {tf:7.1f} TF/s", flush=True)
-        del a, w, out, resf
+        resb = torch.randn(M, N, device="cuda").bfloat16()
+        u2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+
+        def variant(label, cfg, av, ov, rv, uv):
+            if label == "bf16":
+                return lambda: ops.gemm(av, w, bias, out=ov, epi=ops.EPI_BF16, cfg=cfg)
+            if label == "bf16+gelu":
+                return lambda: ops.gemm(av, w, bias, out=ov, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg)
+            if label == "gelu+save":
+                return lambda: ops.gemm(av, w, bias, out=ov, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg, out2=uv)
+            if label == "res_bf16":
+                return lambda: ops.gemm(av, w, bias, out=rv, res=rv, epi=ops.EPI_RES_BF16, cfg=cfg)
+            return lambda: ops.gemm(av, w, None, out=ov, res=rv, epi=ops.EPI_DGELU, cfg=cfg)
+
+        for label in ("bf16", "bf16+gelu", "gelu+save", "res_bf16", "dgelu"):
+            if quick and label in ("bf16+gelu", "gelu+save", "dgelu") and name not in ("fc",):
+                continue
+            if quick and name.startswith("sq") and label != "bf16":
+                continue
+            for cfg in cfgs:
+                Mq = M // 256 * 256 if cfg == 8 else M       # the 4-wave kernel takes whole tiles (auto dispatch adds the tail kernel)
+                med, mn = timeit(variant(label, cfg, a[:Mq], out[:Mq], resb[:Mq], u2[:Mq]))
+                tf = 2.0 * Mq * N * K / (med * 1e-3) / 1e12
+                res["gemm"].append({"shape": name, "M": Mq, "N": N, "K": K, "cfg": cfg, "epi": label, "ms": med, "min_ms": mn, "tflops": tf})
+                print(f"gemm {name:5s} cfg{cfg:2d} {label:10s} M={Mq} {med:8.3f} ms  {tf:7.1f} TF/s", flush=True)
+        del a, w, out, resb, u2
     # qkv + attention at the bench shape
     B, L, H, dh = 256, 257, 16, 64
     D = H * dh

@@ -12,202 +12,22 @@
 //   * staging is either LDS-DMA (global_load_lds_dwordx4, swizzle applied on the per-lane SOURCE
 //     address, LDS image lane-linear) or plain register staging; selected by template flag.
 //   * XCD-aware bijective block remap keeps consecutive N-tiles of one M-tile on one XCD's L2.
-#include "vl_common.h"
-#include "vitlens_hip.h"
+#include "vl_gemm_common.h"
 
 namespace {
 
-enum Epi : int {
-  EPI_BF16 = 0,   // out bf16 = act(acc*alpha + bias)
-  EPI_F32 = 1,    // out f32  = acc*alpha + bias
-  EPI_RES_F32 = 2,   // out f32  = res f32 + acc + bias      (in-place allowed)
-  EPI_RES_BF16 = 3,  // out bf16 = res bf16 + acc + bias
-  EPI_QKV = 4,    // scatter to q[B,H,L,dh], k[B,H,L,dh], vt[B,H,dh,Lp]
-  EPI_GEGLU = 5,  // rows interleaved (a_j, gate_j): out bf16[M, N/2] = a * gelu(gate)
-  EPI_DGELU = 6,  // out bf16 = acc * gelu'(aux[m,n])   (backward through GELU fused into the dX GEMM)
-  EPI_DGEGLU = 7, // acc = dy[M,N]; res = h[M,2N] interleaved (a,g): out[M,2N] = (dy*gelu(g), dy*a*gelu'(g)) interleaved
-};
-
-struct GemmP {
-  const bf16_t* A;   // [M, K]
-  const bf16_t* W;   // [N, K]
-  const float* bias; // [N] or null
-  void* out;
-  const void* res;   // residual (EPI_RES_*) or pre-activation u (EPI_DGELU), same shape/stride as out
-  void* out2;        // EPI_BF16 + act: optional copy of the PRE-activation values (saved for backward)
-  int M, N, K;
-  int lda, ldw, ldo; // row strides in elements
-  float alpha;
-  int act;           // 0 none, 1 gelu(erf), 2 relu
-  int res_div;       // residual row = m / res_div (>=1): broadcast one row over a group of res_div rows
-  int wide;          // 1: 16-byte epilogue stores via half-wave exchange (bf16 row outputs)
-  // QKV scatter
-  bf16_t *q, *k, *vt;
-  bf16_t *qt, *kt, *v;   // optional extra layouts for the attention backward (transposed q/k, row-major v)
-  int L, H, dh, Lp, dh_shift;
-  int which0;        // first part produced by this GEMM: 0 = q, 1 = k, 2 = v
-  float qscale;
-  int m_off;         // absolute row of local row 0 (QKV scatter of a row-split launch)
-  // split-K (gemm_nt_kernel only): blockIdx.y owns k-slabs [y*ksplit_len, (y+1)*ksplit_len) and writes its
-  // partial product to out + y*split_stride (f32 elements); ksplit_len == 0 -> whole K, no offset
-  int ksplit_len;
-  long split_stride;
-  // persistent kernel: workgroups of phase (slot & 3) start phase*stagger sleep units (~1 us each) late, so that the
-  // epilogues of the four phase groups - HBM-bound write/read bursts during which the matrix pipes idle - do not
-  // coincide
-  int stagger;
-};
-
-template <int BM, int BN>
-struct Smem {
-  static constexpr int A_BYTES = BM * 128;
-  static constexpr int B_BYTES = BN * 128;
-  static constexpr int STAGE = A_BYTES + B_BYTES;
-};
-
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  // bijective "each XCD owns a contiguous chunk" remap (dispatch puts block b on XCD b % 8)
-  const int q = nwg >> 3, r = nwg & 7;
-  const int xcd = bid & 7, idx = bid >> 3;
-  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + idx;
-}
-
-// The epilogue parameters (pointers, strides, scatter geometry) are re-read from the kernarg segment through an
-// opaque pointer at the moment a tile is stored.  Without this the compiler keeps ~40 scalars live across
-// the whole k-loop and spills SGPRs to scratch INSIDE it (measured: QKV-scatter GEMM 0.60 -> 2.49 ms).
-typedef const __attribute__((address_space(4))) GemmP* KernargP;
-__device__ __forceinline__ GemmP reload_params() {
-  GemmP r;
-#if defined(__HIP_DEVICE_COMPILE__)
-  KernargP kp = (KernargP)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(kp));
-  __builtin_memcpy(&r, (const void*)kp, sizeof(GemmP));
-#endif
-  return r;
-}
-
 // ---- epilogue: lane owns row m = mrow0 + 32*i + fr, columns n = ncol0 + 32*j + 8*q + 4*fg + {0..3} ----
-// lower half-wave <-> upper half-wave exchange of two packed dword pairs (column groups q, q+1):
-// afterwards lanes 0-31 own 16 contiguous bytes of group q and lanes 32-63 16 contiguous bytes of group q+1
-__device__ __forceinline__ u32x4 pair_swap(u32x2 a, u32x2 b) {
-  const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
-  const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
-  u32x4 o = {(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
-  return o;
-}
-
-// 16-byte-store epilogue for the bf16 row-major outputs (EPI_BF16 incl. GELU/ReLU + pre-activation copy,
-// EPI_DGELU, and the q / k / v row layouts of EPI_QKV).  Halves the number of store instructions of the
-// narrow path; the tile epilogue is store-ISSUE bound (each instruction touches 32 rows).
-template <int EPI, int MT, int NTL>
-__device__ __forceinline__ void store_tile_wide(const GemmP& p, f32x16 (&acc)[MT][NTL], int mrow0, int ncol0, int fr, int fg) {
-  [[maybe_unused]] bf16_t* const pq = p.q; [[maybe_unused]] bf16_t* const pk = p.k; [[maybe_unused]] bf16_t* const pv = p.v;
-  [[maybe_unused]] bf16_t* const pqt = p.qt; [[maybe_unused]] bf16_t* const pkt = p.kt; [[maybe_unused]] bf16_t* const pvt = p.vt;
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = mrow0 + i * 32 + fr;
-    const bool row_ok = m < p.M;
-    [[maybe_unused]] int qb = 0, ql = 0, vz = 0;
-    if constexpr (EPI == EPI_QKV) {
-      const int ma = (row_ok ? m : p.M - 1) + p.m_off; qb = ma / p.L; ql = ma - qb * p.L;
-      asm volatile("" : "+v"(vz));
-    }
-#pragma unroll
-    for (int j = 0; j < NTL; ++j) {
-#pragma unroll
-      for (int qp = 0; qp < 2; ++qp) {
-        const int nbase = ncol0 + j * 32 + qp * 16;             // 16 columns handled by this lane pair
-        if (nbase >= p.N) continue;                              // wave-uniform (N % 16 == 0 on this path)
-        u32x2 pk2[2], pre2[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int q = qp * 2 + h;
-          const int n = nbase + h * 8 + fg * 4;
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e] * p.alpha;
-          if (p.bias) {
-            const f32x4 bv = *(const f32x4*)(p.bias + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += bv[e];
-          }
-          if constexpr (EPI == EPI_BF16) {
-            pre2[h][0] = pack2bf(v[0], v[1]); pre2[h][1] = pack2bf(v[2], v[3]);
-            if (p.act == 1) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-            } else if (p.act == 2) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-          } else if constexpr (EPI == EPI_DGELU) {
-            const int mm = row_ok ? m : p.M - 1;
-            const u32x2 r = *(const u32x2*)((const bf16_t*)p.res + (size_t)mm * p.ldo + n);
-            v[0] *= gelu_erf_grad(bf2f((bf16_t)(r[0] & 0xffff))); v[1] *= gelu_erf_grad(bf2f((bf16_t)(r[0] >> 16)));
-            v[2] *= gelu_erf_grad(bf2f((bf16_t)(r[1] & 0xffff))); v[3] *= gelu_erf_grad(bf2f((bf16_t)(r[1] >> 16)));
-          } else if constexpr (EPI == EPI_QKV) {
-            const int D = p.H << p.dh_shift;
-            const int nv = n + vz;
-            const int wq = (nv >= D) + (nv >= 2 * D);
-            if (wq + p.which0 == 0) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] *= p.qscale;
-            }
-            // transposed copies keep the narrow 2-byte column stores
-            const int c = nv - wq * D, which = wq + p.which0;
-            const int hh = c >> p.dh_shift, dd = c & ((1 << p.dh_shift) - 1);
-            bf16_t* colp = which == 0 ? pqt : (which == 1 ? pkt : pvt);
-            if (colp && row_ok) {
-              const size_t col_off = ((((size_t)qb * p.H + hh) << p.dh_shift) + dd) * p.Lp + ql;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) colp[col_off + (size_t)e * p.Lp] = f2bf(v[e]);
-            }
-          }
-          pk2[h][0] = pack2bf(v[0], v[1]); pk2[h][1] = pack2bf(v[2], v[3]);
-        }
-        const u32x4 w = pair_swap(pk2[0], pk2[1]);
-        const int nst = nbase + fg * 8;                          // this lane's 8 contiguous columns
-        if constexpr (EPI == EPI_BF16) {
-          if (p.act == 1 && p.out2) {
-            const u32x4 w2 = pair_swap(pre2[0], pre2[1]);
-            if (row_ok) *(u32x4*)((bf16_t*)p.out2 + (size_t)m * p.ldo + nst) = w2;
-          }
-          if (row_ok) *(u32x4*)((bf16_t*)p.out + (size_t)m * p.ldo + nst) = w;
-        } else if constexpr (EPI == EPI_DGELU) {
-          if (row_ok) *(u32x4*)((bf16_t*)p.out + (size_t)m * p.ldo + nst) = w;
-        } else if constexpr (EPI == EPI_QKV) {
-          const int D = p.H << p.dh_shift;
-          const int nv = nst + vz;
-          const int wq = (nv >= D) + (nv >= 2 * D);
-          const int c = nv - wq * D, which = wq + p.which0;
-          const int hh = c >> p.dh_shift, dd = c & ((1 << p.dh_shift) - 1);
-          bf16_t* rowp = which == 0 ? pq : (which == 1 ? pk : pv);
-          if (rowp && row_ok) *(u32x4*)(rowp + (((((size_t)qb * p.H + hh) * p.L + ql) << p.dh_shift) + dd)) = w;
-        }
-      }
-    }
-  }
-}
-
 template <int EPI, int MT, int NTL>
 __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL], int mrow0, int ncol0, int fr, int fg) {
-  if constexpr (EPI == EPI_BF16 || EPI == EPI_DGELU || EPI == EPI_QKV) {
-    if ((p.N & 15) == 0 && p.wide == 1) { store_tile_wide<EPI, MT, NTL>(p, acc, mrow0, ncol0, fr, fg); return; }
-  }
   // rows OUTER: a lane writes the 8 column groups of one row back to back, so the 128-byte lines of that row
   // are completed while still in the write-combining window (columns-outer order cost the fc GEMM 40 %).
   // (pointer fields are copied to locals: selecting among struct members by index forces the struct to scratch)
   [[maybe_unused]] bf16_t* const pq = p.q; [[maybe_unused]] bf16_t* const pk = p.k; [[maybe_unused]] bf16_t* const pv = p.v;
   [[maybe_unused]] bf16_t* const pqt = p.qt; [[maybe_unused]] bf16_t* const pkt = p.kt; [[maybe_unused]] bf16_t* const pvt = p.vt;
-  // profiling modes of vl_gemm_set_wide_stores (results are WRONG in both): 2 = no epilogue at all,
-  // 3 = full epilogue arithmetic and store issue, but every row folded onto rows 0..255 (stores stay in L2)
-  if (p.wide == 2) return;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    int m = mrow0 + i * 32 + fr;
+    const int m = mrow0 + i * 32 + fr;
     if (m >= p.M) continue;
-    if (p.wide == 3) m &= 255;
     [[maybe_unused]] int qb = 0, ql = 0, vz = 0;
     if constexpr (EPI == EPI_QKV) {
       const int ma = m + p.m_off; qb = ma / p.L; ql = ma - qb * p.L;
@@ -443,13 +263,11 @@ __device__ __forceinline__ void store_tile_lds(const GemmP& p, f32x16 (&acc)[MT]
     store_tile<EPI, MT, NTL>(p, acc, mrow0, ncol0, fr, fg);
     return;
   } else {
-    if (p.wide >= 1 && p.wide != 4) { store_tile<EPI, MT, NTL>(p, acc, mrow0, ncol0, fr, fg); return; }    // A/B + profiling modes
-    const bool do_store = p.wide != 4;       // profiling mode 4: transpose + arithmetic, no global stores (results WRONG)
     [[maybe_unused]] bool done16 = false;
     if constexpr ((EPI == EPI_BF16 || EPI == EPI_RES_BF16 || EPI == EPI_DGELU || EPI == EPI_QKV) && (NTL & 1) == 0) {
       // bf16 outputs: 16-byte path when rows stay 16-byte aligned (QKV destinations are [.., dh] rows with dh % 8 == 0)
       const bool al = EPI == EPI_QKV ? (p.dh_shift >= 3) : ((p.ldo & 7) == 0);
-      if (do_store && p.wide == 0 && (p.N & 7) == 0 && al) {
+      if ((p.N & 7) == 0 && al) {
 #pragma unroll
         for (int j0 = 0; j0 < NTL; j0 += 2)
           store_tile_lds16<EPI, MT, NTL>(p, acc, j0, mrow0, ncol0 + j0 * 32, fr, fg, lane, wl);
@@ -513,7 +331,6 @@ __device__ __forceinline__ void store_tile_lds(const GemmP& p, f32x16 (&acc)[MT]
           f32x4 v = *(const f32x4*)(wl + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
           if (m >= p.M || !col_ok) continue;
           v = v * p.alpha + bv;
-          if (!do_store) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
           if constexpr (EPI == EPI_BF16) {
             if (p.act == 1) {
               if (p.out2) {
@@ -747,12 +564,8 @@ hipError_t launch(const GemmP& p, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   auto kern = gemm_nt_kernel<BM, BN, WM, WN, EPI, DMA>;
   constexpr int smem = 2 * S::STAGE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);   // C++11 magic static: thread-safe, once
+  if (attr != hipSuccess) return attr;
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), smem, s, p);
   return hipGetLastError();
 }
@@ -850,7 +663,6 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
   const int G = gridDim.x;
   const int slot = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
   if (slot >= ntiles) return;
-  for (int w = (slot & 3) * p.stagger; w > 0; --w) __builtin_amdgcn_s_sleep(32);       // phase offset (~1 us per unit)
   const int my_tiles = (ntiles - slot + G - 1) / G;
   const int nk = p.K >> 6;
   const int total = my_tiles * nk;
@@ -985,20 +797,15 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
   }
 }
 
-static int g_num_cus = 0;
-static int num_cus() {
-  if (g_num_cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    g_num_cus = n;
-  }
-  return g_num_cus;
+static int query_cus() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  return n;
 }
-
-static int g_stagger = 0;       // sleep units per phase step of the persistent kernel (0 = all workgroups start together)
-static int g_wide_stores = 0;   // measured (profiles/r01e_kernel_bench_wide.log): the 16-byte exchange stores are 5-7 % SLOWER than the 8-byte path on fc/out
-extern "C" int vl_gemm_set_stagger(int units) { g_stagger = (units >= 0 && units <= 64) ? units : 0; return 0; }
-extern "C" int vl_gemm_set_wide_stores(int on) { g_wide_stores = (on >= 0 && on <= 4) ? on : 0; return 0; }   // 2, 3: profiling modes (see store_tile)
+static int num_cus() {
+  static const int n = query_cus();      // thread-safe one-time query (all devices of a node are the same part)
+  return n;
+}
 
 template <int EPI, int BN = 256, int NWAVES = 8>
 hipError_t launch_persist(const GemmP& p, hipStream_t s) {
@@ -1010,20 +817,33 @@ hipError_t launch_persist(const GemmP& p, hipStream_t s) {
   const int tiles = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
   auto kern = gemm_nt_persist2_kernel<256, BN, WM, WN, EPI>;
   constexpr int smem = 2 * S::STAGE + 8 * 4096;      // + 32 KB of epilogue-transpose slabs (160 KB at BN = 256)
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);   // C++11 magic static: thread-safe, once
+  if (attr != hipSuccess) return attr;
   int G = num_cus() & ~7;
   if (tiles < G) G = (tiles + 7) & ~7;
   hipLaunchKernelGGL(kern, dim3(G), dim3(NWAVES * 64), smem, s, p);
   return hipGetLastError();
 }
 
+}  // namespace
+// vl_gemm_park.hip: the round-2 persistent kernel (bf16-output epilogues, whole 256x256 tiles, K >= 512)
+bool vl_gemm_park_supported(int epi, const void* params);
+int vl_gemm_park_launch(int epi, const void* params, int ncu, hipStream_t s);
+namespace {
+
+// the persistent kernel for a problem whose M is a whole number of tiles: the round-2 kernel where it applies
+template <int EPI>
+hipError_t launch_best_persist(const GemmP& p, hipStream_t s) {
+  if (vl_gemm_park_supported(EPI, &p)) return (hipError_t)vl_gemm_park_launch(EPI, &p, num_cus(), s);
+  return launch_persist<EPI>(p, s);
+}
+
 template <int EPI>
 hipError_t dispatch(const GemmP& p, int cfg, hipStream_t s) {
+  if (cfg == 8) {
+    if (!vl_gemm_park_supported(EPI, &p)) return hipErrorInvalidValue;
+    return (hipError_t)vl_gemm_park_launch(EPI, &p, num_cus(), s);
+  }
   // cfg bit0: 0 = 256x256 tile (8 waves), 1 = 128x128 tile (4 waves); bit1: 1 = register staging
   if (cfg == 4 || cfg == 5) return launch_persist<EPI>(p, s);       // 4: historical alias
   if (cfg == 6) return launch_persist<EPI, 128>(p, s);              // 256x128 tiles (experiment)
@@ -1057,7 +877,7 @@ static hipError_t run_gemm(const GemmP& p, int cfg, hipStream_t s) {
   if (main_m == 0) return launch_persist<EPI>(p, s);
   const int rows_main = main_m * 256;
   GemmP pm = p; pm.M = rows_main;
-  hipError_t e = launch_persist<EPI>(pm, s);
+  hipError_t e = launch_best_persist<EPI>(pm, s);
   if (e != hipSuccess || rows_main == p.M) return e;
   GemmP pr = p;
   pr.M = p.M - rows_main; pr.m_off = p.m_off + rows_main;
@@ -1095,7 +915,7 @@ extern "C" int vl_gemm_bf16_ex(const void* A, const void* W, const float* bias, 
   VL_CHECK_ARG((ldo & 3) == 0, "vl_gemm_bf16: ldo must be a multiple of 4");
   GemmP p{};
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = bias; p.out = out; p.res = res; p.out2 = out2;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.alpha = alpha; p.act = act; p.res_div = res_div; p.wide = g_wide_stores; p.stagger = g_stagger;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.alpha = alpha; p.act = act; p.res_div = res_div;
   hipError_t e;
   switch (epi) {
     case VL_EPI_BF16: e = run_gemm<EPI_BF16>(p, cfg, stream); break;
@@ -1129,12 +949,8 @@ extern "C" int vl_gemm_splitk_accum_f32(const void* A, const void* W, float* out
   using S = Smem<128, 128>;
   auto kern = gemm_nt_kernel<128, 128, 2, 2, EPI_F32, true>;
   constexpr int smem = 2 * S::STAGE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
-    attr_set = true;
-  }
+  static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  if (attr != hipSuccess) return vl_set_error(hipGetErrorString(attr));
   const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
   hipLaunchKernelGGL(kern, dim3(tiles, eff), dim3(256), smem, stream, p);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)M * (N >> 2) + 255) / 256)), dim3(256), 0, stream, ws, eff, M, N, out, ldo);
@@ -1163,7 +979,7 @@ extern "C" int vl_gemm_qkv_bf16_ex(const void* A, const void* W, const float* bi
   VL_CHECK_ARG(Lp >= L, "vl_gemm_qkv_bf16: Lp < L");
   GemmP p{};
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = bias;
-  p.M = B * L; p.N = count * H * dh; p.K = K; p.which0 = first; p.res_div = 1; p.wide = g_wide_stores; p.stagger = g_stagger; p.lda = lda; p.ldw = K; p.ldo = 0; p.alpha = 1.f;
+  p.M = B * L; p.N = count * H * dh; p.K = K; p.which0 = first; p.res_div = 1; p.lda = lda; p.ldw = K; p.ldo = 0; p.alpha = 1.f;
   p.q = (bf16_t*)q; p.k = (bf16_t*)k; p.vt = (bf16_t*)vt; p.qt = (bf16_t*)qt; p.kt = (bf16_t*)kt; p.v = (bf16_t*)v; p.L = L; p.H = H; p.dh = dh; p.Lp = Lp; p.qscale = qscale; p.dh_shift = __builtin_ctz((unsigned)dh);
   hipError_t e = run_gemm<EPI_QKV>(p, cfg, stream);
   if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));

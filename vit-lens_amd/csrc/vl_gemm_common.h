@@ -1,0 +1,75 @@
+// Shared definitions of the bf16 NT GEMM kernels (vl_gemm.hip: 8-wave tile / tail / split-K kernels,
+// vl_gemm_p4.hip: 4-wave persistent kernel with the store-hidden epilogue).
+#pragma once
+#include "vl_common.h"
+#include "vitlens_hip.h"
+
+namespace {
+
+enum Epi : int {
+  EPI_BF16 = 0,   // out bf16 = act(acc*alpha + bias)
+  EPI_F32 = 1,    // out f32  = acc*alpha + bias
+  EPI_RES_F32 = 2,   // out f32  = res f32 + acc + bias      (in-place allowed)
+  EPI_RES_BF16 = 3,  // out bf16 = res bf16 + acc + bias
+  EPI_QKV = 4,    // scatter to q[B,H,L,dh], k[B,H,L,dh], vt[B,H,dh,Lp]
+  EPI_GEGLU = 5,  // rows interleaved (a_j, gate_j): out bf16[M, N/2] = a * gelu(gate)
+  EPI_DGELU = 6,  // out bf16 = acc * gelu'(aux[m,n])   (backward through GELU fused into the dX GEMM)
+  EPI_DGEGLU = 7, // acc = dy[M,N]; res = h[M,2N] interleaved (a,g): out[M,2N] = (dy*gelu(g), dy*a*gelu'(g)) interleaved
+};
+
+struct GemmP {
+  const bf16_t* A;   // [M, K]
+  const bf16_t* W;   // [N, K]
+  const float* bias; // [N] or null
+  void* out;
+  const void* res;   // residual (EPI_RES_*) or pre-activation u (EPI_DGELU), same shape/stride as out
+  void* out2;        // EPI_BF16 + act: optional copy of the PRE-activation values (saved for backward)
+  int M, N, K;
+  int lda, ldw, ldo; // row strides in elements
+  float alpha;
+  int act;           // 0 none, 1 gelu(erf), 2 relu
+  int res_div;       // residual row = m / res_div (>=1): broadcast one row over a group of res_div rows
+  // QKV scatter
+  bf16_t *q, *k, *vt;
+  bf16_t *qt, *kt, *v;   // optional extra layouts for the attention backward (transposed q/k, row-major v)
+  int L, H, dh, Lp, dh_shift;
+  int which0;        // first part produced by this GEMM: 0 = q, 1 = k, 2 = v
+  float qscale;
+  int m_off;         // absolute row of local row 0 (QKV scatter of a row-split launch)
+  // split-K (gemm_nt_kernel only): blockIdx.y owns k-slabs [y*ksplit_len, (y+1)*ksplit_len) and writes its
+  // partial product to out + y*split_stride (f32 elements); ksplit_len == 0 -> whole K, no offset
+  int ksplit_len;
+  long split_stride;
+};
+
+template <int BM, int BN>
+struct Smem {
+  static constexpr int A_BYTES = BM * 128;
+  static constexpr int B_BYTES = BN * 128;
+  static constexpr int STAGE = A_BYTES + B_BYTES;
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  // bijective "each XCD owns a contiguous chunk" remap (dispatch puts block b on XCD b % 8)
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+// The epilogue parameters (pointers, strides, scatter geometry) are re-read from the kernarg segment through an
+// opaque pointer at the moment a tile is stored.  Without this the compiler keeps ~40 scalars live across
+// the whole k-loop and spills SGPRs to scratch INSIDE it (measured: QKV-scatter GEMM 0.60 -> 2.49 ms).
+typedef const __attribute__((address_space(4))) GemmP* KernargP;
+__device__ __forceinline__ GemmP reload_params() {
+  GemmP r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  KernargP kp = (KernargP)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp));
+  __builtin_memcpy(&r, (const void*)kp, sizeof(GemmP));
+#endif
+  return r;
+}
+
+
+}  // namespace

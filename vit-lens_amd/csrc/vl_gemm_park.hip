@@ -1,0 +1,373 @@
+// Persistent bf16 NT GEMM for gfx950 (round-2 kernel): C[M,N] = A[M,K] * W[N,K]^T (+ fused bf16-output epilogue),
+// 256x256 output tiles, BK = 64, 8 waves (2x4, 128x64 each, two per SIMD), M % 256 == N % 256 == 0, K >= 512.
+//
+// What changed against the round-1 persistent kernel of vl_gemm.hip, and why (measurements: DESIGN.md section 7,
+// profiles/r02*_gemm_var_probe.log; every number below is the c_fc shape M = 65536, N = 4096, K = 1024):
+//
+//  * ONE barrier per k-step, placed in FRONT of the last 16-deep substep's MFMAs instead of at the end of the step:
+//    by then every wave holds its last fragments of the current LDS stage and the next stage has landed, so the DMA of
+//    step s+2 and the first fragment reads of step s+1 are issued UNDER those MFMAs, not behind the barrier.
+//  * LDS-DMA through a buffer descriptor (`buffer_load_dwordx4 ... offen lds`): ONE voffset VGPR per operand, all
+//    other addressing scalar (round 1: 16 address VGPRs).  hipcc does not model this builtin's LDS write in its waitcnt
+//    insertion, so the kernel waits `vmcnt(0)` by hand in front of a raw `s_barrier`.
+//  * The two waves of a SIMD (wave w and w+4) issue their 8 DMA instructions half a k-step apart (group A right after
+//    the barrier, group B at the top of the next step): an LDS-DMA issue blocks its wave for tens of cycles and with
+//    both partners blocked at once the matrix pipe idles.  Main loop alone: 1231 TF/s (round 1) -> 1300-1350 TF/s.
+//  * Epilogue = arithmetic in the accumulator layout -> bf16 -> wave-private 4 KB LDS slab (XOR-swizzled, no barrier)
+//    -> 16-byte NON-TEMPORAL stores, 8 lanes per 128-byte line, issued as ONE burst per wave; the next tile's main
+//    loop starts while they drain.  Plain (L2-allocating) stores cost +0.10 ms here: the 0.5 GB output evicts the
+//    operand slabs from the 4 MB L2s.  Trickling the stores through the next tile's k-loop from parked registers
+//    (the obvious "hide the epilogue" design, built and measured: 0.53 ms) is SLOWER than the burst (0.48 ms): a store
+//    instruction blocks its wave and the CU's vector-memory pipe wherever it is placed, so spreading them only spreads
+//    the damage over more k-steps.
+//  * Epilogues with a second operand of the output's shape (bf16 residual, saved pre-activation of dGELU) load it with
+//    16 loads per wave at the START of the epilogue, under the arithmetic of the first row block.  Prefetching it inside
+//    the k-loop (2 loads per k-step over the last 8 steps) was built and measured: 0.74 ms against 0.67 ms (c_fc shape,
+//    bf16 residual) - same lesson as for the stores: keep the k-loop's vector-memory queue for the DMA.
+//
+// Replaces: nn.Linear / MultiheadAttention in/out projections of ResidualAttentionBlock
+// (open_clip/transformer.py:215,226-234,252-272) in forward and dX-backward at ViT-L sizes.
+#include <type_traits>
+
+#include "vl_gemm_common.h"
+
+namespace {
+
+constexpr int PK_STAGE = 65536, PK_ABYTES = 32768;
+constexpr int PK_LDS = 2 * PK_STAGE + 32768;            // 160 KB: two operand stages + 8 x 4 KB transpose slabs
+constexpr int PK_GN = 4;                                 // N-tiles per group (tile order, see tile_origin)
+
+template <int I>
+using IC = std::integral_constant<int, I>;
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// ACT (EPI_BF16 only): 0 none, 1 GELU, 2 ReLU, 3 GELU with the pre-activation also written to out2 (saved for backward)
+template <int EPI, int ACT>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+    gemm_nt_pk_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr bool HAS_AUX = (EPI == EPI_RES_BF16 || EPI == EPI_DGELU);   // second operand of the output's shape
+  constexpr int NW = 8, NTL = 2, WTN = 64;   // 2 (M) x 4 (N) waves of 128 x 64
+  constexpr int NU = 4;                      // 1 KB DMA units per operand per wave per k-step
+  constexpr int NCH = 16;                    // output chunks per wave: chunk = 8 rows x 128 bytes = one store instruction
+  constexpr int SLAB = 4096;                 // wave-private transpose slab: 32 rows x 64 columns bf16
+
+  const int tiles_n = p.N >> 8, tiles_m = p.M >> 8;
+  const int ntiles = tiles_m * tiles_n;
+  const int G = gridDim.x;
+  const int slot = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  if (slot >= ntiles) return;
+  const int my_tiles = (ntiles - slot + G - 1) / G;
+  const int nk = p.K >> 6;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wid & 1, wave_n = (wid >> 1) & 3;
+  const bool grpB = wid >= 4;                // the second wave of each SIMD (waves w and w+4 share one)
+  const int fr = lane & 31, fg = lane >> 5;
+  const int fsw = (fr >> 1) & 7;
+
+  // tile order: groups of PK_GN consecutive N-tiles, M fastest inside a group, each XCD owns a contiguous run per round
+  auto tile_origin = [&](int ti, int& m0, int& n0) {
+    const int v = ti * G + slot;
+    const int gsz = PK_GN * tiles_m;
+    const int gid = v / gsz, rem = v - gid * gsz;
+    const int first_n = gid * PK_GN;
+    const int gn = min(tiles_n - first_n, PK_GN);
+    const int tm = rem / gn;
+    m0 = tm << 8; n0 = (first_n + (rem - tm * gn)) << 8;
+  };
+
+  // ---- LDS-DMA: unit i of an operand = rows i*64 + wid*8 + (lane>>3), 16-byte chunk (lane&7) ^ swizzle(row) ----
+  const int drow = wid * 8 + (lane >> 3);
+  const int dsw = ((lane & 7) ^ ((drow >> 1) & 7)) * 16;            // (i*64 >> 1) is a multiple of 8: the swizzle does not depend on i
+  const unsigned voffA = (unsigned)(drow * p.lda * 2 + dsw), voffW = (unsigned)(drow * p.ldw * 2 + dsw);
+  const int a_unit = p.lda * 128, w_unit = p.ldw * 128;            // bytes between units (64 rows)
+  __amdgpu_buffer_rsrc_t rsA, rsW;
+  auto make_rsrc = [&](int m0, int n0, __amdgpu_buffer_rsrc_t& ra, __amdgpu_buffer_rsrc_t& rw) {
+    ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)m0 * p.lda), 0, 0x7ffffff0, 0x00020000);
+    rw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)n0 * p.ldw), 0, 0x7ffffff0, 0x00020000);
+  };
+
+  // ---- fragments (two sets: the reads of substep s+1 are in flight under the MFMAs of substep s) ----
+  const int fa_base = (wave_m * 128 + fr) * 128, fw_base = PK_ABYTES + (wave_n * WTN + fr) * 128;
+  bf16x8 af[2][4], wf[2][NTL];
+  auto ldfrag = [&](const unsigned char* stage, int kk, int c) {
+    const int off = ((kk * 2 + fg) ^ fsw) * 16;
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) wf[c][j] = *(const bf16x8*)(stage + fw_base + j * 4096 + off);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[c][i] = *(const bf16x8*)(stage + fa_base + i * 4096 + off);
+  };
+  f32x16 acc[4][NTL];
+  auto mma = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NTL; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][j], af[c][i], acc[i][j], 0, 0, 0);
+  };
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+
+  // ---- epilogue operands ----
+  // chunk ci (0..15) = rows (ci>>2)*32 + (ci&3)*8 + (lane>>3) of the wave's sub-tile, columns (lane&7)*8 .. +7
+  [[maybe_unused]] u32x4 aux[NCH];
+  const int prow = lane >> 3, pcol = (lane & 7) * 8;
+  const unsigned lo_out = (unsigned)((prow * p.ldo + pcol) * 2);     // lane part of an output / aux address (row-major outputs)
+  const int ldo2 = p.ldo * 2;
+  [[maybe_unused]] const float inv_L = EPI == EPI_QKV ? 1.0f / (float)p.L : 0.f;
+  auto chunk_row = [](int ci) { return (ci >> 2) * 32 + (ci & 3) * 8; };
+  [[maybe_unused]] const unsigned char* aux_src = nullptr;      // &aux[tile row 0 of this wave][tile col 0 of this wave] (current tile)
+  auto load_pair = [&](auto GI) {
+    constexpr int g = decltype(GI)::value;
+    if constexpr (HAS_AUX) {
+      aux[g * 2] = *(const u32x4*)(aux_src + (size_t)(chunk_row(g * 2) * ldo2) + lo_out);
+      aux[g * 2 + 1] = *(const u32x4*)(aux_src + (size_t)(chunk_row(g * 2 + 1) * ldo2) + lo_out);
+    }
+  };
+
+  int cur_m0, cur_n0;
+  tile_origin(0, cur_m0, cur_n0);
+  auto set_aux = [&]() {
+    if constexpr (HAS_AUX) {
+      // EPI_RES_BF16 indexes its residual by the absolute row (m + m_off) with an un-offset pointer (vl_gemm.hip run_gemm)
+      const int moff = EPI == EPI_RES_BF16 ? p.m_off : 0;
+      aux_src = (const unsigned char*)p.res + ((size_t)(cur_m0 + moff + wave_m * 128) * p.ldo + cur_n0 + wave_n * WTN) * 2;
+    }
+  };
+  make_rsrc(cur_m0, cur_n0, rsA, rsW);
+  // DMA position (dti, dkt) = the step whose operands the next DMA batch loads; it runs two k-steps ahead of the MFMAs and
+  // therefore enters the next tile at kt = nk-2: that tile's descriptors are prepared once per tile, outside the k-loop
+  __amdgpu_buffer_rsrc_t rsA_n = rsA, rsW_n = rsW;
+  int dti = 0, dkt = 0;
+  auto dma_step = [&](unsigned char* stage) {
+    const int kbyte = dkt << 7;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(stage + (i * NW + wid) * 1024), 16, voffA, kbyte + i * a_unit, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(stage + PK_ABYTES + (i * NW + wid) * 1024), 16, voffW, kbyte + i * w_unit, 0, 0);
+    }
+    ++dkt;
+    if (dkt == nk) { dkt = 0; ++dti; rsA = rsA_n; rsW = rsW_n; }
+  };
+  // hipcc does not wait for this builtin's LDS writes in front of a barrier: wait by hand.  The barrier is the raw
+  // instruction: __syncthreads() carries a release fence, i.e. a compiler vmcnt(0)/lgkmcnt(0) for everything else, which
+  // is what we want to control here.  The only cross-wave LDS traffic is the DMA (vmcnt) and fragment READS (lgkmcnt).
+  // vmcnt(0) also retires the previous tile's output stores (in-order counter): they have ~1.5 k-steps to drain before
+  // they can delay a barrier.
+  auto dma_wait_and_barrier = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+
+  zero_acc();
+  dma_step(smem);
+  dma_step(smem + PK_STAGE);                     // nk >= 8: still inside tile 0
+  dma_wait_and_barrier();
+  ldfrag(smem, 0, 0);
+
+  int par = 0;                                   // stage buffer of the k-step being computed
+  bool pendB = false;                            // group B: a DMA batch is due at the top of the next k-step
+  auto kstep = [&](auto LAST) {
+    constexpr bool last = decltype(LAST)::value;
+    unsigned char* cur = smem + par * PK_STAGE;
+    unsigned char* oth = smem + (par ^ 1) * PK_STAGE;
+    if (grpB && pendB) { dma_step(oth); pendB = false; }
+    __builtin_amdgcn_sched_barrier(0);
+    ldfrag(cur, 1, 1);
+    mma(0);
+    __builtin_amdgcn_sched_barrier(0);
+    ldfrag(cur, 2, 0);
+    mma(1);
+    __builtin_amdgcn_sched_barrier(0);
+    ldfrag(cur, 3, 1);
+    mma(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // every wave holds its last fragments of `cur`; the DMA of the next k-step (issued 0.5 - 1 k-step ago) has landed
+    dma_wait_and_barrier();
+    if (dti < my_tiles) { if (!grpB) dma_step(cur); else pendB = true; }
+    if constexpr (!last) ldfrag(oth, 0, 0);      // (at a tile boundary the fragments would sit in registers through the epilogue)
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1);
+    __builtin_amdgcn_sched_barrier(0);
+    par ^= 1;
+  };
+
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    if (ti + 1 < my_tiles) {
+      int nm0, nn0;
+      tile_origin(ti + 1, nm0, nn0);
+      make_rsrc(nm0, nn0, rsA_n, rsW_n);
+    }
+    set_aux();
+    for (int kt = 0; kt < nk - 1; ++kt) kstep(std::false_type{});
+    kstep(std::true_type{});
+    {
+      // ---------------- tile finished: arithmetic, LDS transpose, one burst of 16-byte non-temporal stores ----------------
+      const GemmP pe = reload_params();
+      const int mrow0 = cur_m0 + wave_m * 128, ncol0 = cur_n0 + wave_n * WTN;
+      if constexpr (HAS_AUX) {
+        load_pair(IC<0>{}); load_pair(IC<1>{}); load_pair(IC<2>{}); load_pair(IC<3>{});
+        load_pair(IC<4>{}); load_pair(IC<5>{}); load_pair(IC<6>{}); load_pair(IC<7>{});
+      }
+      unsigned char* const slab = smem + 2 * PK_STAGE + wid * SLAB;
+      unsigned char* const wr = slab + fr * 128 + fg * 8;
+      const int wsw = fr & 7;
+      // branch-free optional bias: read SOMETHING valid (the weight matrix) and select zero
+      const bool has_bias = pe.bias != nullptr;
+      const float* const bsrc = has_bias ? pe.bias : (const float*)pe.W;
+      [[maybe_unused]] const int Dm = pe.H << pe.dh_shift;
+      // destination of this lane's chunks
+      [[maybe_unused]] unsigned char* out_base = nullptr;
+      [[maybe_unused]] bf16_t* qkv_base = nullptr;       // QKV: per-lane &part[0, head(lane's columns), 0, dd]
+      if constexpr (EPI == EPI_QKV) {
+        bf16_t* const pq = pe.q; bf16_t* const pk = pe.k; bf16_t* const pv = pe.v;
+        const int n8 = ncol0 + pcol;
+        const int wq = (n8 >= Dm) + (n8 >= 2 * Dm);
+        const int cc = n8 - wq * Dm;
+        const int which = wq + pe.which0;
+        bf16_t* rowp = which == 0 ? pq : (which == 1 ? pk : pv);
+        const int hh = cc >> pe.dh_shift, dd = cc & ((1 << pe.dh_shift) - 1);
+        qkv_base = rowp ? rowp + (((size_t)hh * pe.L) << pe.dh_shift) + dd : nullptr;
+      } else {
+        out_base = (unsigned char*)pe.out + ((size_t)mrow0 * pe.ldo + ncol0) * 2 + lo_out;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n = ncol0 + j * 32 + q * 8 + fg * 4;
+            f32x4 v = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+            f32x4 bv = *(const f32x4*)(bsrc + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = has_bias ? bv[e] : 0.f;
+            v = v * pe.alpha + bv;
+            if constexpr (EPI == EPI_QKV) {
+              if (pe.which0 == 0 && n < Dm) v = v * pe.qscale;
+            }
+            if constexpr (EPI == EPI_BF16 && ACT == 1) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            } else if constexpr (EPI == EPI_BF16 && ACT == 2) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+            *(u32x2*)(wr + (((j * 4 + q) ^ wsw) << 4)) = o;
+            if constexpr (EPI == EPI_QKV) {
+              // transposed attention operands (token index contiguous) straight from the accumulator layout
+              const int wq = (n >= Dm) + (n >= 2 * Dm);
+              const int which = wq + pe.which0;
+              bf16_t* const pqt = pe.qt; bf16_t* const pkt = pe.kt; bf16_t* const pvt = pe.vt;
+              bf16_t* colp = which == 0 ? pqt : (which == 1 ? pkt : pvt);
+              if (colp) {
+                const int cc = n - wq * Dm;
+                const int h2 = cc >> pe.dh_shift, d2 = cc & ((1 << pe.dh_shift) - 1);
+                const int ma = mrow0 + i * 32 + fr + pe.m_off;
+                int qb = (int)(((float)ma + 0.5f) * inv_L);          // floor(ma / L) (exact for ma < 2^22; one correction step anyway)
+                int ql = ma - qb * pe.L;
+                if (ql < 0) { ql += pe.L; --qb; } else if (ql >= pe.L) { ql -= pe.L; ++qb; }
+                const size_t col_off = ((((size_t)qb * pe.H + h2) << pe.dh_shift) + d2) * pe.Lp + ql;
+                colp[col_off] = (bf16_t)(o[0] & 0xffff); colp[col_off + pe.Lp] = (bf16_t)(o[0] >> 16);
+                colp[col_off + 2 * (size_t)pe.Lp] = (bf16_t)(o[1] & 0xffff); colp[col_off + 3 * (size_t)pe.Lp] = (bf16_t)(o[1] >> 16);
+              }
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int r = pass * 8 + prow;
+          u32x4 w = *(const u32x4*)(slab + r * 128 + (((lane & 7) ^ (r & 7)) << 4));
+          [[maybe_unused]] u32x4 rr;
+          if constexpr (HAS_AUX) rr = aux[i * 4 + pass];
+          if constexpr (EPI == EPI_BF16 && ACT == 3) {
+            __builtin_nontemporal_store(w, (u32x4*)((unsigned char*)pe.out2 + ((size_t)(mrow0 + i * 32 + pass * 8) * pe.ldo + ncol0) * 2 + lo_out));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              w[e] = pack2bf(gelu_erf(bf2f((bf16_t)(w[e] & 0xffff))), gelu_erf(bf2f((bf16_t)(w[e] >> 16))));
+          } else if constexpr (EPI == EPI_RES_BF16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float lo = bf2f((bf16_t)(w[e] & 0xffff)) + bf2f((bf16_t)(rr[e] & 0xffff));
+              const float hi = bf2f((bf16_t)(w[e] >> 16)) + bf2f((bf16_t)(rr[e] >> 16));
+              w[e] = pack2bf(lo, hi);
+            }
+          } else if constexpr (EPI == EPI_DGELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              w[e] = pack2bf(bf2f((bf16_t)(w[e] & 0xffff)) * gelu_erf_grad(bf2f((bf16_t)(rr[e] & 0xffff))),
+                             bf2f((bf16_t)(w[e] >> 16)) * gelu_erf_grad(bf2f((bf16_t)(rr[e] >> 16))));
+          }
+          if constexpr (EPI == EPI_QKV) {
+            if (qkv_base) {
+              const int m = mrow0 + pe.m_off + i * 32 + pass * 8 + prow;
+              int qb = (int)(((float)m + 0.5f) * inv_L);
+              int ql = m - qb * pe.L;
+              if (ql < 0) { ql += pe.L; --qb; } else if (ql >= pe.L) { ql -= pe.L; ++qb; }
+              __builtin_nontemporal_store(w, (u32x4*)(qkv_base + ((((size_t)qb * pe.H) * pe.L + ql) << pe.dh_shift)));
+            }
+          } else {
+            __builtin_nontemporal_store(w, (u32x4*)(out_base + (size_t)((i * 32 + pass * 8) * ldo2)));
+          }
+        }
+      }
+      zero_acc();
+      if (ti + 1 < my_tiles) { tile_origin(ti + 1, cur_m0, cur_n0); ldfrag(smem + par * PK_STAGE, 0, 0); }
+    }
+  }
+}
+
+template <int EPI, int ACT>
+hipError_t launch_pk(const GemmP& p, int ncu, hipStream_t s) {
+  auto kern = gemm_nt_pk_kernel<EPI, ACT>;
+  static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PK_LDS);   // thread-safe one-time init
+  if (attr != hipSuccess) return attr;
+  const int tiles = (p.M >> 8) * (p.N >> 8);
+  int G = ncu & ~7;
+  if (tiles < G) G = (tiles + 7) & ~7;
+  hipLaunchKernelGGL(kern, dim3(G), dim3(512), PK_LDS, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+// Internal entries used by vl_gemm.hip's dispatcher (not part of the public C ABI).
+bool vl_gemm_park_supported(int epi, const void* params) {
+  const GemmP& p = *(const GemmP*)params;
+  if (!(epi == EPI_BF16 || epi == EPI_RES_BF16 || epi == EPI_DGELU || epi == EPI_QKV)) return false;
+  // whole tiles; the DMA prologue issues two k-steps of tile 0 up front
+  if ((p.M & 255) || (p.N & 255) || (p.K & 63) || p.K < 512 || p.M <= 0 || p.N <= 0) return false;
+  if (p.res_div != 1) return false;
+  if (epi == EPI_RES_BF16 && p.act != 0) return false;
+  if (epi == EPI_BF16 && p.out2 && p.act != 1) return false;
+  if (epi != EPI_QKV && (p.ldo & 7)) return false;
+  if (epi == EPI_QKV && (p.dh_shift < 3 || ((p.H << p.dh_shift) & 63) || (size_t)p.M + p.m_off >= (1u << 22))) return false;
+  // 16-byte accesses on every operand
+  if (((uintptr_t)p.A | (uintptr_t)p.W) & 15) return false;
+  if (epi != EPI_QKV && (((uintptr_t)p.out | (uintptr_t)p.res | (uintptr_t)p.out2) & 15)) return false;
+  return true;
+}
+
+int vl_gemm_park_launch(int epi, const void* params, int ncu, hipStream_t s) {
+  const GemmP& p = *(const GemmP*)params;
+  switch (epi) {
+    case EPI_BF16:
+      if (p.act == 1) return p.out2 ? (int)launch_pk<EPI_BF16, 3>(p, ncu, s) : (int)launch_pk<EPI_BF16, 1>(p, ncu, s);
+      return p.act == 2 ? (int)launch_pk<EPI_BF16, 2>(p, ncu, s) : (int)launch_pk<EPI_BF16, 0>(p, ncu, s);
+    case EPI_RES_BF16: return (int)launch_pk<EPI_RES_BF16, 0>(p, ncu, s);
+    case EPI_DGELU: return (int)launch_pk<EPI_DGELU, 0>(p, ncu, s);
+    case EPI_QKV: return (int)launch_pk<EPI_QKV, 0>(p, ncu, s);
+    default: return (int)hipErrorInvalidValue;
+  }
+}

@@ -383,14 +383,3 @@ def group_sum(x, M):
     return out
 
 
-def set_wide_stores(on):
-    """0 = 8-byte epilogue stores (default), 1 = 16-byte exchange stores; 2 / 3 = profiling modes with WRONG results
-    (no epilogue / epilogue with all stores folded onto 256 rows), see csrc/vl_gemm.hip:store_tile."""
-    _lib.vl_gemm_set_wide_stores(int(on))
-
-
-def set_stagger(units: int):
-    """Phase offset (sleep units of ~1 us) between the four workgroup phase groups of the persistent GEMM; 0 = off."""
-    _lib.vl_gemm_set_stagger(int(units))
-
-
