@@ -161,12 +161,20 @@ int vl_ce_grad(const float* logits, long ld, int R, int C, int label_off, const 
 int vl_layernorm_bwd(const void* dy, int dy_dtype, long dy_stride, const void* x, int x_dtype, long x_stride,
                      const float* mean, const float* rstd, const float* w, const float* dres, float* dx,
                      void* dx_bf16, long dx_stride, int rows, int D, hipStream_t stream);
+/* The same with the residual-gradient stream (dres in, dx out) in dtype g_dtype (VL_F32 | VL_BF16): bf16 is what the
+ * reference's amp_bf16 autocast carries for the gradients of its bf16 residual stream. */
+int vl_layernorm_bwd_g(const void* dy, int dy_dtype, long dy_stride, const void* x, int x_dtype, long x_stride,
+                       const float* mean, const float* rstd, const float* w, const void* dres, void* dx, int g_dtype,
+                       void* dx_bf16, long dx_stride, int rows, int D, hipStream_t stream);
+/* Column reductions are deterministic two-stage sums (row slabs -> fixed-order combine, no atomics) and need a caller
+ * workspace of vl_colreduce_ws_floats(rows, cols, planes) floats (planes: 2 for the LayerNorm parameters, 1 for vl_colsum). */
+long vl_colreduce_ws_floats(int rows, int cols, int planes);
 /* dw[j] += sum_r dy*xhat ; db[j] += sum_r dy   (accumulating; zero the buffers first) */
 int vl_layernorm_bwd_params(const void* dy, int dy_dtype, long dy_stride, const void* x, int x_dtype, long x_stride,
                             const float* mean, const float* rstd, float* dw, float* db, int rows, int D,
-                            hipStream_t stream);
+                            float* ws, hipStream_t stream);
 /* out[j] += scale * sum_r a[r,j]  (bias gradients) */
-int vl_colsum(const void* a, int a_dtype, long lda, float* out, int rows, int cols, float scale, hipStream_t stream);
+int vl_colsum(const void* a, int a_dtype, long lda, float* out, int rows, int cols, float scale, float* ws, hipStream_t stream);
 int vl_gelu_bf16(const void* u, void* y, long n, hipStream_t stream);
 /* y[m,j] = h[m,2j] * gelu(h[m,2j+1])  (recompute of the GEGLU output from the saved pre-activation) */
 int vl_geglu_bf16(const void* h, void* y, long rows, int n_out, hipStream_t stream);

@@ -141,6 +141,33 @@ def test_layernorm_backward_and_params():
     dw = torch.zeros(D, device="cuda"); db = torch.zeros(D, device="cuda")
     ops.layernorm_bwd_params(dy.cuda(), xc, mean, rstd, dw, db, rows, D)
     assert relerr(dw, wr.grad) < 1e-5 and relerr(db, br.grad) < 1e-5
+    # deterministic reductions: a second call adds exactly the same numbers
+    dw2 = torch.zeros(D, device="cuda"); db2 = torch.zeros(D, device="cuda")
+    ops.layernorm_bwd_params(dy.cuda(), xc, mean, rstd, dw2, db2, rows, D)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("rows,D", [(50, 1024), (7, 768), (33, 512), (20, 384)])
+def test_layernorm_backward_bf16_streams(rows, D):
+    """bf16 residual x and bf16 residual-gradient stream (what the reference's amp_bf16 autocast carries): the kernel reads
+    the bf16-rounded x / dres and rounds dx once -> compare with fp32 autograd on the rounded inputs at bf16 resolution."""
+    from vitlens_hip import ops
+    g = torch.Generator().manual_seed(16)
+    x = (torch.randn(rows, D, generator=g) * 2 + 0.5).bfloat16()
+    w = 1 + 0.1 * torch.randn(D, generator=g); b = 0.1 * torch.randn(D, generator=g)
+    dy = torch.randn(rows, D, generator=g).bfloat16()
+    dres = torch.randn(rows, D, generator=g).bfloat16()
+    xr = x.float().requires_grad_(True)
+    (torch.nn.functional.layer_norm(xr, (D,), w, b, 1e-5) * dy.float()).sum().backward()
+    xc = x.cuda(); y = torch.empty(rows, D, device="cuda", dtype=torch.bfloat16)
+    mean = torch.empty(rows, device="cuda"); rstd = torch.empty(rows, device="cuda")
+    ops.layernorm(xc, w.cuda(), b.cuda(), y, rows, D, mean=mean, rstd=rstd)
+    dx = dres.clone().cuda()
+    ops.layernorm_bwd(dy.cuda(), xc, mean, rstd, w.cuda(), rows, D, dres=dx, dx=dx)        # in place, bf16 stream
+    assert dx.dtype == torch.bfloat16 and relerr(dx, xr.grad + dres.float()) < 4e-3
+    dxf = torch.empty(rows, D, device="cuda")
+    ops.layernorm_bwd(dy.cuda(), xc, mean, rstd, w.cuda(), rows, D, dx=dxf)                 # bf16 x, f32 out, no upstream
+    assert relerr(dxf, xr.grad) < 1e-5
 
 
 def test_adamw_matches_torch():
@@ -182,16 +209,20 @@ def test_gemm_dgelu_and_preact_save():
     assert relerr(y, torch.nn.functional.gelu(u.float().cpu())) < 4e-3
 
 
-def test_tri_modal_step_matches_reference_step():
+@pytest.mark.parametrize("res_dtype", [torch.float32, torch.bfloat16])
+def test_tri_modal_step_matches_reference_step(res_dtype):
     """The whole tri-modal step (3 towers -> TriClipLoss -> backward) against the reference's own step on the
-    tiny golden model: loss value and every gradient of the unlocked set (adapter + blocks + logit_scale)."""
+    tiny golden model: loss value and every gradient of the unlocked set (adapter + blocks + logit_scale).
+    res_dtype = dtype of the trainable tower's residual stream and residual-gradient stream (bf16 = the reference's
+    amp_bf16 autocast, what bench.py runs; the reference gradients here are its fp32 ones)."""
     from vitlens_hip import engine as E, step as ST
     sd, ins, outs, grads, tc, lc = _tiny_depth()
     _, _, _, _, meta = split(load_npz("tiny_depth.npz"))
     _, text, _ = specs_from_meta(meta)
     xc = E.TextCfg(context_length=text.context_length, vocab_size=text.vocab_size, width=text.width, heads=text.heads,
                    layers=text.layers, embed_dim=text.embed_dim)
-    st = ST.TriModalDepthStep(sd, tc, xc, "cuda", micro_batch=2, unlock_first_n=tc.layers, lr=1e-3)
+    st = ST.TriModalDepthStep(sd, tc, xc, "cuda", micro_batch=2, unlock_first_n=tc.layers, lr=1e-3, train_res_dtype=res_dtype,
+                              frozen_res_dtype=res_dtype)
     loss = st.forward_backward(ins["image"].cuda(), ins["text"].cuda(), ins["visual_x"].cuda())
     assert abs(float(loss) - float(outs["step_loss"])) < 2e-2, (float(loss), float(outs["step_loss"]))
     n = 0

@@ -15,44 +15,94 @@ namespace {
 __device__ __forceinline__ float ld1(const float* p) { return *p; }
 __device__ __forceinline__ float ld1(const bf16_t* p) { return bf2f(*p); }
 
+__device__ __forceinline__ void ld4(const float* p, float (&v)[4]) {
+  const f32x4 t = *(const f32x4*)p; v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+__device__ __forceinline__ void ld4(const bf16_t* p, float (&v)[4]) {
+  const u32x2 t = *(const u32x2*)p;
+  v[0] = bf2f((bf16_t)(t[0] & 0xffff)); v[1] = bf2f((bf16_t)(t[0] >> 16));
+  v[2] = bf2f((bf16_t)(t[1] & 0xffff)); v[3] = bf2f((bf16_t)(t[1] >> 16));
+}
+__device__ __forceinline__ void st4(float* p, const float (&v)[4]) { f32x4 t = {v[0], v[1], v[2], v[3]}; *(f32x4*)p = t; }
+__device__ __forceinline__ void st4(bf16_t* p, const float (&v)[4]) {
+  u32x2 t; t[0] = pack2bf(v[0], v[1]); t[1] = pack2bf(v[2], v[3]); *(u32x2*)p = t;
+}
+
 struct LnBwdP {
   const void* dy; const void* x; const float* mean; const float* rstd; const float* w;
-  const float* dres;      // optional upstream gradient of the residual stream (added to dx)
-  float* dx; bf16_t* dxb; // outputs (dx may alias dres)
+  const void* dres;       // optional upstream gradient of the residual stream (added to dx), gradient-stream dtype
+  void* dx; bf16_t* dxb;  // outputs: dx in the gradient-stream dtype (may alias dres), optional bf16 copy
   long dys, xs, dxs;      // row strides
   int rows, D;
 };
 
-template <typename TDY, typename TX>
+// One wave per row.  NCH > 0: the row (D = NCH*256 elements) is read ONCE into registers with 8/16-byte accesses;
+// NCH == 0: any D, two passes over global memory.  TG = dtype of the residual-gradient stream (dres / dx).
+template <int NCH, typename TDY, typename TX, typename TG>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnBwdP p) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.rows) return;
   const TDY* dy = (const TDY*)p.dy + (long)row * p.dys;
   const TX* x = (const TX*)p.x + (long)row * p.xs;
+  const TG* dres = p.dres ? (const TG*)p.dres + (long)row * p.dxs : nullptr;
+  TG* dx = p.dx ? (TG*)p.dx + (long)row * p.dxs : nullptr;
+  bf16_t* dxb = p.dxb ? p.dxb + (long)row * p.dxs : nullptr;
   const float mu = p.mean[row], rs = p.rstd[row];
   const int D = p.D;
-  float s1 = 0.f, s2 = 0.f;
-  for (int e = lane; e < D; e += 64) {
-    const float g = ld1(dy + e) * p.w[e];
-    const float xh = (ld1(x + e) - mu) * rs;
-    s1 += g; s2 = fmaf(g, xh, s2);
-  }
-  s1 = wave_sum(s1) / (float)D; s2 = wave_sum(s2) / (float)D;
-  for (int e = lane; e < D; e += 64) {
-    const float g = ld1(dy + e) * p.w[e];
-    const float xh = (ld1(x + e) - mu) * rs;
-    float v = rs * (g - s1 - xh * s2);
-    if (p.dres) v += p.dres[(long)row * p.dxs + e];
-    if (p.dx) p.dx[(long)row * p.dxs + e] = v;
-    if (p.dxb) p.dxb[(long)row * p.dxs + e] = f2bf(v);
+  if constexpr (NCH > 0) {
+    float g[NCH][4], xh[NCH][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int e = c * 256 + lane * 4;
+      float ww[4];
+      ld4(dy + e, g[c]); ld4(x + e, xh[c]); ld4(p.w + e, ww);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        g[c][k] *= ww[k]; xh[c][k] = (xh[c][k] - mu) * rs;
+        s1 += g[c][k]; s2 = fmaf(g[c][k], xh[c][k], s2);
+      }
+    }
+    s1 = wave_sum(s1) / (float)D; s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int e = c * 256 + lane * 4;
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = rs * (g[c][k] - s1 - xh[c][k] * s2);
+      if (dres) {
+        float r[4]; ld4(dres + e, r);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += r[k];
+      }
+      if (dx) st4(dx + e, v);
+      if (dxb) st4(dxb + e, v);
+    }
+  } else {
+    float s1 = 0.f, s2 = 0.f;
+    for (int e = lane; e < D; e += 64) {
+      const float g = ld1(dy + e) * p.w[e];
+      const float xh = (ld1(x + e) - mu) * rs;
+      s1 += g; s2 = fmaf(g, xh, s2);
+    }
+    s1 = wave_sum(s1) / (float)D; s2 = wave_sum(s2) / (float)D;
+    for (int e = lane; e < D; e += 64) {
+      const float g = ld1(dy + e) * p.w[e];
+      const float xh = (ld1(x + e) - mu) * rs;
+      float v = rs * (g - s1 - xh * s2);
+      if (dres) v += ld1(dres + e);
+      if (dx) { if constexpr (sizeof(TG) == 4) dx[e] = v; else dx[e] = f2bf(v); }
+      if (dxb) dxb[e] = f2bf(v);
+    }
   }
 }
 
-// thread per column, a slab of rows per block; atomics combine slabs
+// LayerNorm weight / bias gradients, deterministic two-stage column reduction (no atomics):
+// stage 1: block (column block, row slab) -> partial sums ws[slab][2][D]; stage 2: fixed-order sum over slabs, += into dw / db.
 template <typename TDY, typename TX>
 __global__ void __launch_bounds__(256) ln_bwd_params_kernel(const TDY* dy, long dys, const TX* x, long xs, const float* mean,
-                                                            const float* rstd, float* dw, float* db, int rows, int D, int slab) {
+                                                            const float* rstd, float* ws, int rows, int D, int slab) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= D) return;
   const int r0 = blockIdx.y * slab, r1 = min(rows, r0 + slab);
@@ -62,17 +112,30 @@ __global__ void __launch_bounds__(256) ln_bwd_params_kernel(const TDY* dy, long 
     a = fmaf(g, (ld1(x + (long)r * xs + j) - mean[r]) * rstd[r], a);
     b += g;
   }
-  atomicAdd(dw + j, a); atomicAdd(db + j, b);
+  ws[((long)blockIdx.y * 2) * D + j] = a; ws[((long)blockIdx.y * 2 + 1) * D + j] = b;
 }
 
+// out_k[j] += scale * sum_s ws[s][k][j]   (k < K planes), fixed summation order
+__global__ void __launch_bounds__(256) slab_finalize_kernel(const float* ws, int nslab, int K, int D, float scale, float* out0, float* out1) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= D) return;
+  for (int k = 0; k < K; ++k) {
+    float s = 0.f;
+    for (int t = 0; t < nslab; ++t) s += ws[((long)t * K + k) * D + j];
+    float* o = k == 0 ? out0 : out1;
+    o[j] += s * scale;
+  }
+}
+
+// bias gradients: stage 1 of the same deterministic two-stage column reduction (partials ws[slab][cols])
 template <typename T>
-__global__ void __launch_bounds__(256) colsum_kernel(const T* a, long lda, float* out, int rows, int cols, int slab, float scale) {
+__global__ void __launch_bounds__(256) colsum_kernel(const T* a, long lda, float* ws, int rows, int cols, int slab) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= cols) return;
   const int r0 = blockIdx.y * slab, r1 = min(rows, r0 + slab);
   float s = 0.f;
   for (int r = r0; r < r1; ++r) s += ld1(a + (long)r * lda + j);
-  atomicAdd(out + j, s * scale);
+  ws[(long)blockIdx.y * cols + j] = s;
 }
 
 __global__ void __launch_bounds__(256) gelu_kernel(const bf16_t* u, bf16_t* y, long n) {
@@ -137,44 +200,76 @@ extern "C" int vl_set_error(const char* msg);
 #define VL_HIP_OK(e) do { hipError_t _e = (e); if (_e != hipSuccess) return vl_set_error(hipGetErrorString(_e)); } while (0)
 static int grid_for(long n) { long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
+template <typename TDY, typename TX, typename TG>
+static void ln_bwd_launch(const LnBwdP& p, hipStream_t stream) {
+  const dim3 g((p.rows + 3) / 4), b(256);
+  const bool vec = (p.D % 256 == 0) && (p.dys % 4 == 0) && (p.xs % 4 == 0) && (p.dxs % 4 == 0);
+  if (vec && p.D == 1024) hipLaunchKernelGGL((ln_bwd_kernel<4, TDY, TX, TG>), g, b, 0, stream, p);
+  else if (vec && p.D == 768) hipLaunchKernelGGL((ln_bwd_kernel<3, TDY, TX, TG>), g, b, 0, stream, p);
+  else if (vec && p.D == 512) hipLaunchKernelGGL((ln_bwd_kernel<2, TDY, TX, TG>), g, b, 0, stream, p);
+  else if (vec && p.D == 256) hipLaunchKernelGGL((ln_bwd_kernel<1, TDY, TX, TG>), g, b, 0, stream, p);
+  else hipLaunchKernelGGL((ln_bwd_kernel<0, TDY, TX, TG>), g, b, 0, stream, p);
+}
+
+extern "C" int vl_layernorm_bwd_g(const void* dy, int dy_dtype, long dy_stride, const void* x, int x_dtype, long x_stride,
+                                  const float* mean, const float* rstd, const float* w, const void* dres, void* dx, int g_dtype,
+                                  void* dx_bf16, long dx_stride, int rows, int D, hipStream_t stream) {
+  if (rows <= 0 || D <= 0) return vl_set_error("vl_layernorm_bwd: empty problem");
+  LnBwdP p{dy, x, mean, rstd, w, dres, dx, (bf16_t*)dx_bf16, dy_stride, x_stride, dx_stride, rows, D};
+  const int key = (dy_dtype == VL_BF16 ? 4 : 0) | (x_dtype == VL_BF16 ? 2 : 0) | (g_dtype == VL_BF16 ? 1 : 0);
+  switch (key) {
+    case 0: ln_bwd_launch<float, float, float>(p, stream); break;
+    case 1: ln_bwd_launch<float, float, bf16_t>(p, stream); break;
+    case 2: ln_bwd_launch<float, bf16_t, float>(p, stream); break;
+    case 3: ln_bwd_launch<float, bf16_t, bf16_t>(p, stream); break;
+    case 4: ln_bwd_launch<bf16_t, float, float>(p, stream); break;
+    case 5: ln_bwd_launch<bf16_t, float, bf16_t>(p, stream); break;
+    case 6: ln_bwd_launch<bf16_t, bf16_t, float>(p, stream); break;
+    default: ln_bwd_launch<bf16_t, bf16_t, bf16_t>(p, stream); break;
+  }
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}
+
 extern "C" int vl_layernorm_bwd(const void* dy, int dy_dtype, long dy_stride, const void* x, int x_dtype, long x_stride,
                                 const float* mean, const float* rstd, const float* w, const float* dres, float* dx,
                                 void* dx_bf16, long dx_stride, int rows, int D, hipStream_t stream) {
-  if (rows <= 0 || D <= 0) return vl_set_error("vl_layernorm_bwd: empty problem");
-  LnBwdP p{dy, x, mean, rstd, w, dres, dx, (bf16_t*)dx_bf16, dy_stride, x_stride, dx_stride, rows, D};
-  const dim3 g((rows + 3) / 4), b(256);
-  if (dy_dtype == VL_BF16 && x_dtype == VL_F32) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, float>), g, b, 0, stream, p);
-  else if (dy_dtype == VL_BF16) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t>), g, b, 0, stream, p);
-  else if (x_dtype == VL_F32) hipLaunchKernelGGL((ln_bwd_kernel<float, float>), g, b, 0, stream, p);
-  else hipLaunchKernelGGL((ln_bwd_kernel<float, bf16_t>), g, b, 0, stream, p);
-  VL_HIP_OK(hipGetLastError());
-  return 0;
+  return vl_layernorm_bwd_g(dy, dy_dtype, dy_stride, x, x_dtype, x_stride, mean, rstd, w, dres, dx, VL_F32, dx_bf16, dx_stride, rows, D, stream);
+}
+
+static const int kSlabRows = 256;
+extern "C" long vl_colreduce_ws_floats(int rows, int cols, int planes) {
+  return (long)((rows + kSlabRows - 1) / kSlabRows) * planes * cols;
 }
 
 extern "C" int vl_layernorm_bwd_params(const void* dy, int dy_dtype, long dy_stride, const void* x, int x_dtype, long x_stride,
                                        const float* mean, const float* rstd, float* dw, float* db, int rows, int D,
-                                       hipStream_t stream) {
+                                       float* ws, hipStream_t stream) {
   if (rows <= 0 || D <= 0) return vl_set_error("vl_layernorm_bwd_params: empty problem");
-  const int slab = 256;
-  const dim3 g((D + 255) / 256, (rows + slab - 1) / slab), b(256);
+  if (!ws) return vl_set_error("vl_layernorm_bwd_params: workspace of vl_colreduce_ws_floats(rows, D, 2) floats required");
+  const int slab = kSlabRows, nslab = (rows + slab - 1) / slab;
+  const dim3 g((D + 255) / 256, nslab), b(256);
   if (dy_dtype == VL_BF16 && x_dtype == VL_F32)
-    hipLaunchKernelGGL((ln_bwd_params_kernel<bf16_t, float>), g, b, 0, stream, (const bf16_t*)dy, dy_stride, (const float*)x, x_stride, mean, rstd, dw, db, rows, D, slab);
+    hipLaunchKernelGGL((ln_bwd_params_kernel<bf16_t, float>), g, b, 0, stream, (const bf16_t*)dy, dy_stride, (const float*)x, x_stride, mean, rstd, ws, rows, D, slab);
   else if (dy_dtype == VL_BF16)
-    hipLaunchKernelGGL((ln_bwd_params_kernel<bf16_t, bf16_t>), g, b, 0, stream, (const bf16_t*)dy, dy_stride, (const bf16_t*)x, x_stride, mean, rstd, dw, db, rows, D, slab);
+    hipLaunchKernelGGL((ln_bwd_params_kernel<bf16_t, bf16_t>), g, b, 0, stream, (const bf16_t*)dy, dy_stride, (const bf16_t*)x, x_stride, mean, rstd, ws, rows, D, slab);
   else if (x_dtype == VL_F32)
-    hipLaunchKernelGGL((ln_bwd_params_kernel<float, float>), g, b, 0, stream, (const float*)dy, dy_stride, (const float*)x, x_stride, mean, rstd, dw, db, rows, D, slab);
+    hipLaunchKernelGGL((ln_bwd_params_kernel<float, float>), g, b, 0, stream, (const float*)dy, dy_stride, (const float*)x, x_stride, mean, rstd, ws, rows, D, slab);
   else
-    hipLaunchKernelGGL((ln_bwd_params_kernel<float, bf16_t>), g, b, 0, stream, (const float*)dy, dy_stride, (const bf16_t*)x, x_stride, mean, rstd, dw, db, rows, D, slab);
+    hipLaunchKernelGGL((ln_bwd_params_kernel<float, bf16_t>), g, b, 0, stream, (const float*)dy, dy_stride, (const bf16_t*)x, x_stride, mean, rstd, ws, rows, D, slab);
+  hipLaunchKernelGGL(slab_finalize_kernel, dim3((D + 255) / 256), b, 0, stream, ws, nslab, 2, D, 1.0f, dw, db);
   VL_HIP_OK(hipGetLastError());
   return 0;
 }
 
-extern "C" int vl_colsum(const void* a, int a_dtype, long lda, float* out, int rows, int cols, float scale, hipStream_t stream) {
+extern "C" int vl_colsum(const void* a, int a_dtype, long lda, float* out, int rows, int cols, float scale, float* ws, hipStream_t stream) {
   if (rows <= 0 || cols <= 0) return vl_set_error("vl_colsum: empty problem");
-  const int slab = 256;
-  const dim3 g((cols + 255) / 256, (rows + slab - 1) / slab), b(256);
-  if (a_dtype == VL_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, g, b, 0, stream, (const bf16_t*)a, lda, out, rows, cols, slab, scale);
-  else hipLaunchKernelGGL(colsum_kernel<float>, g, b, 0, stream, (const float*)a, lda, out, rows, cols, slab, scale);
+  if (!ws) return vl_set_error("vl_colsum: workspace of vl_colreduce_ws_floats(rows, cols, 1) floats required");
+  const int slab = kSlabRows, nslab = (rows + slab - 1) / slab;
+  const dim3 g((cols + 255) / 256, nslab), b(256);
+  if (a_dtype == VL_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, g, b, 0, stream, (const bf16_t*)a, lda, ws, rows, cols, slab);
+  else hipLaunchKernelGGL(colsum_kernel<float>, g, b, 0, stream, (const float*)a, lda, ws, rows, cols, slab);
+  hipLaunchKernelGGL(slab_finalize_kernel, dim3((cols + 255) / 256), b, 0, stream, ws, nslab, 1, cols, scale, out, out);
   VL_HIP_OK(hipGetLastError());
   return 0;
 }

@@ -49,8 +49,9 @@ SIGNATURES = {
     "vl_group_sum": [P, L, P, L, L, I, I, P],
     "vl_gemm_qkv_bf16_ex": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, I, I, P],
     "vl_layernorm_bwd": [P, I, L, P, I, L, P, P, P, P, P, P, L, I, I, P],
-    "vl_layernorm_bwd_params": [P, I, L, P, I, L, P, P, P, P, I, I, P],
-    "vl_colsum": [P, I, L, P, I, I, F, P],
+    "vl_layernorm_bwd_g": [P, I, L, P, I, L, P, P, P, P, P, I, P, L, I, I, P],
+    "vl_layernorm_bwd_params": [P, I, L, P, I, L, P, P, P, P, I, I, P, P],
+    "vl_colsum": [P, I, L, P, I, I, F, P, P],
     "vl_gelu_bf16": [P, P, L, P],
     "vl_geglu_bf16": [P, P, L, I, P],
     "vl_attn_delta": [P, P, P, I, I, I, I, P],

@@ -238,20 +238,41 @@ def device_info(device=0):
 # ------------------------------------------------------------------------------------------------ backward
 def layernorm_bwd(dy, x, mean, rstd, w, rows, D, dres=None, dx=None, dx_bf16=None, x_row_stride=None,
                   dy_row_stride=None, dx_row_stride=None):
-    check(_lib.vl_layernorm_bwd(_p(dy), _dt(dy), D if dy_row_stride is None else dy_row_stride, _p(x), _dt(x),
-                                D if x_row_stride is None else x_row_stride, _p(mean), _p(rstd), _p(w), _p(dres),
-                                _p(dx), _p(dx_bf16), D if dx_row_stride is None else dx_row_stride, rows, D, _stream()))
+    """dx = dLN(dy) (+ dres).  dres / dx form the residual-gradient stream: f32 or bf16 (both the same dtype); dx_bf16 is
+    an optional extra bf16 copy (the next GEMM operand when the stream is f32)."""
+    g = dx if dx is not None else dres
+    gdt = F32 if g is None else _dt(g)
+    if dres is not None and dx is not None and dres.dtype != dx.dtype:
+        raise TypeError("layernorm_bwd: dres and dx must share a dtype")
+    check(_lib.vl_layernorm_bwd_g(_p(dy), _dt(dy), D if dy_row_stride is None else dy_row_stride, _p(x), _dt(x),
+                                  D if x_row_stride is None else x_row_stride, _p(mean), _p(rstd), _p(w), _p(dres),
+                                  _p(dx), gdt, _p(dx_bf16), D if dx_row_stride is None else dx_row_stride, rows, D, _stream()))
+
+
+_colreduce_ws = {}
+
+
+def _ws_for(device, rows, cols, planes):
+    """Workspace of the deterministic two-stage column reductions (cached per device, grown on demand)."""
+    need = ((rows + 255) // 256) * planes * cols
+    t = _colreduce_ws.get(device)
+    if t is None or t.numel() < need:
+        t = torch.empty(need, device=device, dtype=torch.float32)
+        _colreduce_ws[device] = t
+    return t
 
 
 def layernorm_bwd_params(dy, x, mean, rstd, dw, db, rows, D, x_row_stride=None, dy_row_stride=None):
+    ws = _ws_for(dy.device, rows, D, 2)
     check(_lib.vl_layernorm_bwd_params(_p(dy), _dt(dy), D if dy_row_stride is None else dy_row_stride, _p(x), _dt(x),
                                        D if x_row_stride is None else x_row_stride, _p(mean), _p(rstd), _p(dw), _p(db),
-                                       rows, D, _stream()))
+                                       rows, D, _p(ws), _stream()))
 
 
 def colsum(a, out, scale=1.0):
     _chk2d(a, "a")
-    check(_lib.vl_colsum(_p(a), _dt(a), a.stride(0), _p(out), a.shape[0], a.shape[1], float(scale), _stream()))
+    ws = _ws_for(a.device, a.shape[0], a.shape[1], 1)
+    check(_lib.vl_colsum(_p(a), _dt(a), a.stride(0), _p(out), a.shape[0], a.shape[1], float(scale), _p(ws), _stream()))
 
 
 def geglu_bf16(h, out):

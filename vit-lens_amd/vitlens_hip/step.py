@@ -106,14 +106,16 @@ class TriModalDepthStep:
     def __init__(self, sd: Dict[str, torch.Tensor], tower: TowerCfg, text: TextCfg, device, micro_batch: int = 256,
                  unlock_first_n: int = 4, lr: float = 5e-4, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2,
                  rank: int = 0, world_size: int = 1, gemm_cfg: int = -1, comm=None, frozen_res_dtype=torch.float32,
-                 local_loss: bool = False, gather_with_grad: bool = False):
+                 local_loss: bool = False, gather_with_grad: bool = False, train_res_dtype=torch.float32):
         self.dev, self.mb, self.rank, self.world = torch.device(device), micro_batch, rank, world_size
         self.comm = comm or TorchComm()
         self.local_loss, self.gather_with_grad = local_loss, gather_with_grad
         # frozen towers: forward only; their residual stream may be kept in bf16 (= the reference's autocast)
         self.image = VitEngine(sd, "image.", tower, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
         self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
-        self.lens = LensEngine(sd, "visual.", tower, LensCfg(modality="depth", perceiver_identity=True), device, gemm_cfg=gemm_cfg)
+        # trainable tower: residual stream AND residual-gradient stream in `train_res_dtype` (bf16 = the reference's amp_bf16)
+        self.lens = LensEngine(sd, "visual.", tower, LensCfg(modality="depth", perceiver_identity=True), device, gemm_cfg=gemm_cfg,
+                               res_dtype=train_res_dtype)
         self.trainers = []            # one activation store per micro-batch (created lazily)
         self.unlock_first_n = unlock_first_n
         self.logit_scale = sd["logit_scale"].detach().float().reshape(1).to(device)
@@ -339,11 +341,11 @@ class DualAudioStep(_PerceiverLensStep):
     def __init__(self, sd, tower: TowerCfg, text: TextCfg, lens: LensCfg, device, micro_batch: int = 256, lr: float = 2e-4,
                  betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2, rank: int = 0, world_size: int = 1,
                  gemm_cfg: int = -1, comm=None, frozen_res_dtype=torch.float32, local_loss: bool = False,
-                 gather_with_grad: bool = False):
+                 gather_with_grad: bool = False, train_res_dtype=torch.float32):
         from .train import AudioLensTrainer
         self._init_common(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad)
         self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
-        self.lens = LensEngine(sd, "visual.", tower, lens, device, gemm_cfg=gemm_cfg)
+        self.lens = LensEngine(sd, "visual.", tower, lens, device, gemm_cfg=gemm_cfg, res_dtype=train_res_dtype)
         self._mk = lambda: AudioLensTrainer(self.lens)
         self.masters["visual.class_embedding"] = self.lens.vit.cls
         self.masters["visual.visual_adapter.pos_emb"] = self.lens.adapter_pos
@@ -397,13 +399,14 @@ class TriModalPCStep(_PerceiverLensStep):
     def __init__(self, sd, tower: TowerCfg, text: TextCfg, lens: LensCfg, device, micro_batch: int = 32, lr: float = 2e-4,
                  betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2, rank: int = 0, world_size: int = 1,
                  gemm_cfg: int = -1, bn_training: bool = True, unlock_cls: bool = False, comm=None,
-                 frozen_res_dtype=torch.float32, local_loss: bool = False, gather_with_grad: bool = False):
+                 frozen_res_dtype=torch.float32, local_loss: bool = False, gather_with_grad: bool = False,
+                 train_res_dtype=torch.float32):
         from .points import PointTokenizerTrainer
         from .train import PCLensTrainer
         self._init_common(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad)
         self.image = VitEngine(sd, "image.", tower, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
         self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
-        self.lens = LensEngine(sd, "visual.", tower, lens, device, gemm_cfg=gemm_cfg)
+        self.lens = LensEngine(sd, "visual.", tower, lens, device, gemm_cfg=gemm_cfg, res_dtype=train_res_dtype)
         self.tok = PointTokenizerTrainer(sd, "visual.visual_adapter.", lens, device, gemm_cfg=gemm_cfg, bn_training=bn_training)
         self._mk = lambda: PCLensTrainer(self.lens, self.tok, train_cls=unlock_cls)
         if unlock_cls:

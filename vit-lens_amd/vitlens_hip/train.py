@@ -22,14 +22,15 @@ BF = torch.bfloat16
 class _Saved:
     """Per-(B, L) activation store: residual-stream snapshots and attention operands of every block."""
 
-    def __init__(self, B, L, D, H, hidden, layers, device):
+    def __init__(self, B, L, D, H, hidden, layers, device, res_dtype=torch.float32):
         dh = D // H
         T = B * L
         Lp = (L + 7) // 8 * 8
         f32 = lambda *s: torch.empty(*s, device=device, dtype=torch.float32)
         bf = lambda *s: torch.empty(*s, device=device, dtype=BF)
         self.Lp = Lp
-        self.X = [f32(T, D) for _ in range(2 * layers + 1)]           # X[2l]=block input, X[2l+1]=after attention
+        xres = f32 if res_dtype == torch.float32 else bf
+        self.X = [xres(T, D) for _ in range(2 * layers + 1)]          # X[2l]=block input, X[2l+1]=after attention
         self.stats = [[f32(T) for _ in range(4)] for _ in range(layers)]   # mean1, rstd1, mean2, rstd2
         self.q = [bf(B, H, L, dh) for _ in range(layers)]
         self.k = [bf(B, H, L, dh) for _ in range(layers)]
@@ -45,7 +46,10 @@ class _Saved:
         self.post_stats = [f32(B), f32(B)]
         self.pooled = bf(B, D)
         # backward temporaries
-        self.dx = f32(T, D); self.dxb = bf(T, D); self.du = bf(T, hidden); self.dh = bf(T, D)
+        # residual-gradient stream in the residual dtype (the reference's autocast: bf16 activations -> bf16 gradients);
+        # with an f32 stream the GEMM operand is a separate bf16 copy
+        self.dx = xres(T, D); self.dxb = bf(T, D) if res_dtype == torch.float32 else self.dx
+        self.du = bf(T, hidden); self.dh = bf(T, D)
         self.dO = bf(B, H, L, dh); self.dOt = torch.zeros(B, H, dh, Lp, device=device, dtype=BF)
         self.delta = f32(B, H, L); self.dqkv = bf(T, 3 * D)
 
@@ -70,7 +74,7 @@ class TowerTrainer:
     def saved(self, B, L):
         key = (B, L)
         if key not in self._saved:
-            self._saved[key] = _Saved(B, L, self.D, self.H, self.hidden, self.layers, self.eng.device)
+            self._saved[key] = _Saved(B, L, self.D, self.H, self.hidden, self.layers, self.eng.device, self.eng.res_dtype)
         return self._saved[key]
 
     def grad_buffer(self, name, like):
@@ -93,6 +97,7 @@ class TowerTrainer:
         dh = D // H
         S = self.saved(B, L)
         cfg = e.gemm_cfg
+        res_epi = ops.EPI_RES_F32 if e.res_dtype == torch.float32 else ops.EPI_RES_BF16
         ops.assemble_ln_pre(tokens, e.cls, e.pos, pos2, e.ln_pre[0], e.ln_pre[1], S.X[0], B, T, D,
                             xpre=S.xpre, mean=S.pre_stats[0], rstd=S.pre_stats[1])
         for l, w in enumerate(e.blocks):
@@ -101,10 +106,10 @@ class TowerTrainer:
             ops.gemm_qkv(S.h, w["in_w"], w["in_b"], S.q[l], S.k[l], S.vt, B, L, H, dh, cfg=cfg,
                          qt=S.qt[l], kt=S.kt[l], v=S.v[l])
             ops.attn_fwd(S.q[l], S.k[l], S.vt, S.a[l], lse=S.lse[l])
-            ops.gemm(S.a[l], w["out_w"], w["out_b"], out=S.X[2 * l + 1], res=S.X[2 * l], epi=ops.EPI_RES_F32, cfg=cfg)
+            ops.gemm(S.a[l], w["out_w"], w["out_b"], out=S.X[2 * l + 1], res=S.X[2 * l], epi=res_epi, cfg=cfg)
             ops.layernorm(S.X[2 * l + 1], w["ln2_w"], w["ln2_b"], S.h, B * L, D, mean=m2, rstd=r2)
             ops.gemm(S.h, w["fc_w"], w["fc_b"], out=S.hid, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg, out2=S.u[l])
-            ops.gemm(S.hid, w["proj_w"], w["proj_b"], out=S.X[2 * l + 2], res=S.X[2 * l + 1], epi=ops.EPI_RES_F32, cfg=cfg)
+            ops.gemm(S.hid, w["proj_w"], w["proj_b"], out=S.X[2 * l + 2], res=S.X[2 * l + 1], epi=res_epi, cfg=cfg)
         xl = S.X[2 * self.layers]
         ops.layernorm(xl, e.ln_post[0], e.ln_post[1], S.pooled, B, D, x_row_stride=L * D,
                       mean=S.post_stats[0], rstd=S.post_stats[1])
@@ -141,7 +146,10 @@ class TowerTrainer:
         # only the cls rows (row b*L) of the final residual receive gradient: write them in place
         ops.layernorm_bwd(dpooled, S.X[2 * self.layers], S.post_stats[0], S.post_stats[1], e.ln_post[0], B, D,
                           dx=S.dx, x_row_stride=L * D, dx_row_stride=L * D)
-        ops.cast_bf16(S.dx, out=S.dxb)
+        f32_stream = S.dx.dtype == torch.float32
+        dxb_out = S.dxb if f32_stream else None
+        if f32_stream:
+            ops.cast_bf16(S.dx, out=S.dxb)
         for l in reversed(range(self.layers)):
             w, wT = e.blocks[l], self.wT[l]
             m1, r1, m2, r2 = S.stats[l]
@@ -158,7 +166,7 @@ class TowerTrainer:
             if trainable:
                 ops.layernorm_bwd_params(S.dh, S.X[2 * l + 1], m2, r2, self.grad_buffer(bp + "ln_2.weight", w["ln2_w"]),
                                          self.grad_buffer(bp + "ln_2.bias", w["ln2_b"]), rows, D)
-            ops.layernorm_bwd(S.dh, S.X[2 * l + 1], m2, r2, w["ln2_w"], rows, D, dres=S.dx, dx=S.dx, dx_bf16=S.dxb)
+            ops.layernorm_bwd(S.dh, S.X[2 * l + 1], m2, r2, w["ln2_w"], rows, D, dres=S.dx, dx=S.dx, dx_bf16=dxb_out)
             # ---- attention branch: x1 = x0 + out(attn(qkv(ln1(x0)))) ----
             if trainable:
                 self._dw(bp + "attn.out_proj.weight", S.dx, S.a[l], rows); self._db(bp + "attn.out_proj.bias", S.dx)
@@ -174,9 +182,9 @@ class TowerTrainer:
             if trainable:
                 ops.layernorm_bwd_params(S.dh, S.X[2 * l], m1, r1, self.grad_buffer(bp + "ln_1.weight", w["ln1_w"]),
                                          self.grad_buffer(bp + "ln_1.bias", w["ln1_b"]), rows, D)
-            ops.layernorm_bwd(S.dh, S.X[2 * l], m1, r1, w["ln1_w"], rows, D, dres=S.dx, dx=S.dx, dx_bf16=S.dxb)
+            ops.layernorm_bwd(S.dh, S.X[2 * l], m1, r1, w["ln1_w"], rows, D, dres=S.dx, dx=S.dx, dx_bf16=dxb_out)
         # ---- ln_pre and the [cls; tokens] + pos assembly ----
-        dxpre = torch.empty_like(S.dx)
+        dxpre = torch.empty(S.dx.shape, device=S.dx.device, dtype=torch.float32)
         ops.layernorm_bwd(S.dx, S.xpre, S.pre_stats[0], S.pre_stats[1], e.ln_pre[0], rows, D, dx=dxpre)
         if self.train_cls:
             ops.batch_rowsum(dxpre, self.grad_buffer(P + "class_embedding", e.cls).view(1, D), B, 1, D, L, 0)
