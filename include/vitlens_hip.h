@@ -139,6 +139,11 @@ int vl_add_rows(const void* x, int x_dtype, const float* table, void* y, int y_d
                 hipStream_t stream);
 /* out[c,r] bf16 = in[r,c]; columns r in [R, ldo) zero-filled (operand prep for gradient GEMMs) */
 int vl_transpose_to_bf16(const void* in, int in_dtype, long ldi, int R, int C, void* out, long ldo, hipStream_t stream);
+/* The same for the weight-gradient path (C % 64 == 0, ldo % 8 == 0, ldi % 8 == 0, 16-byte aligned pointers), optionally
+ * fused with the bias gradient: colsum_out[c] += colsum_scale * sum_r in[r, c] (deterministic two-stage sum; ws =
+ * ceil(ldo/256)*C floats).  Autograd counterpart of nn.Linear's dW operands and bias gradient. */
+int vl_transpose_colsum_bf16(const void* in, int in_dtype, long ldi, int R, int C, void* out, long ldo,
+                             float* colsum_out, float colsum_scale, float* ws, hipStream_t stream);
 
 /* InfoNCE pieces over logits f32 [R,C] (row r's positive is column r+label_off):
  *   vl_ce_stats      row_lse[R], col_lse[C], diag[R]; col_ws = 2*ceil(R/64)*C floats of workspace

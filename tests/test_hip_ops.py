@@ -276,7 +276,28 @@ def test_transpose_to_bf16():
     assert float(t[:, 70:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 128, 8192), (128, 64, 65536), (512, 256, 4096 + 64), (1024, 4096, 2048)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,C,ldo", [(257 * 8, 1024, 257 * 8), (1000, 192, 1024), (300, 64, 320)])
+def test_transpose_colsum_fused(R, C, ldo, dt):
+    """Transpose for the dW operands fused with the bias gradient: exact transposed bf16 copy, zero pad columns, and a
+    deterministic (bit-reproducible) column sum accumulated into the destination."""
+    ops = _ops()
+    x = rnd(R, C, seed=28).to(dt).cuda()
+    cs = torch.full((C,), 3.0, device="cuda")
+    t = ops.transpose_colsum(x, ldo, colsum_out=cs, scale=0.5)
+    assert t.shape == (C, ldo)
+    assert torch.equal(t[:, :R].cpu(), x.cpu().t().bfloat16())
+    if ldo > R:
+        assert float(t[:, R:].abs().max()) == 0.0
+    ref = 3.0 + 0.5 * x.bfloat16().float().cpu().sum(0)
+    assert relerr(cs, ref) < 1e-5, relerr(cs, ref)
+    cs2 = torch.full((C,), 3.0, device="cuda")
+    ops.transpose_colsum(x, ldo, colsum_out=cs2, scale=0.5)
+    assert torch.equal(cs, cs2)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 8192), (128, 64, 65536), (512, 256, 4096 + 64), (1024, 4096, 2048),
+                                   (1024, 1024, 257 * 256), (4096, 1024, 64 * 256), (3072, 1024, 4096)])
 def test_gemm_dw_splitk_accumulates(M, N, K):
     """Weight-gradient GEMM g += dyT @ xT^T: the split-K path (few tiles, long K) and the plain accumulate path give the
     fp32 product of the bf16 operands added to the existing contents; strided destination views are honoured."""

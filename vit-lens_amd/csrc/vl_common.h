@@ -39,26 +39,32 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): far below the bf16 output
-// resolution of the GELU epilogue and ~3x cheaper than erff().
-__device__ __forceinline__ float erf_as(float x) {
+// GELU(x) = x*Phi(x) and its derivative from ONE shared evaluation of q(t)*exp(-x^2/2) (A&S 7.1.26 with the 1/2 folded
+// into the coefficients, |abs err| <= 4e-7): 13 / 15 VALU instructions per element instead of 17 / 24 - the activation
+// arithmetic is 15-30 % of a K = 1024 GEMM's epilogue-inclusive time.
+//   x >= 0: Phi = 1 - h, x < 0: Phi = h, with h = q(t) e^{-x^2/2}, t = 1 / (1 + p|x|/sqrt 2)
+//   gelu  = max(x, 0) - |x| h                gelu' = [x >= 0] + e^{-x^2/2} (x / sqrt(2 pi) - sign(x) q(t))
+struct GeluParts { float q, e; };
+__device__ __forceinline__ GeluParts gelu_parts(float x) {
   const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  p *= t;
-  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
-  const float r = fmaf(-p, e, 1.0f);
-  return copysignf(r, x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.23164190f, ax, 1.0f));          // 0.3275911 / sqrt(2)
+  float p = fmaf(0.5307027145f, t, -0.7265760135f);                            // 0.5 * (a5, a4, a3, a2, a1)
+  p = fmaf(p, t, 0.7107068705f);
+  p = fmaf(p, t, -0.142248368f);
+  p = fmaf(p, t, 0.127414796f);
+  const float zs = x * 0.84932180f;                                            // sqrt(0.5 * log2 e)
+  GeluParts r;
+  r.q = p * t;
+  r.e = __builtin_amdgcn_exp2f(-(zs * zs));
+  return r;
 }
 __device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f));
+  const GeluParts g = gelu_parts(x);
+  return fmaf(-(fabsf(x) * g.q), g.e, fmaxf(x, 0.0f));
 }
 // d/dx gelu(x) = Phi(x) + x*phi(x)
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-  return fmaf(x, pdf, cdf);
+  const GeluParts g = gelu_parts(x);
+  const float step = (__builtin_bit_cast(int, x) >= 0) ? 1.0f : 0.0f;           // by the sign BIT: consistent with copysign at +-0
+  return fmaf(g.e, fmaf(0.3989422804014327f, x, -copysignf(g.q, x)), step);
 }

@@ -943,6 +943,18 @@ extern "C" int vl_gemm_splitk_accum_f32(const void* A, const void* W, float* out
   GemmP p{};
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.out = ws; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldo = N;
   p.alpha = alpha; p.res_div = 1;
+  p.split_stride = (long)M * N;
+  if (nk % splits == 0) {       // whole 256x256 tiles and equal slices: the round-2 persistent kernel writes the partials
+    p.ksplit_len = nk / splits;
+    if (vl_gemm_park_supported(EPI_F32, &p)) {
+      hipError_t e = (hipError_t)vl_gemm_park_launch(EPI_F32, &p, num_cus(), stream);
+      if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)M * (N >> 2) + 255) / 256)), dim3(256), 0, stream, ws, splits, M, N, out, ldo);
+      e = hipGetLastError();
+      if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
+      return 0;
+    }
+  }
   p.ksplit_len = (nk + splits - 1) / splits;
   const int eff = (nk + p.ksplit_len - 1) / p.ksplit_len;
   p.split_stride = (long)M * N;

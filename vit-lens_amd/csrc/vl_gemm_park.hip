@@ -54,12 +54,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   constexpr int SLAB = 4096;                 // wave-private transpose slab: 32 rows x 64 columns bf16
 
   const int tiles_n = p.N >> 8, tiles_m = p.M >> 8;
-  const int ntiles = tiles_m * tiles_n;
+  // split-K (EPI_F32 only: weight gradients, few output tiles and a very long reduction): work item = (k-slice, tile),
+  // slice sp reduces k-steps [sp*nk, (sp+1)*nk) and writes its partial product to out + sp*split_stride
+  const int nk = (EPI == EPI_F32 && p.ksplit_len) ? p.ksplit_len : (p.K >> 6);
+  const int ntiles_mn = tiles_m * tiles_n;
+  const int ntiles = ntiles_mn * ((EPI == EPI_F32 && p.ksplit_len) ? (p.K >> 6) / p.ksplit_len : 1);
   const int G = gridDim.x;
   const int slot = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
   if (slot >= ntiles) return;
   const int my_tiles = (ntiles - slot + G - 1) / G;
-  const int nk = p.K >> 6;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -70,8 +73,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int fsw = (fr >> 1) & 7;
 
   // tile order: groups of PK_GN consecutive N-tiles, M fastest inside a group, each XCD owns a contiguous run per round
-  auto tile_origin = [&](int ti, int& m0, int& n0) {
-    const int v = ti * G + slot;
+  auto tile_origin = [&](int ti, int& m0, int& n0, int& sp) {
+    int v = ti * G + slot;
+    sp = 0;
+    if constexpr (EPI == EPI_F32) { sp = v / ntiles_mn; v -= sp * ntiles_mn; }
     const int gsz = PK_GN * tiles_m;
     const int gid = v / gsz, rem = v - gid * gsz;
     const int first_n = gid * PK_GN;
@@ -86,9 +91,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   const unsigned voffA = (unsigned)(drow * p.lda * 2 + dsw), voffW = (unsigned)(drow * p.ldw * 2 + dsw);
   const int a_unit = p.lda * 128, w_unit = p.ldw * 128;            // bytes between units (64 rows)
   __amdgpu_buffer_rsrc_t rsA, rsW;
-  auto make_rsrc = [&](int m0, int n0, __amdgpu_buffer_rsrc_t& ra, __amdgpu_buffer_rsrc_t& rw) {
-    ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)m0 * p.lda), 0, 0x7ffffff0, 0x00020000);
-    rw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)n0 * p.ldw), 0, 0x7ffffff0, 0x00020000);
+  auto make_rsrc = [&](int m0, int n0, int sp, __amdgpu_buffer_rsrc_t& ra, __amdgpu_buffer_rsrc_t& rw) {
+    const size_t k0 = (size_t)sp * nk * 64;        // first reduction index of the slice
+    ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)m0 * p.lda + k0), 0, 0x7ffffff0, 0x00020000);
+    rw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)n0 * p.ldw + k0), 0, 0x7ffffff0, 0x00020000);
   };
 
   // ---- fragments (two sets: the reads of substep s+1 are in flight under the MFMAs of substep s) ----
@@ -135,8 +141,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
   };
 
-  int cur_m0, cur_n0;
-  tile_origin(0, cur_m0, cur_n0);
+  int cur_m0, cur_n0, cur_sp;
+  tile_origin(0, cur_m0, cur_n0, cur_sp);
   auto set_aux = [&]() {
     if constexpr (HAS_AUX) {
       // EPI_RES_BF16 indexes its residual by the absolute row (m + m_off) with an un-offset pointer (vl_gemm.hip run_gemm)
@@ -144,7 +150,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       aux_src = (const unsigned char*)p.res + ((size_t)(cur_m0 + moff + wave_m * 128) * p.ldo + cur_n0 + wave_n * WTN) * 2;
     }
   };
-  make_rsrc(cur_m0, cur_n0, rsA, rsW);
+  make_rsrc(cur_m0, cur_n0, cur_sp, rsA, rsW);
   // DMA position (dti, dkt) = the step whose operands the next DMA batch loads; it runs two k-steps ahead of the MFMAs and
   // therefore enters the next tile at kt = nk-2: that tile's descriptors are prepared once per tile, outside the k-loop
   __amdgpu_buffer_rsrc_t rsA_n = rsA, rsW_n = rsW;
@@ -203,9 +209,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
   for (int ti = 0; ti < my_tiles; ++ti) {
     if (ti + 1 < my_tiles) {
-      int nm0, nn0;
-      tile_origin(ti + 1, nm0, nn0);
-      make_rsrc(nm0, nn0, rsA_n, rsW_n);
+      int nm0, nn0, nsp;
+      tile_origin(ti + 1, nm0, nn0, nsp);
+      make_rsrc(nm0, nn0, nsp, rsA_n, rsW_n);
     }
     set_aux();
     for (int kt = 0; kt < nk - 1; ++kt) kstep(std::false_type{});
@@ -240,6 +246,28 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       } else {
         out_base = (unsigned char*)pe.out + ((size_t)mrow0 * pe.ldo + ncol0) * 2 + lo_out;
       }
+      if constexpr (EPI == EPI_F32) {
+        // fp32 partial product of a k-slice: 32x32 blocks through the slab, 16-byte stores (8 lanes per 128-byte line)
+        float* const fout = (float*)pe.out + (size_t)cur_sp * pe.split_stride + (size_t)mrow0 * pe.ldo + ncol0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int j = 0; j < NTL; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              f32x4 v = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+              *(f32x4*)(slab + fr * 128 + (((q * 2 + fg) ^ wsw) << 4)) = v * pe.alpha;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+              const int r = pass * 8 + prow;
+              const f32x4 w = *(const f32x4*)(slab + r * 128 + (((lane & 7) ^ (r & 7)) << 4));
+              __builtin_nontemporal_store(w, (f32x4*)(fout + (size_t)(i * 32 + r) * pe.ldo + j * 32 + (lane & 7) * 4));
+            }
+          }
+        }
+      } else
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -323,7 +351,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
       }
       zero_acc();
-      if (ti + 1 < my_tiles) { tile_origin(ti + 1, cur_m0, cur_n0); ldfrag(smem + par * PK_STAGE, 0, 0); }
+      if (ti + 1 < my_tiles) { tile_origin(ti + 1, cur_m0, cur_n0, cur_sp); ldfrag(smem + par * PK_STAGE, 0, 0); }
     }
   }
 }
@@ -333,7 +361,7 @@ hipError_t launch_pk(const GemmP& p, int ncu, hipStream_t s) {
   auto kern = gemm_nt_pk_kernel<EPI, ACT>;
   static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PK_LDS);   // thread-safe one-time init
   if (attr != hipSuccess) return attr;
-  const int tiles = (p.M >> 8) * (p.N >> 8);
+  const int tiles = (p.M >> 8) * (p.N >> 8) * ((EPI == EPI_F32 && p.ksplit_len) ? (p.K >> 6) / p.ksplit_len : 1);
   int G = ncu & ~7;
   if (tiles < G) G = (tiles + 7) & ~7;
   hipLaunchKernelGGL(kern, dim3(G), dim3(512), PK_LDS, s, p);
@@ -345,6 +373,12 @@ hipError_t launch_pk(const GemmP& p, int ncu, hipStream_t s) {
 // Internal entries used by vl_gemm.hip's dispatcher (not part of the public C ABI).
 bool vl_gemm_park_supported(int epi, const void* params) {
   const GemmP& p = *(const GemmP*)params;
+  if (epi == EPI_F32) {       // split-K partial products into a workspace (vl_gemm_splitk_accum_f32)
+    if ((p.M & 255) || (p.N & 255) || (p.K & 63) || p.M <= 0 || p.N <= 0 || (p.ldo & 3) || p.bias) return false;
+    const int nk = p.K >> 6;
+    if (p.ksplit_len < 2 || nk % p.ksplit_len) return false;
+    return !((((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.out) & 15));
+  }
   if (!(epi == EPI_BF16 || epi == EPI_RES_BF16 || epi == EPI_DGELU || epi == EPI_QKV)) return false;
   // whole tiles; the DMA prologue issues two k-steps of tile 0 up front
   if ((p.M & 255) || (p.N & 255) || (p.K & 63) || p.K < 512 || p.M <= 0 || p.N <= 0) return false;
@@ -368,6 +402,7 @@ int vl_gemm_park_launch(int epi, const void* params, int ncu, hipStream_t s) {
     case EPI_RES_BF16: return (int)launch_pk<EPI_RES_BF16, 0>(p, ncu, s);
     case EPI_DGELU: return (int)launch_pk<EPI_DGELU, 0>(p, ncu, s);
     case EPI_QKV: return (int)launch_pk<EPI_QKV, 0>(p, ncu, s);
+    case EPI_F32: return (int)launch_pk<EPI_F32, 0>(p, ncu, s);
     default: return (int)hipErrorInvalidValue;
   }
 }

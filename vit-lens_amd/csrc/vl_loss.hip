@@ -139,7 +139,8 @@ __global__ void __launch_bounds__(256) l2norm_bwd_kernel(const float* f, const f
   for (int e = lane; e < D; e += 64) dx[(long)row * D + e] = (dr[e] - fr[e] * s) * inv;
 }
 
-// out[c, r] (bf16, ld) = in[r, c] (f32 or bf16) ; pads columns r in [R, ld) with zeros
+// out[c, r] (bf16, ld) = in[r, c] (f32 or bf16) ; pads columns r in [R, ld) with zeros.  Generic small-tile version
+// (any R, C); the weight-gradient path uses transpose64_kernel below.
 template <typename TIN>
 __global__ void __launch_bounds__(256) transpose_bf16_kernel(const TIN* in, long ldi, int R, int C, bf16_t* out, long ldo) {
   __shared__ float tile[32][33];
@@ -161,6 +162,81 @@ __global__ void __launch_bounds__(256) transpose_bf16_kernel(const TIN* in, long
     const int c = c0 + ty + k * 8, r = r0 + tx;
     if (c < C && r < ldo) out[(long)c * ldo + r] = f2bf(tile[tx][ty + k * 8]);
   }
+}
+
+// Transpose for the weight-gradient GEMMs (dW = dY^T X needs both operands with the token axis contiguous), fused with
+// the bias gradient: a block owns 64 columns x 256 rows (four 64x64 tiles), reads with 16-byte loads, goes through an
+// XOR-swizzled 8 KB LDS tile (conflict-free both ways), writes whole 128-byte lines of the transposed matrix
+// (8 lanes x 16 bytes), and - if `colws` is given - leaves the column sums of its 256 rows in colws[blockIdx.y][C]
+// (stage 1 of the deterministic two-stage bias-gradient reduction; no separate pass over dY).
+// Requires C % 64 == 0 and ldo % 8 == 0; rows beyond R read as zero (the pad columns of the output).
+template <typename TIN>
+__global__ void __launch_bounds__(256) transpose64_kernel(const TIN* in, long ldi, int R, int C, bf16_t* out, long ldo, float* colws) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 64];
+  const int c0 = blockIdx.x * 64;
+  const int t = threadIdx.x;
+  const int lrow = t >> 3, lch = t & 7;                 // load: row (0..31, +32), 16-byte chunk of 8 columns
+  const int gch = t & 7, gc = t >> 3;                   // gather: row chunk (8 rows), column (0..31, +32)
+  float csum[2] = {0.f, 0.f};
+  for (int rt = 0; rt < 4; ++rt) {
+    const int r0 = blockIdx.y * 256 + rt * 64;
+    if (r0 >= ldo) break;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = lrow + 32 * h;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (r0 + r < R) {
+        if constexpr (sizeof(TIN) == 2) {
+          v = *(const u32x4*)((const bf16_t*)in + (long)(r0 + r) * ldi + c0 + lch * 8);
+        } else {
+          const f32x4 a = *(const f32x4*)((const float*)in + (long)(r0 + r) * ldi + c0 + lch * 8);
+          const f32x4 b = *(const f32x4*)((const float*)in + (long)(r0 + r) * ldi + c0 + lch * 8 + 4);
+          v[0] = pack2bf(a[0], a[1]); v[1] = pack2bf(a[2], a[3]); v[2] = pack2bf(b[0], b[1]); v[3] = pack2bf(b[2], b[3]);
+        }
+      }
+      *(u32x4*)(tile + r * 64 + ((lch ^ ((r >> 3) & 7)) << 3)) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = gc + 32 * h;
+      unsigned int w[4];
+      float sacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = gch * 8 + j;
+        const bf16_t e = tile[r * 64 + ((((c >> 3) ^ gch) << 3) | (c & 7))];       // (r >> 3) & 7 == gch
+        sacc += bf2f(e);
+        if (j & 1) w[j >> 1] |= ((unsigned int)e) << 16; else w[j >> 1] = e;
+      }
+      if (r0 + gch * 8 < ldo) {
+        const u32x4 o = {w[0], w[1], w[2], w[3]};
+        *(u32x4*)(out + (long)(c0 + c) * ldo + r0 + gch * 8) = o;
+      }
+      // sum over the 8 row chunks = the 8 lanes of this column
+      sacc += __shfl_xor(sacc, 1, 64); sacc += __shfl_xor(sacc, 2, 64); sacc += __shfl_xor(sacc, 4, 64);
+      csum[h] += sacc;
+    }
+    __syncthreads();
+  }
+  if (colws && gch == 0) {
+    colws[(long)blockIdx.y * C + c0 + gc] = csum[0];
+    colws[(long)blockIdx.y * C + c0 + gc + 32] = csum[1];
+  }
+}
+
+// out[j] += scale * sum_s ws[s][j], fixed order, 8 independent partial sums in flight per thread
+__global__ void __launch_bounds__(256) colws_finalize_kernel(const float* ws, int nslab, int C, float scale, float* out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= C) return;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 8 <= nslab; s += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += ws[(long)(s + u) * C + j];
+  }
+  for (; s < nslab; ++s) a[0] += ws[(long)s * C + j];
+  out[j] += (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) * scale;
 }
 
 // x f32 [R,D] -> bf16 [R,3D]: hi = bf16(x), lo = bf16(x - hi);  pattern 0: [hi|lo|hi], 1: [hi|hi|lo].
@@ -229,9 +305,26 @@ extern "C" int vl_l2_normalize_bwd(const float* f, const float* df, const float*
   return 0;
 }
 
+extern "C" int vl_transpose_colsum_bf16(const void* in, int in_dtype, long ldi, int R, int C, void* out, long ldo,
+                                        float* colsum_out, float colsum_scale, float* ws, hipStream_t stream) {
+  if (R <= 0 || C <= 0) return vl_set_error("vl_transpose_colsum_bf16: empty problem");
+  if (ldo < R || (ldo & 7) || (C & 63) || (ldi & 7)) return vl_set_error("vl_transpose_colsum_bf16: need ldo >= R, ldo % 8 == 0, C % 64 == 0, ldi % 8 == 0");
+  if (colsum_out && !ws) return vl_set_error("vl_transpose_colsum_bf16: colsum needs a workspace of ceil(ldo/256)*C floats");
+  const int nslab = (int)((ldo + 255) / 256);
+  const dim3 g(C / 64, nslab);
+  float* cw = colsum_out ? ws : nullptr;
+  if (in_dtype == VL_F32) hipLaunchKernelGGL(transpose64_kernel<float>, g, dim3(256), 0, stream, (const float*)in, ldi, R, C, (bf16_t*)out, ldo, cw);
+  else hipLaunchKernelGGL(transpose64_kernel<bf16_t>, g, dim3(256), 0, stream, (const bf16_t*)in, ldi, R, C, (bf16_t*)out, ldo, cw);
+  if (colsum_out) hipLaunchKernelGGL(colws_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, ws, nslab, C, colsum_scale, colsum_out);
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}
+
 extern "C" int vl_transpose_to_bf16(const void* in, int in_dtype, long ldi, int R, int C, void* out, long ldo, hipStream_t stream) {
   if (R <= 0 || C <= 0) return vl_set_error("vl_transpose_to_bf16: empty problem");
   if (ldo < R) return vl_set_error("vl_transpose_to_bf16: ldo < R");
+  if (R >= 256 && !(ldo & 7) && !(C & 63) && !(ldi & 7) && !(((uintptr_t)in | (uintptr_t)out) & 15))
+    return vl_transpose_colsum_bf16(in, in_dtype, ldi, R, C, out, ldo, nullptr, 0.f, nullptr, stream);
   const dim3 g((C + 31) / 32, (int)((ldo + 31) / 32));
   if (in_dtype == VL_F32) hipLaunchKernelGGL(transpose_bf16_kernel<float>, g, dim3(256), 0, stream, (const float*)in, ldi, R, C, (bf16_t*)out, ldo);
   else hipLaunchKernelGGL(transpose_bf16_kernel<bf16_t>, g, dim3(256), 0, stream, (const bf16_t*)in, ldi, R, C, (bf16_t*)out, ldo);

@@ -33,6 +33,7 @@ SIGNATURES = {
     "vl_cast_f32_bf16": [P, P, L, P],
     "vl_add_rows": [P, I, P, P, I, L, I, I, P],
     "vl_transpose_to_bf16": [P, I, L, I, I, P, L, P],
+    "vl_transpose_colsum_bf16": [P, I, L, I, I, P, L, P, F, P, P],
     "vl_split_bf16x3": [P, P, L, I, I, P],
     "vl_ce_stats": [P, L, I, I, I, P, P, P, P, P],
     "vl_ce_loss_accum": [P, P, P, I, I, I, F, F, P, P],

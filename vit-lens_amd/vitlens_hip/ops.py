@@ -80,8 +80,17 @@ def gemm_dw(dyt, xt, g, cfg=-1, alpha=1.0):
     _chk2d(dyt, "dyt", torch.bfloat16); _chk2d(xt, "xt", torch.bfloat16); _chk2d(g, "g", torch.float32)
     M, K = dyt.shape
     N = xt.shape[0]
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
     nk = K // 64
+    if K % 64 == 0 and M % 256 == 0 and N % 256 == 0 and nk >= 64:
+        # whole 256x256 tiles: k-slices on the persistent kernel (fp32 partials + fixed-order reduce)
+        t256 = (M // 256) * (N // 256)
+        for splits in (1, 2, 4, 8, 16):
+            if nk % splits == 0 and t256 * splits >= 192 and nk // splits >= 16:
+                ws = torch.empty(splits * M * N, device=g.device, dtype=torch.float32)
+                check(_lib.vl_gemm_splitk_accum_f32(_p(dyt), _p(xt), _p(g), M, N, K, dyt.stride(0), xt.stride(0), g.stride(0),
+                                                    float(alpha), splits, _p(ws), _stream()))
+                return g
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if K % 64 == 0 and tiles * 2 <= 256 and nk >= 32:
         splits = max(1, min(512 // tiles, nk // 16))
         if splits > 1:
@@ -188,6 +197,25 @@ def transpose_to_bf16(x, ldo=None, out=None):
     if out is None:
         out = torch.empty(Cc, ldo, device=x.device, dtype=torch.bfloat16)
     check(_lib.vl_transpose_to_bf16(_p(x), _dt(x), x.stride(0), R, Cc, _p(out), ldo, _stream()))
+    return out
+
+
+def transpose_colsum(x, ldo, colsum_out=None, scale=1.0, out=None):
+    """x [R,C] -> bf16 [C, ldo] (as transpose_to_bf16) and, fused, colsum_out[c] += scale * sum_r x[r, c] (bias gradient).
+    Falls back to the separate kernels when the shape does not fit the fused one."""
+    _chk2d(x, "x")
+    R, Cc = x.shape
+    ok = Cc % 64 == 0 and ldo % 8 == 0 and x.stride(0) % 8 == 0 and R >= 256 and x.data_ptr() % 16 == 0
+    if not ok:
+        out = transpose_to_bf16(x, ldo=ldo, out=out)
+        if colsum_out is not None:
+            colsum(x, colsum_out, scale)
+        return out
+    if out is None:
+        out = torch.empty(Cc, ldo, device=x.device, dtype=torch.bfloat16)
+    ws = _ws_for(x.device, ldo, Cc, 1) if colsum_out is not None else None
+    check(_lib.vl_transpose_colsum_bf16(_p(x), _dt(x), x.stride(0), R, Cc, _p(out), ldo, _p(colsum_out), float(scale), _p(ws),
+                                        _stream()))
     return out
 
 

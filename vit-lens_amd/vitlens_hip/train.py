@@ -118,17 +118,15 @@ class TowerTrainer:
         return feat
 
     # ------------------------------------------------------------------------------------------ backward
-    def _dw(self, name, dy, x, rows):
-        """grads[name] += dy^T x  (dy [rows, N], x [rows, K] -> [N, K]); operands transposed to bf16."""
+    def _dw(self, name, dy, x, rows, bias_name=None):
+        """grads[name] += dy^T x  (dy [rows, N], x [rows, K] -> [N, K]); operands transposed to bf16.  The bias gradient
+        (column sums of dy) is produced by the transpose of dy, which reads all of dy anyway."""
         g = self.grad_buffer(name, torch.empty(dy.shape[1], x.shape[1]))
         rp = (rows + 63) // 64 * 64
-        dyt = ops.transpose_to_bf16(dy, ldo=rp)
-        xt = ops.transpose_to_bf16(x, ldo=rp)
+        gb = self.grad_buffer(bias_name, torch.empty(dy.shape[1])) if bias_name else None
+        dyt = ops.transpose_colsum(dy, rp, colsum_out=gb)
+        xt = ops.transpose_colsum(x, rp)
         ops.gemm_dw(dyt, xt, g, cfg=self.eng.gemm_cfg)
-
-    def _db(self, name, dy):
-        g = self.grad_buffer(name, torch.empty(dy.shape[1]))
-        ops.colsum(dy, g)
 
     def backward(self, dfeat: torch.Tensor) -> torch.Tensor:
         """dfeat f32 [B, E] -> gradient w.r.t. the input tokens, f32 [B*T, D]; fills self.grads."""
@@ -159,9 +157,9 @@ class TowerTrainer:
             ops.gemm(S.dxb, wT["proj_w"], None, out=S.du, res=S.u[l], epi=ops.EPI_DGELU, cfg=cfg)       # du = (dx W_proj) * gelu'(u)
             if trainable:
                 ops.gelu_bf16(S.u[l], S.hid)
-                self._dw(bp + "mlp.c_proj.weight", S.dx, S.hid, rows); self._db(bp + "mlp.c_proj.bias", S.dx)
+                self._dw(bp + "mlp.c_proj.weight", S.dx, S.hid, rows, bp + "mlp.c_proj.bias")
                 ops.layernorm(S.X[2 * l + 1], w["ln2_w"], w["ln2_b"], S.h, rows, D)
-                self._dw(bp + "mlp.c_fc.weight", S.du, S.h, rows); self._db(bp + "mlp.c_fc.bias", S.du)
+                self._dw(bp + "mlp.c_fc.weight", S.du, S.h, rows, bp + "mlp.c_fc.bias")
             ops.gemm(S.du, wT["fc_w"], None, out=S.dh, epi=ops.EPI_BF16, cfg=cfg)                           # dh2
             if trainable:
                 ops.layernorm_bwd_params(S.dh, S.X[2 * l + 1], m2, r2, self.grad_buffer(bp + "ln_2.weight", w["ln2_w"]),
@@ -169,7 +167,7 @@ class TowerTrainer:
             ops.layernorm_bwd(S.dh, S.X[2 * l + 1], m2, r2, w["ln2_w"], rows, D, dres=S.dx, dx=S.dx, dx_bf16=dxb_out)
             # ---- attention branch: x1 = x0 + out(attn(qkv(ln1(x0)))) ----
             if trainable:
-                self._dw(bp + "attn.out_proj.weight", S.dx, S.a[l], rows); self._db(bp + "attn.out_proj.bias", S.dx)
+                self._dw(bp + "attn.out_proj.weight", S.dx, S.a[l], rows, bp + "attn.out_proj.bias")
             ops.gemm_qkv(S.dxb, wT["out_w"], None, S.dO, None, None, B, L, H, dh, cfg=cfg, first=0, count=1,
                          qt=S.dOt, raw_scale=1.0)                                                           # dO (+ transposed)
             ops.attn_delta(S.dO, S.a[l], S.delta)
@@ -177,7 +175,7 @@ class TowerTrainer:
                          S.dqkv, S.dqkv[:, D:], S.dqkv[:, 2 * D:], 3 * D, 3 * D)
             if trainable:
                 ops.layernorm(S.X[2 * l], w["ln1_w"], w["ln1_b"], S.h, rows, D)
-                self._dw(bp + "attn.in_proj_weight", S.dqkv, S.h, rows); self._db(bp + "attn.in_proj_bias", S.dqkv)
+                self._dw(bp + "attn.in_proj_weight", S.dqkv, S.h, rows, bp + "attn.in_proj_bias")
             ops.gemm(S.dqkv, wT["in_w"], None, out=S.dh, epi=ops.EPI_BF16, cfg=cfg)                         # dh1
             if trainable:
                 ops.layernorm_bwd_params(S.dh, S.X[2 * l], m1, r1, self.grad_buffer(bp + "ln_1.weight", w["ln1_w"]),
