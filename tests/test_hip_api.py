@@ -46,7 +46,8 @@ def test_c1_vitb32_image_text_pairs_through_api():
     image = torch.randn(4, 3, 224, 224, generator=g)
     text = oc.tokenize(CAPTIONS)
     assert text.shape == (4, 77) and text.dtype == torch.long
-    out = model(image=image.cuda(), text=text.cuda())
+    with torch.no_grad():
+        out = model(image=image.cuda(), text=text.cuda())
     tower = O.TowerSpec(width=768, layers=12, heads=12, patch=32, image_size=224, embed_dim=512)
     tspec = O.TextSpec(width=512, heads=8, layers=12, embed_dim=512)
     ri = O.encode_image(sd, image, tower, normalize=True)
@@ -80,8 +81,9 @@ def test_tiny_golden_forward_and_loss_through_api(modality):
     assert not [k for k in missing.missing_keys if not k.endswith("num_batches_tracked")], missing.missing_keys
     model.eval()
     kw = {"fps_start": ins["fps_start"].cuda()} if modality == "pc" else {}
-    fv = model.encode_visual(ins["visual_x"].cuda(), normalize=True, **kw)
-    out = model(image=ins["image"].cuda(), text=ins["text"].cuda())
+    with torch.no_grad():
+        fv = model.encode_visual(ins["visual_x"].cuda(), normalize=True, **kw)
+        out = model(image=ins["image"].cuda(), text=ins["text"].cuda())
     for got, k in ((out["image_features"], "image_features"), (out["text_features"], "text_features"), (fv, "visual_features")):
         ref = outs[k]
         assert float((got.float().cpu() - ref).norm() / ref.norm()) < 3e-2, k
@@ -93,6 +95,88 @@ def test_tiny_golden_forward_and_loss_through_api(modality):
     assert abs(float(loss) - float(outs["tri_loss"])) < 3e-2
     loss.backward()
     assert all(torch.isfinite(t.grad).all() for t in feats)
+
+
+def _pc_tol(name):
+    # PointNet encoder gradients carry the arg-max routing noise of two max-pools over bf16 activations
+    return 0.30 if "visual_adapter.encoder" in name else 8e-2
+
+
+@pytest.mark.parametrize("modality", ["depth", "audio", "pc"])
+def test_reference_training_sequence_through_api(modality):
+    """The reference's loop body (training/train.py:131-152, 212-235) verbatim on the drop-in modules:
+        out = model(image, text, visual_x); loss = loss_fn(**out); loss.backward(); optimizer.step()
+    `.grad` of EVERY parameter of the unlocked `visual` tower (Lens, adapter, all ViT blocks, cls / pos, ln_pre / ln_post,
+    proj) and of logit_scale against the gradients the reference's autograd produced for the same step."""
+    oc = _oc()
+    case = load_npz(f"tiny_{modality}.npz")
+    sd, ins, outs, grads, meta = split(case)
+    args = SimpleNamespace(**meta["args"])
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "tiny-lens.json"), "w") as f:
+            json.dump(meta["model_cfg"], f)
+        oc.add_model_config(td)
+        model = oc.tri_create_model("tiny-lens", None, precision="fp32", device="cuda", output_dict=True, args=args)
+    model.load_state_dict(sd, strict=False)
+    model.eval()                                   # the golden step ran BatchNorm on its running statistics
+    model.lock_image_tower(); model.lock_text_tower()
+    assert all(p.requires_grad for p in model.visual.parameters()) and model.logit_scale.requires_grad
+    largs = SimpleNamespace(local_loss=False, gather_with_grad=False, rank=0, world_size=1, horovod=False, n_tower=3,
+                            use_dual_loss=False, cache_dir=None)
+    loss_fn = oc.create_loss(largs)
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    image, text, vx = ins["image"].cuda(), ins["text"].cuda(), ins["visual_x"].cuda()
+
+    def run():
+        if modality == "pc":       # the reference draws the FPS start inside the tokenizer; the golden recorded it
+            out = model(image=image, text=text)
+            out["visual_features"] = model.encode_visual(vx, normalize=True, fps_start=ins["fps_start"].cuda())
+        else:
+            out = model(image=image, text=text, visual_x=vx)
+        return loss_fn(**out)
+    opt.zero_grad()
+    loss = run()
+    assert abs(float(loss) - float(outs["step_loss"])) < 3e-2, (float(loss), float(outs["step_loss"]))
+    loss.backward()
+    named = dict(model.named_parameters())
+    bad, n = {}, 0
+    for k, ref in grads.items():
+        prm = named[k]
+        assert prm.grad is not None, k
+        e = float((prm.grad.float().cpu() - ref).norm() / (ref.norm() + 1e-30))
+        tol = _pc_tol(k) if modality == "pc" else 6e-2
+        if e >= tol:
+            bad[k] = e
+        n += 1
+    assert not bad, bad
+    assert n >= 30 and all(p.grad is None for p in model.image.parameters())
+    before = {k: v.detach().clone() for k, v in named.items() if v.requires_grad}
+    opt.step()
+    moved = [k for k, v in before.items() if not torch.equal(v, named[k].detach())]
+    assert len(moved) == len(before), set(before) - set(moved)
+    with torch.no_grad():
+        loss2 = run()                              # engines picked up the updated parameters
+    assert torch.isfinite(loss2) and abs(float(loss2) - float(loss)) > 1e-6
+
+
+def test_forward_without_no_grad_refuses_an_untrainable_tower():
+    """A tower whose parameters require grad but whose backward is not implemented must not silently produce graph-less
+    features (round-1 finding): the text tower raises; under no_grad / after lock_text_tower it runs."""
+    oc = _oc()
+    case = load_npz("tiny_depth.npz")
+    sd, ins, outs, grads, meta = split(case)
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "tiny-lens.json"), "w") as f:
+            json.dump(meta["model_cfg"], f)
+        oc.add_model_config(td)
+        model = oc.tri_create_model("tiny-lens", None, device="cuda", output_dict=True, args=SimpleNamespace(**meta["args"]))
+    with pytest.raises(NotImplementedError):
+        model.encode_text(ins["text"].cuda())
+    with torch.no_grad():
+        model.encode_text(ins["text"].cuda())
+    model.lock_text_tower()
+    f = model.encode_text(ins["text"].cuda())
+    assert not f.requires_grad
 
 
 def test_vitlens_encode_api_at_full_size():

@@ -174,6 +174,8 @@ class VisionTransformer(nn.Module):
         self.image_mean = self.image_std = None
         self._engine = None
         self._engine_key = None
+        self._trainer_obj, self._trainer_key, self._gen = None, None, 0
+        self._freeze_bn = False
 
     # -------------------------------------------------------------------------------------- lock recipes
     def lock(self, unlocked_groups=0, freeze_bn_stats=False, unlock_cls=False, unlock_pos_emb=False,
@@ -181,12 +183,11 @@ class VisionTransformer(nn.Module):
         """VisionTransformer.lock, open_clip/transformer.py:553-627."""
         for p in self.parameters():
             p.requires_grad = False
+        self._freeze_bn = bool(freeze_bn_stats)      # PointTokenizer BatchNorm: running statistics, no update (transformer.py:558-560)
         on = []
         if unlocked_groups != 0:
             # LiT-style grouped unlock (transformer.py:565-597): [stem] + one group per block but the last +
             # [last block, ln_post] + [proj]; the first k groups with exp_args.unlock_from_head, else the last k.
-            # (requires_grad bookkeeping only: the fused HIP trainers implement the recipes of SURVEY 8-a15 - adapter,
-            # Perceiver, cls/pos, first-n blocks - and do not produce ln_pre / ln_post / proj gradients yet.)
             L = self.cfg.layers
             stem = ("conv1.", "class_embedding", "positional_embedding", "ln_pre.")
             groups = [stem] + [(f"transformer.resblocks.{i}.",) for i in range(L - 1)]
@@ -251,18 +252,135 @@ class VisionTransformer(nn.Module):
             self._engine_key = key
         return self._engine
 
+    # -------------------------------------------------------------------------------------- training (autograd)
+    def _train_flags(self):
+        req = {n for n, p in self.named_parameters() if p.requires_grad}
+        blocks = tuple(sorted({int(n.split(".")[2]) for n in req if n.startswith("transformer.resblocks.")}))
+        return (blocks, "class_embedding" in req, "positional_embedding" in req, any(n.startswith("ln_pre.") for n in req),
+                any(n.startswith("ln_post.") for n in req), "proj" in req, "conv1.weight" in req,
+                self.training and not self._freeze_bn)
+
+    def _trainer(self):
+        """Forward-with-saved-activations / backward executor for the current lock recipe (vitlens_hip.train), bound to
+        the up-to-date engine; rebuilt when the engine or the set of trainable parameters changes."""
+        from vitlens_hip import train as T
+        eng = self.engine()
+        flags = self._train_flags()
+        key = (id(eng), flags)
+        if self._trainer_obj is None or key != self._trainer_key:
+            blocks, cls, pos, lpre, lpost, proj, conv, bn_train = flags
+            kw = dict(train_blocks=blocks, train_cls=cls, train_pos=pos, train_ln_pre=lpre, train_ln_post=lpost, train_proj=proj)
+            if self.modality in ("image", "tactile"):
+                tr = T.ImageTowerTrainer(eng, kw, train_conv=conv)
+            elif self.modality == "depth" and self.perceiver_identity:
+                tr = T.DepthLensTrainer(eng, tower_kw=kw)
+            elif self.modality == "audio" and not self.perceiver_identity:
+                tr = T.AudioLensTrainer(eng, tower_kw=kw)
+            elif self.modality == "pc" and not self.perceiver_identity:
+                from vitlens_hip.points import PointTokenizerTrainer
+                sd = {("t." + k): v for k, v in self.state_dict().items() if k.startswith("visual_adapter.")}
+                tok = PointTokenizerTrainer(sd, "t.visual_adapter.", eng.lens, eng.device, bn_training=bn_train)
+                tr = T.PCLensTrainer(eng, tok, tower_kw=kw)
+            else:
+                raise NotImplementedError(f"training recipe for modality {self.modality!r} "
+                                          f"(perceiver_identity={self.perceiver_identity}) is not implemented")
+            self._trainer_obj, self._trainer_key = tr, key
+        return self._trainer_obj
+
+    def _named_grads(self, tr):
+        """Gradients of the last backward under THIS module's parameter names and shapes."""
+        raw = tr.perc.reference_named_grads() if hasattr(tr, "perc") else dict(tr.grads)
+        params = dict(self.named_parameters())
+        out = {}
+        for k, g in raw.items():
+            for pre in ("visual.", "t."):
+                if k.startswith(pre):
+                    k = k[len(pre):]
+                    break
+            if k.endswith(".weight_gemm"):          # conv-as-GEMM layout [O, K padded to 64] -> [O, C, kh, kw]
+                k = k[:-5]
+                g = g[:, :params[k][0].numel()]
+            if k in params:
+                out[k] = g.reshape(params[k].shape)
+        return out
+
     def forward(self, x: torch.Tensor, fwd_output_tokens: bool = False, **kwargs):
         if fwd_output_tokens:
             raise NotImplementedError("token outputs are only used by the video-distillation losses (out of scope)")
-        eng = self.engine()
         x = x.to(self.class_embedding.device)
+        trainable = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+        if torch.is_grad_enabled() and trainable:
+            names = tuple(n for n, _ in trainable)
+            return _TowerFn.apply(self, x, kwargs, names, *[p for _, p in trainable])
+        eng = self.engine()
         if self.modality in ("image", "tactile"):
             return eng.encode_image(x)
         return eng.encode(x, **kwargs)
 
 
+class _TowerFn(torch.autograd.Function):
+    """One autograd node per tower call: forward = the HIP forward with saved activations, backward = the hand-written
+    HIP backward of the tower (vitlens_hip.train); returns a gradient for every parameter that requires grad, so
+    `loss.backward(); optimizer.step()` of the reference's loop (training/train.py:131-152, 212-235) trains the Lens."""
+
+    @staticmethod
+    def forward(ctx, module, x, kwargs, names, *params):
+        tr = module._trainer()
+        module._gen += 1
+        ctx.module, ctx.names, ctx.gen = module, names, module._gen
+        ctx.shapes = [tuple(p.shape) for p in params]
+        feat = tr.forward(x.detach(), **kwargs)
+        if module.modality == "pc" and module.training and not module._freeze_bn:      # BatchNorm running statistics
+            bufs = dict(module.named_buffers())
+            for k, (rm, rv) in tr.tok.running.items():
+                for nm, src in ((".running_mean", rm), (".running_var", rv)):
+                    dst = bufs["visual_adapter." + k + nm]
+                    if dst.data_ptr() != src.data_ptr():
+                        dst.copy_(src)
+                bufs["visual_adapter." + k + ".num_batches_tracked"] += 1
+        return feat.clone()        # the trainer's feature buffer is reused by the next forward
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        m = ctx.module
+        if m._gen != ctx.gen:
+            raise RuntimeError("this tower ran another forward before this backward: its saved activations were overwritten. "
+                               "Run backward after each forward (the reference's accumulation loop does), or use vitlens_hip.step.")
+        tr = m._trainer_obj
+        for g in tr.grads.values():
+            g.zero_()
+        tr.backward(dfeat.contiguous().float())
+        named = m._named_grads(tr)
+        outs = []
+        for n, shp in zip(ctx.names, ctx.shapes):
+            g = named.get(n)
+            outs.append(None if g is None else g.reshape(shp).clone())
+        return (None, None, None, None, *outs)
+
+
+class _NormalizeFn(torch.autograd.Function):
+    """F.normalize(dim=-1) (model.py:522-540) with its backward, both on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from vitlens_hip import ops
+        x = x.contiguous().float()
+        norms = torch.empty(x.shape[0], device=x.device, dtype=torch.float32)
+        f = ops.l2_normalize(x, norms=norms)
+        ctx.save_for_backward(f, norms)
+        return f
+
+    @staticmethod
+    def backward(ctx, df):
+        from vitlens_hip import ops
+        f, norms = ctx.saved_tensors
+        return ops.l2_normalize_bwd(f, df.contiguous().float(), norms)
+
+
 def _normalize(x):
-    """F.normalize(dim=-1) on the HIP kernel (model.py:522-540)."""
+    """F.normalize(dim=-1) on the HIP kernel (model.py:522-540); differentiable when the features carry a graph."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _NormalizeFn.apply(x)
     from vitlens_hip import ops
     return ops.l2_normalize(x.contiguous().float())
 
@@ -313,6 +431,8 @@ class TriCLIP(nn.Module):
                          unlock_pos_emb=unlock_pos_emb, unlock_trans_first_n_layers=unlock_trans_first_n_layers)
 
     def lock_text_tower(self, unlocked_layers: int = 0, freeze_layer_norm: bool = True):
+        """As the reference: TriCLIP has no `.text` module, so its lock_text_tower falls through to Transformer.lock,
+        which freezes every parameter whatever `unlocked_layers` says (model.py:479-502, transformer.py:373-375)."""
         for n, p in self.named_parameters():
             if n.startswith(("transformer.", "token_embedding.", "ln_final.")) or n in ("positional_embedding", "text_projection"):
                 p.requires_grad = False
@@ -339,7 +459,7 @@ class TriCLIP(nn.Module):
 
     def encode_image(self, image, normalize: bool = False):
         n_img = None
-        if image.ndim == 5:                                           # [b, t, c, h, w]: mean over frames
+        if image.ndim == 5:                                           # [b, t, c, h, w]: mean of the frames' raw features (model.py:510-523)
             n_img = image.size(1)
             image = image.reshape(-1, *image.shape[2:])
         features = self.image(image)
@@ -352,13 +472,24 @@ class TriCLIP(nn.Module):
         return _normalize(features) if normalize else features
 
     def encode_text(self, text, normalize: bool = False):
+        if torch.is_grad_enabled():
+            names = [n for n, p in self.named_parameters() if p.requires_grad and not n.startswith(("image.", "visual."))
+                     and n != "logit_scale"]
+            if names:
+                raise NotImplementedError("training the text tower is not implemented on the HIP path (every ViT-Lens recipe "
+                                          f"locks it, TRAIN_INFERENCE.md); parameters with requires_grad: {names[:3]}...")
         features = self._text().encode_text(text.to(self.positional_embedding.device))
         return _normalize(features) if normalize else features
 
     def forward(self, image=None, text=None, visual_x=None):
-        image_features = self.encode_image(image, normalize=True) if image is not None else None
+        image_features = None
         if image is not None and image.ndim == 5:
-            image_features = _normalize(image_features)
+            # [b, t, c, h, w]: normalise every frame's feature, mean over frames, normalise again (model.py:588-600)
+            n_img = image.size(1)
+            f = self.encode_image(image.reshape(-1, *image.shape[2:]), normalize=True)
+            image_features = _normalize(f.reshape(-1, n_img, f.shape[-1]).mean(1).contiguous())
+        elif image is not None:
+            image_features = self.encode_image(image, normalize=True)
         text_features = self.encode_text(text, normalize=True) if text is not None else None
         visual_features = self.encode_visual(visual_x, normalize=True) if visual_x is not None else None
         if self.output_dict:

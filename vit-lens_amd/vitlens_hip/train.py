@@ -56,10 +56,12 @@ class _Saved:
 
 class TowerTrainer:
     def __init__(self, eng: VitEngine, train_blocks: Iterable[int] = (), train_cls=False, train_pos=False,
-                 param_prefix: str = "visual."):
+                 param_prefix: str = "visual.", train_ln_pre=False, train_ln_post=False, train_proj=False):
         self.eng, self.prefix = eng, param_prefix
         self.train_blocks = sorted(set(train_blocks))
         self.train_cls, self.train_pos = train_cls, train_pos
+        # the stem / head pieces of the grouped (LiT) unlock, VisionTransformer.lock open_clip/transformer.py:564-597
+        self.train_ln_pre, self.train_ln_post, self.train_proj = train_ln_pre, train_ln_post, train_proj
         c = eng.cfg
         self.D, self.H, self.hidden, self.layers = c.width, c.heads, int(c.width * c.mlp_ratio), c.layers
         dev = eng.device
@@ -139,7 +141,16 @@ class TowerTrainer:
         cfg = e.gemm_cfg
         P = self.prefix
         # feat = pooled @ proj ; pooled = ln_post(x[:, 0])
-        dpooled = ops.gemm(ops.cast_bf16(dfeat.contiguous()), self.proj, None, epi=ops.EPI_BF16, cfg=cfg)   # [B, D]
+        dfb = ops.cast_bf16(dfeat.contiguous())
+        dpooled = ops.gemm(dfb, self.proj, None, epi=ops.EPI_BF16, cfg=cfg)   # [B, D]
+        if self.train_proj:          # feat = pooled @ proj  ->  dproj[D, E] += pooled^T dfeat
+            bp = (B + 63) // 64 * 64
+            ops.gemm_dw(ops.transpose_to_bf16(S.pooled, ldo=bp), ops.transpose_to_bf16(dfb, ldo=bp),
+                        self.grad_buffer(P + "proj", torch.empty(D, dfeat.shape[1])), cfg=cfg)
+        if self.train_ln_post:
+            ops.layernorm_bwd_params(dpooled, S.X[2 * self.layers], S.post_stats[0], S.post_stats[1],
+                                     self.grad_buffer(P + "ln_post.weight", e.ln_post[0]),
+                                     self.grad_buffer(P + "ln_post.bias", e.ln_post[1]), B, D, x_row_stride=L * D)
         S.dx.zero_()
         # only the cls rows (row b*L) of the final residual receive gradient: write them in place
         ops.layernorm_bwd(dpooled, S.X[2 * self.layers], S.post_stats[0], S.post_stats[1], e.ln_post[0], B, D,
@@ -183,6 +194,9 @@ class TowerTrainer:
             ops.layernorm_bwd(S.dh, S.X[2 * l], m1, r1, w["ln1_w"], rows, D, dres=S.dx, dx=S.dx, dx_bf16=dxb_out)
         # ---- ln_pre and the [cls; tokens] + pos assembly ----
         dxpre = torch.empty(S.dx.shape, device=S.dx.device, dtype=torch.float32)
+        if self.train_ln_pre:
+            ops.layernorm_bwd_params(S.dx, S.xpre, S.pre_stats[0], S.pre_stats[1], self.grad_buffer(P + "ln_pre.weight", e.ln_pre[0]),
+                                     self.grad_buffer(P + "ln_pre.bias", e.ln_pre[1]), rows, D)
         ops.layernorm_bwd(S.dx, S.xpre, S.pre_stats[0], S.pre_stats[1], e.ln_pre[0], rows, D, dx=dxpre)
         if self.train_cls:
             ops.batch_rowsum(dxpre, self.grad_buffer(P + "class_embedding", e.cls).view(1, D), B, 1, D, L, 0)
@@ -195,9 +209,10 @@ class TowerTrainer:
 class DepthLensTrainer:
     """`visual.` tower of the depth recipe: DepthTokenizer conv1 + pos_emb -> ViT trunk (Perceiver = Identity)."""
 
-    def __init__(self, lens_engine, unlock_first_n: int = 4):
+    def __init__(self, lens_engine, unlock_first_n: int = 4, tower_kw=None):
         self.le = lens_engine
-        self.tower = TowerTrainer(lens_engine.vit, train_blocks=range(unlock_first_n), param_prefix="visual.")
+        kw = dict(train_blocks=range(unlock_first_n)) if tower_kw is None else dict(tower_kw)
+        self.tower = TowerTrainer(lens_engine.vit, param_prefix="visual.", **kw)
         self.ctx = None
 
     @property
@@ -221,6 +236,37 @@ class DepthLensTrainer:
         rp = (dtok.shape[0] + 63) // 64 * 64
         ops.gemm_dw(ops.transpose_to_bf16(dtok, ldo=rp), ops.transpose_to_bf16(cols, ldo=rp), g, cfg=self.le.gemm_cfg)
         ops.batch_rowsum(t.dxpre, t.grad_buffer("visual.visual_adapter.pos_emb", self.le.adapter_pos), B, T, D, T + 1, 1)
+
+
+class ImageTowerTrainer:
+    """An image-modality tower (conv1 patchify -> ViT trunk) under any lock recipe; the stem convolution's weight
+    gradient is produced when `train_conv` (grouped unlock reaching the stem, transformer.py:566-573)."""
+
+    def __init__(self, vit_engine, tower_kw=None, train_conv: bool = False):
+        self.eng = vit_engine
+        self.tower = TowerTrainer(vit_engine, param_prefix="visual.", **(tower_kw or {}))
+        self.train_conv = train_conv
+        self.ctx = None
+
+    @property
+    def grads(self):
+        return self.tower.grads
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        e = self.eng
+        p = e.cfg.patch
+        cols, gh, gw = ops.im2col(x.contiguous().float(), p, p, p, p, e.conv_w.shape[1])
+        tok = ops.gemm(cols, e.conv_w, None, epi=ops.EPI_BF16, cfg=e.gemm_cfg)
+        self.ctx = cols
+        return self.tower.forward(tok, x.shape[0])
+
+    def backward(self, dfeat: torch.Tensor):
+        dtok = self.tower.backward(dfeat)
+        if self.train_conv:
+            cols = self.ctx
+            g = self.tower.grad_buffer("visual.conv1.weight_gemm", torch.empty(dtok.shape[1], cols.shape[1]))
+            rp = (dtok.shape[0] + 63) // 64 * 64
+            ops.gemm_dw(ops.transpose_to_bf16(dtok, ldo=rp), ops.transpose_to_bf16(cols, ldo=rp), g, cfg=self.eng.gemm_cfg)
 
 
 class AdamW:
@@ -472,9 +518,10 @@ class AudioLensTrainer:
     """`visual.` tower of the audio recipe (TRAIN_INFERENCE.md:283-299): AST tokenizer + Perceiver trainable,
     ViT blocks locked, class_embedding unlocked (--lock-visual --unlock-cls)."""
 
-    def __init__(self, lens_engine):
+    def __init__(self, lens_engine, tower_kw=None):
         self.le = lens_engine
-        self.tower = TowerTrainer(lens_engine.vit, train_blocks=(), train_cls=True, param_prefix="visual.")
+        kw = dict(train_blocks=(), train_cls=True) if tower_kw is None else dict(tower_kw)
+        self.tower = TowerTrainer(lens_engine.vit, param_prefix="visual.", **kw)
         self.perc = PerceiverTrainer(lens_engine.perceiver, "visual.perceiver.")
         self.perc.grads = self.tower.grads            # one gradient dictionary
         self.ctx = None
@@ -513,10 +560,11 @@ class PCLensTrainer:
     `tok` is the shared PointTokenizerTrainer (masters, bf16 operands, running statistics); each micro-batch gets
     a shallow copy that only owns its saved activations."""
 
-    def __init__(self, lens_engine, tok, train_cls: bool = False):
+    def __init__(self, lens_engine, tok, train_cls: bool = False, tower_kw=None):
         import copy
         self.le = lens_engine
-        self.tower = TowerTrainer(lens_engine.vit, train_blocks=(), train_cls=train_cls, param_prefix="visual.")
+        kw = dict(train_blocks=(), train_cls=train_cls) if tower_kw is None else dict(tower_kw)
+        self.tower = TowerTrainer(lens_engine.vit, param_prefix="visual.", **kw)
         self.perc = PerceiverTrainer(lens_engine.perceiver, "visual.perceiver.")
         self.perc.grads = self.tower.grads
         self.tok = copy.copy(tok)
