@@ -92,3 +92,109 @@ def test_cpu_model_forward_fails_loudly():
     m = oc.tri_create_model("ViT-B-32", device="cpu", args=fetch_model_cfg("image"))
     with pytest.raises(RuntimeError):
         m.encode_image(torch.zeros(1, 3, 224, 224))
+
+
+# ------------------------------------------------------------------------------------------------ checkpoints / registry
+def _tiny_vitlens(monkeypatch, modalities):
+    """ViTLens on the tiny golden configuration (CPU construction only; the forward needs a GPU)."""
+    import importlib
+    from types import SimpleNamespace
+    from golden_util import load_npz, split
+    oc = importlib.import_module("open_clip")
+    import mm_vit_lens.vitlens as V
+    metas = {m: split(load_npz(f"tiny_{m}.npz"))[4] for m in ("depth", "audio")}
+    td = tempfile.mkdtemp()
+    json.dump(metas["depth"]["model_cfg"], open(os.path.join(td, "tiny-lens.json"), "w"))
+    oc.add_model_config(td)
+
+    def fake_cfg(modality, model_option="vitlensL"):
+        a = dict(metas["depth" if modality in ("image", "text") else modality]["args"])
+        if modality in ("image", "text"):
+            a.update(visual_modality_type="image", use_perceiver=False, use_visual_adapter=False)
+        a["model"] = "tiny-lens"
+        return SimpleNamespace(**a)
+    monkeypatch.setattr(V, "fetch_model_cfg", fake_cfg)
+    return V.ViTLens(modality_loaded=list(modalities), device="cpu")
+
+
+def test_vitlens_checkpoint_roundtrip_and_reference_format(monkeypatch, tmp_path):
+    """export_checkpoint writes the reference's release layout (`vitlens.<modality>.<submodule keys>`: the image tower,
+    the text tower, the modality's `visual` tower - mm_vit_lens/vitlens.py:63-118,153-159), load_checkpoint reads it back
+    (round trip is exact), and a hand-made reference-format file lands in the right parameters."""
+    from golden_util import load_npz, split
+    mods = ["image", "text", "depth", "audio"]
+    torch.manual_seed(0)
+    a = _tiny_vitlens(monkeypatch, mods)
+    path = str(tmp_path / "vitlens.pt")
+    a.export_checkpoint(path)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert ck["model_var"] == "vitlensL" and ck["modality_loaded"] == mods
+    keys = set(ck["state_dict"].keys())
+    assert "vitlens.image.conv1.weight" in keys and "vitlens.image.transformer.resblocks.0.attn.in_proj_weight" in keys
+    assert "vitlens.text.token_embedding.weight" in keys and "vitlens.text.text_projection" in keys
+    assert "vitlens.text.transformer.resblocks.0.mlp.c_fc.weight" in keys
+    assert "vitlens.depth.visual_adapter.conv1.weight" in keys and "vitlens.audio.perceiver.latents" in keys
+    assert not [k for k in keys if ".visual." in k or k.startswith("vitlens.depth.image.") or k.startswith("vitlens.image.image.")]
+    assert not [k for k in keys if k.startswith("vitlens.depth.transformer.resblocks.0.") and ck["state_dict"][k].shape[-1] ==
+                a.vitlens["text"].positional_embedding.shape[1] and "visual" in k]
+    torch.manual_seed(1)
+    b = _tiny_vitlens(monkeypatch, mods)
+    assert not torch.equal(a.vitlens["depth"].visual.class_embedding, b.vitlens["depth"].visual.class_embedding)
+    missing, unexpected = b.load_checkpoint(path)
+    assert not missing and not unexpected
+    sa, sb = a.state_dict(), b.state_dict()
+    assert sa.keys() == sb.keys() and all(torch.equal(sa[k], sb[k]) for k in sa)
+    # a release-format file built from the reference-generated golden weights
+    sd = split(load_npz("tiny_depth.npz"))[0]
+    ref_fmt = {"vitlens.depth." + k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}
+    ref_fmt.update({"vitlens.image." + k[len("image."):]: v for k, v in sd.items() if k.startswith("image.")})
+    ref_fmt.update({"vitlens.text." + k: v for k, v in sd.items()
+                    if k.startswith(("transformer.", "token_embedding.", "ln_final.")) or k in ("positional_embedding", "text_projection")})
+    torch.save({"state_dict": {"module." + k: v for k, v in ref_fmt.items()}}, path)
+    c = _tiny_vitlens(monkeypatch, ["image", "text", "depth"])
+    missing, unexpected = c.load_checkpoint(path)
+    assert not missing and not unexpected
+    assert torch.equal(c.vitlens["depth"].visual.visual_adapter.conv1.weight, sd["visual.visual_adapter.conv1.weight"])
+    assert torch.equal(c.vitlens["image"].image.conv1.weight, sd["image.conv1.weight"])
+    assert torch.equal(c.vitlens["text"].token_embedding.weight, sd["token_embedding.weight"])
+    # training checkpoint -> one modality (load_modality_from_pt_ckpt)
+    torch.save({"state_dict": {"module." + k: v for k, v in sd.items()}}, path)
+    torch.manual_seed(2)
+    d = _tiny_vitlens(monkeypatch, ["depth"])
+    d.load_modality_from_pt_ckpt("depth", path)
+    assert torch.equal(d.vitlens["depth"].visual.positional_embedding, sd["visual.positional_embedding"])
+
+
+def test_list_models_natural_order_and_pos_embed_resize():
+    import importlib
+    oc = importlib.import_module("open_clip")
+    from open_clip import factory as F
+    with tempfile.TemporaryDirectory() as td:
+        base = oc.get_model_config("ViT-B-32")
+        for n in ("zz-net-2", "zz-net-10", "zz-net-1"):
+            json.dump(base, open(os.path.join(td, n + ".json"), "w"))
+        oc.add_model_config(td)
+        names = [n for n in oc.list_models() if n.startswith("zz-net")]
+        assert names == ["zz-net-1", "zz-net-2", "zz-net-10"], names
+    # checkpoint with a 7x7 (+cls) grid into a tower that resamples to 16 latents: bicubic to 4x4; into 20 latents: + nearest
+    from types import SimpleNamespace
+
+    def model_with(n_lat):
+        vis = SimpleNamespace(cfg=SimpleNamespace(image_size=224, patch_size=32, exp_args=SimpleNamespace(perceiver_num_latents=n_lat)),
+                              use_perceiver=True)
+        return SimpleNamespace(visual=vis)
+    g = torch.Generator().manual_seed(0)
+    pe = torch.randn(50, 8, generator=g)
+    sd = {"visual.positional_embedding": pe.clone()}
+    F.resize_pos_embed(sd, model_with(16))
+    out = sd["visual.positional_embedding"]
+    assert out.shape == (17, 8) and torch.equal(out[0], pe[0])
+    ref = torch.nn.functional.interpolate(pe[1:].reshape(1, 7, 7, 8).permute(0, 3, 1, 2), size=(4, 4), mode="bicubic",
+                                          antialias=True, align_corners=False).permute(0, 2, 3, 1).reshape(16, 8)
+    assert torch.allclose(out[1:], ref)
+    sd = {"visual.positional_embedding": pe.clone()}
+    F.resize_pos_embed(sd, model_with(20))
+    assert sd["visual.positional_embedding"].shape == (21, 8)
+    sd = {"visual.positional_embedding": pe.clone()}
+    F.resize_pos_embed(sd, model_with(49))
+    assert torch.equal(sd["visual.positional_embedding"], pe)

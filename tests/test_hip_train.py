@@ -244,6 +244,84 @@ def test_tri_modal_step_matches_reference_step(res_dtype):
     assert torch.isfinite(loss2) and float(loss2) < float(loss) + 1e-3
 
 
+@pytest.mark.parametrize("recipe", ["depth", "audio", "pc"])
+def test_step_checkpoint_export_reload_and_resume(recipe):
+    """Train one step with a fused step object, export `state_dict()` (reference names / layouts: conv weight un-padded,
+    GEGLU de-interleaved, to_qkv split) and load it into a fresh TriCLIP: the drop-in forward must reproduce the step's own
+    tower.  Then resume a NEW step object from (state_dict, optimizer_state_dict): its next step equals the original's."""
+    import importlib, json, os, sys, tempfile
+    from types import SimpleNamespace
+    from vitlens_hip import engine as E, step as ST
+    for k in [k for k in sys.modules if k == "open_clip" or k.startswith("open_clip.")]:
+        if "vit-lens_amd" not in (getattr(sys.modules[k], "__file__", "") or ""):
+            del sys.modules[k]
+    oc = importlib.import_module("open_clip")
+    case = load_npz(f"tiny_{recipe}.npz")
+    sd, ins, outs, grads, meta = split(case)
+    tower, text, lens = specs_from_meta(meta)
+    tc = E.TowerCfg(width=tower.width, layers=tower.layers, heads=tower.heads, patch=tower.patch, image_size=tower.image_size,
+                    embed_dim=tower.embed_dim)
+    xc = E.TextCfg(context_length=text.context_length, vocab_size=text.vocab_size, width=text.width, heads=text.heads,
+                   layers=text.layers, embed_dim=text.embed_dim)
+    sd = {k: v.cuda() if v.is_floating_point() else v for k, v in sd.items()}      # on-device fp32 input: the aliasing case
+    before = {k: v.clone() for k, v in sd.items()}
+
+    def make(state):
+        if recipe == "depth":
+            return ST.TriModalDepthStep(state, tc, xc, "cuda", micro_batch=2, unlock_first_n=1, lr=1e-3)
+        with tempfile.TemporaryDirectory() as td:
+            json.dump(meta["model_cfg"], open(os.path.join(td, "tiny-lens.json"), "w"))
+            oc.add_model_config(td)
+            m = oc.tri_create_model("tiny-lens", None, device="cpu", args=SimpleNamespace(**meta["args"]))
+        _, lc = m.visual._cfgs()
+        if recipe == "audio":
+            return ST.DualAudioStep(state, tc, xc, lc, "cuda", micro_batch=2, lr=1e-3)
+        return ST.TriModalPCStep(state, tc, xc, lc, "cuda", micro_batch=4, lr=1e-3, bn_training=True)
+
+    def run(st):
+        if recipe == "depth":
+            return st.step(ins["image"].cuda(), ins["text"].cuda(), ins["visual_x"].cuda())
+        if recipe == "audio":
+            return st.step(ins["visual_x"].cuda(), ins["text"].cuda())
+        return st.step(ins["image"].cuda(), ins["text"].cuda(), ins["visual_x"].cuda(), ins["fps_start"].cuda())
+    st = make(sd)
+    run(st)
+    assert all(torch.equal(before[k], sd[k]) for k in sd), "the step modified the caller's state_dict in place"
+    exported = st.state_dict()
+    assert exported.keys() == sd.keys() and all(exported[k].shape == sd[k].shape for k in sd)
+    changed = [k for k in sd if not torch.equal(exported[k].cpu(), before[k].cpu())]
+    assert any(k.startswith("visual.visual_adapter.") for k in changed) and "logit_scale" in changed
+    assert not [k for k in changed if k.startswith("image.") or k.startswith("transformer.")]
+    # drop-in model on the exported weights == the step's own tower
+    with tempfile.TemporaryDirectory() as td:
+        json.dump(meta["model_cfg"], open(os.path.join(td, "tiny-lens.json"), "w"))
+        oc.add_model_config(td)
+        model = oc.tri_create_model("tiny-lens", None, device="cuda", args=SimpleNamespace(**meta["args"]))
+    missing = model.load_state_dict(exported, strict=False)
+    assert not missing.unexpected_keys and not [k for k in missing.missing_keys if not k.endswith("num_batches_tracked")]
+    model.eval()
+    kw = {"fps_start": ins["fps_start"].cuda()} if recipe == "pc" else {}
+    with torch.no_grad():
+        got = model.encode_visual(ins["visual_x"].cuda(), normalize=True, **kw)
+    if recipe == "pc":      # the step's engine-side tokenizer keeps construction-time weights; compare through a fresh step instead
+        ref = make(exported).lens
+        ref_f = E.LensEngine(exported, "visual.", tc, ref.lens, "cuda").encode(ins["visual_x"].cuda(), normalize=True, **kw)
+    else:
+        ref_f = st.lens.encode(ins["visual_x"].cuda(), normalize=True)
+    assert relerr(got, ref_f) < 2e-3, relerr(got, ref_f)
+    # resume
+    st2 = make(exported)
+    st2.load_optimizer_state_dict(st.optimizer_state_dict())
+    l_a, l_b = run(st), run(st2)
+    assert abs(float(l_a) - float(l_b)) < 1e-5
+    for k in st.masters:
+        assert relerr(st2.masters[k], st.masters[k]) < 1e-5, k
+    # load_state_dict into an existing object restores the trainable set
+    st2.load_state_dict(sd)
+    for k, v in st2.state_dict().items():
+        assert relerr(v.float(), before[k].float()) < 1e-6 or v.dtype == torch.long, k
+
+
 def test_audio_lens_backward_vs_reference_grads():
     """Audio recipe: AST tokenizer + Perceiver (cross + self attention, GEGLU FF) trainable, ViT locked, cls unlocked.
     Every gradient the HIP backward produces vs the reference's own autograd on the tiny golden model."""

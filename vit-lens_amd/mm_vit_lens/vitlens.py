@@ -42,24 +42,65 @@ class ViTLens(nn.Module):
     def device(self):
         return self._dev
 
+    # ---- checkpoint format of the reference release (vitlens.py:33,63-118,153-159) ----------------------------------
+    # `vitlens.image.<VisionTransformer keys>`  = TriCLIP.image, `vitlens.text.{transformer.*, token_embedding.weight,
+    # positional_embedding, ln_final.*, text_projection}` = the text tower (flattened into the TriCLIP root), and
+    # `vitlens.<modality>.<VisionTransformer keys>` = TriCLIP.visual of that modality's model.
+    _TEXT_KEYS = ("transformer.", "token_embedding.", "ln_final.")
+
+    def _part(self, m):
+        model = self.vitlens[m]
+        if m == ModalityType.IMAGE:
+            return model.image, None
+        if m == ModalityType.TEXT:
+            return model, lambda k: k.startswith(self._TEXT_KEYS) or k in ("positional_embedding", "text_projection")
+        return model.visual, None
+
+    def state_dict(self, *args, **kwargs):
+        out = {}
+        for m in self.vitlens.keys():
+            mod, keep = self._part(m)
+            for k, v in mod.state_dict().items():
+                if keep is None or keep(k):
+                    out[f"vitlens.{m}.{k}"] = v
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = False):
+        """Loads a release-format dict; returns (missing, unexpected) and logs them (the reference logs its
+        incompatible keys, vitlens.py:131-133)."""
+        import logging
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        missing, unexpected, used = [], [], set()
+        for m in self.vitlens.keys():
+            pre = f"vitlens.{m}."
+            sub = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+            used.update(pre + k for k in sub)
+            mod, keep = self._part(m)
+            own = {k for k in mod.state_dict().keys() if keep is None or keep(k)}
+            missing += [pre + k for k in sorted(own - set(sub)) if not k.endswith("num_batches_tracked")]
+            unexpected += [pre + k for k in sorted(set(sub) - own)]
+            mod.load_state_dict({k: v for k, v in sub.items() if k in own}, strict=False)
+        unexpected += sorted(k for k in sd if k.startswith("vitlens.") and k not in used)
+        if missing or unexpected:
+            logging.info("ViTLens.load_state_dict: missing %s, unexpected %s", missing, unexpected)
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"ViTLens.load_state_dict: missing {missing}, unexpected {unexpected}")
+        return missing, unexpected
+
     def load_checkpoint(self, path):
         ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        return self.load_state_dict(ckpt.get("state_dict", ckpt), strict=False)
+
+    def load_modality_from_pt_ckpt(self, modality, pt_ckpt_path):
+        """Load the `visual.*` tower of a TRAINING checkpoint into one modality (vitlens.py:135-151)."""
+        ckpt = torch.load(pt_ckpt_path, map_location="cpu", weights_only=False)
         sd = ckpt.get("state_dict", ckpt)
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
-        # released file prefixes modules as vitlens.<modality>.<part> (vitlens.py:153-159)
-        for m, model in self.vitlens.items():
-            sub = {k[len(f"vitlens.{m}."):]: v for k, v in sd.items() if k.startswith(f"vitlens.{m}.")}
-            if not sub:
-                continue
-            if m == ModalityType.IMAGE:
-                sub = {"image." + k: v for k, v in sub.items()}
-            elif m not in (ModalityType.TEXT,):
-                sub = {"visual." + k: v for k, v in sub.items()}
-            model.load_state_dict(sub, strict=False)
+        sd = {k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}
+        return self.vitlens[modality].visual.load_state_dict(sd, strict=False)
 
-    def export_checkpoint(self, path):
-        torch.save({"model_var": self.model_var, "modality_loaded": self.modality_loaded,
-                    "state_dict": self.state_dict()}, path)
+    def export_checkpoint(self, save_path="model_release/vitlens.pt"):
+        torch.save(dict(model_var=self.model_var, modality_loaded=self.modality_loaded, state_dict=self.state_dict()), save_path)
 
     @torch.no_grad()
     def encode(self, input_dict: Dict[str, object], normalize: bool = True) -> Dict[str, torch.Tensor]:

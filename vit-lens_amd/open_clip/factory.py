@@ -28,7 +28,7 @@ def _rescan():
             cfg = json.load(open(f))
             if all(k in cfg for k in ("embed_dim", "vision_cfg", "text_cfg")):
                 found[f.stem] = cfg
-    _CONFIGS = dict(sorted(found.items(), key=lambda kv: [int(t) if t.isdigit() else t for t in re.split(r"(\\d+)", kv[0].lower())]))
+    _CONFIGS = dict(sorted(found.items(), key=lambda kv: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", kv[0].lower())]))
 
 
 _rescan()
@@ -68,14 +68,54 @@ def load_state_dict(checkpoint_path: str, map_location="cpu"):
     return sd
 
 
+def resize_pos_embed(state_dict, model, interpolation: str = "bicubic", antialias: bool = True):
+    """Rescale `visual.positional_embedding` of a checkpoint to the model's token count (open_clip/model.py:1079-1150):
+    bicubic resize of the square grid to grid_size - or to floor(sqrt(num_latents))^2 followed by a nearest resample to
+    exactly num_latents when the tower resamples with a Perceiver (e.g. a ViT-B/16 checkpoint, grid 196, into 256 latents)."""
+    import math
+    import torch.nn.functional as F
+    old = state_dict.get("visual.positional_embedding", None)
+    vis = getattr(model, "visual", None)
+    if old is None or vis is None:
+        return
+    g = vis.cfg.image_size // vis.cfg.patch_size
+    new_len = g * g + 1
+    n_lat = None
+    if vis.use_perceiver:
+        n_lat = getattr(vis.cfg.exp_args, "perceiver_num_latents", g * g)
+        new_len = n_lat + 1
+    if new_len == old.shape[0]:
+        return
+    tok, img = old[:1], old[1:]
+    og = int(math.sqrt(len(img)))
+    to = (int(math.sqrt(n_lat)),) * 2 if n_lat is not None else (g, g)
+    logging.info("Resizing position embedding grid-size from %s to %s", (og, og), to)
+    img = img.reshape(1, og, og, -1).permute(0, 3, 1, 2)
+    img = F.interpolate(img.float(), size=to, mode=interpolation, antialias=antialias, align_corners=False)
+    img = img.permute(0, 2, 3, 1).reshape(1, to[0] * to[1], -1)[0]
+    if n_lat is not None and to[0] * to[1] != n_lat:
+        img = F.interpolate(img.unsqueeze(0).transpose(1, 2), size=n_lat, mode="nearest").transpose(1, 2).squeeze(0)
+    state_dict["visual.positional_embedding"] = torch.cat([tok.float(), img], dim=0).to(old.dtype)
+
+
 def load_checkpoint(model, checkpoint_path, strict=True, args=None):
-    """factory.py:130-160: open_clip checkpoints call the image encoder `visual`; copy it to `image.*`."""
+    """factory.py:130-160: open_clip checkpoints call the image encoder `visual`; copy it to `image.*` (and drop the
+    original when the visual tower does not start from the pretrained ViT), resize the position embedding, load,
+    log the incompatible keys."""
     sd = load_state_dict(checkpoint_path)
+    do_pop = args is not None and (getattr(args, "visual_arch", "perceiver_vit") != "perceiver_vit"
+                                   or getattr(args, "disable_pt_vit", False))
     if hasattr(model, "image") and hasattr(model, "visual"):
         for k in list(sd.keys()):
             if "visual." in k:
                 sd[k.replace("visual.", "image.")] = sd[k]
-    return model.load_state_dict(sd, strict=strict)
+                if do_pop:
+                    sd.pop(k)
+    resize_pos_embed(sd, model)
+    incompatible = model.load_state_dict(sd, strict=strict)
+    if len(incompatible.missing_keys) or len(incompatible.unexpected_keys):
+        logging.info(msg=incompatible)
+    return incompatible
 
 
 def tri_create_model(model_name: str, pretrained: Optional[str] = None, precision: str = "fp32",

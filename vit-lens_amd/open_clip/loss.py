@@ -98,7 +98,7 @@ class _ContrastivePair(torch.autograd.Function):
         scale = float(logit_scale)
         # hi/lo bf16 split of both feature sets: logits accurate to ~2^-17 (one GEMM with K = 3D)
         xb, yb = ops.split_bf16x3(x, 0), ops.split_bf16x3(y, 1)
-        logits = ops.gemm(xb, yb, None, epi=ops.EPI_F32, alpha=scale)          # [R, Cn] f32, written once
+        logits = ops.logits_gemm(xb, yb, scale)                                # [R, Cn] f32 (view of a 4-column-padded buffer), written once
         row_lse, col_lse, diag = ops.ce_stats(logits, label_off, want_cols=(w_col != 0.0))
         loss = torch.zeros(1, device=x.device, dtype=torch.float32)
         ops.ce_loss_accum(loss, row_lse if w_row != 0.0 else None, col_lse, diag, R, Cn, label_off, w_row, w_col)

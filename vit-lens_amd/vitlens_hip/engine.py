@@ -43,7 +43,10 @@ def _pad64(n):
 
 
 def _dev(t, device, dtype=torch.float32):
-    return t.detach().to(device=device, dtype=dtype).contiguous()
+    """Device copy owned by the engine: never an alias of the caller's tensor (a fused step updates these in place through
+    raw kernels, which would otherwise modify the model's Parameters behind autograd's back)."""
+    out = t.detach().to(device=device, dtype=dtype).contiguous()
+    return out.clone() if out.data_ptr() == t.data_ptr() else out
 
 
 def prep_block(sd: Dict[str, torch.Tensor], p: str, device) -> Dict[str, torch.Tensor]:
@@ -59,13 +62,13 @@ def prep_block(sd: Dict[str, torch.Tensor], p: str, device) -> Dict[str, torch.T
     }
 
 
-def conv_weight_as_gemm(w: torch.Tensor, device) -> torch.Tensor:
-    """Conv2d weight [O,C,kh,kw] -> bf16 [O, Kp] (K = C*kh*kw zero-padded to a multiple of 64)."""
+def conv_weight_as_gemm(w: torch.Tensor, device, dtype=torch.bfloat16) -> torch.Tensor:
+    """Conv2d weight [O,C,kh,kw] -> [O, Kp] (K = C*kh*kw zero-padded to a multiple of 64), bf16 operand or f32 master."""
     O = w.shape[0]
     K = w[0].numel()
     out = torch.zeros(O, _pad64(K), dtype=torch.float32)
     out[:, :K] = w.detach().reshape(O, K).float().cpu()
-    return out.to(device=device, dtype=torch.bfloat16).contiguous()
+    return out.to(device=device, dtype=dtype).contiguous()
 
 
 class _Workspace:
@@ -321,7 +324,7 @@ class LensEngine:
         if lens.modality in ("depth", "audio"):
             self.conv_w = conv_weight_as_gemm(sd[a + "conv1.weight"], device)
             pos = sd[a + "pos_emb"].detach().float()
-            self.adapter_pos = _dev(pos * (0.0 if lens.disable_adapter_pos else 1.0), device)
+            self.adapter_pos = _dev(pos * (0.0 if lens.disable_adapter_pos else 1.0), device)      # (the product is a new tensor)
         elif lens.modality == "pc":
             from .points import PointTokenizerEngine
             self.points = PointTokenizerEngine(sd, a, lens, device, gemm_cfg=gemm_cfg)

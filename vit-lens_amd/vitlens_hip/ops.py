@@ -73,6 +73,18 @@ def gemm(a, w, bias=None, out=None, res=None, epi=EPI_BF16, act=ACT_NONE, alpha=
     return out
 
 
+def logits_gemm(xb, yb, scale):
+    """scale * xb @ yb^T as f32 [R, C] for ANY number of columns (a partial last batch, a batch of 6 ...): the GEMM wants
+    N % 4 == 0, so the column operand is zero-padded to a multiple of 4 rows and a [R, C] view of the padded result is
+    returned (the CE kernels take the row stride)."""
+    Cn = yb.shape[0]
+    Cp = (Cn + 3) // 4 * 4
+    if Cp != Cn:
+        yb = torch.cat([yb, torch.zeros(Cp - Cn, yb.shape[1], device=yb.device, dtype=yb.dtype)], 0)
+    out = gemm(xb, yb, None, epi=EPI_F32, alpha=scale)
+    return out if Cp == Cn else out[:, :Cn]
+
+
 def gemm_dw(dyt, xt, g, cfg=-1, alpha=1.0):
     """g += dyt @ xt^T: the weight-gradient GEMM (dyt [N_out, R], xt [K_in, R] bf16 - both already transposed so
     that the token axis R is the reduction axis; g f32 [N_out, K_in], may be a strided view).  Few output tiles

@@ -83,7 +83,7 @@ class PointTokenizerTrainer:
     def __init__(self, sd, a: str, lens, device, grads=None, gemm_cfg=-1, bn_training=True):
         self.a, self.lens, self.device, self.cfg, self.bn_training = a, lens, torch.device(device), gemm_cfg, bn_training
         self.grads = {} if grads is None else grads
-        f32 = lambda k: sd[a + k].detach().float().to(device).contiguous()
+        f32 = lambda k: sd[a + k].detach().float().to(device).contiguous().clone()      # masters never alias the caller's tensors
         m = self.masters = {}
         for k in ("encoder.first_conv.0", "encoder.first_conv.3", "encoder.second_conv.0", "encoder.second_conv.3"):
             m[a + k + ".weight"] = f32(k + ".weight")[:, :, 0].contiguous(); m[a + k + ".bias"] = f32(k + ".bias")

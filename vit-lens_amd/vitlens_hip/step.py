@@ -40,11 +40,85 @@ class TorchComm:
         dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM)
 
 
+# ------------------------------------------------------------------------------------------------ checkpointing
+def _master_from_sd(name: str, sd, like: torch.Tensor) -> torch.Tensor:
+    """Value of master `name` (kernel layout) from a reference-layout state_dict."""
+    from .engine import _interleave_geglu, conv_weight_as_gemm
+    dev = like.device
+    f32 = lambda k: sd[k].detach().float().to(dev).clone()
+    if name.endswith("conv1.weight_gemm"):                       # conv-as-GEMM, K zero-padded to 64
+        return conv_weight_as_gemm(sd[name[:-5]], dev, torch.float32)
+    if name.endswith("net.0.weight_il") or name.endswith("net.0.bias_il"):      # GEGLU rows interleaved (a_j, gate_j)
+        base = name[:name.rindex("net.0.")] + "net.0."
+        w, b = _interleave_geglu(f32(base + "weight"), f32(base + "bias"))
+        return (w if name.endswith("weight_il") else b).contiguous()
+    if name.endswith("fn.to_qkv.weight"):                        # self-attention: [to_q ; to_kv]
+        return torch.cat([f32(name.replace("to_qkv", "to_q")), f32(name.replace("to_qkv", "to_kv"))], 0).contiguous()
+    return f32(name).reshape(like.shape).contiguous()
+
+
+def _master_to_sd(name: str, m: torch.Tensor, base_sd, cfg) -> Dict[str, torch.Tensor]:
+    """Reference-layout entries produced by master `name`."""
+    from .train import deinterleave_geglu
+    if name.endswith("conv1.weight_gemm"):
+        ref = base_sd[name[:-5]]
+        return {name[:-5]: m[:, :ref[0].numel()].reshape(ref.shape)}
+    if name.endswith("_il"):
+        return {name[:-3]: deinterleave_geglu(m)}
+    if name.endswith("fn.to_qkv.weight"):
+        inner = cfg.latent_heads * cfg.latent_dim_head
+        return {name.replace("to_qkv", "to_q"): m[:inner], name.replace("to_qkv", "to_kv"): m[inner:]}
+    return {name: m.reshape(base_sd[name].shape)}
+
+
+class _StepState:
+    """state_dict / load_state_dict of a fused training step in the REFERENCE's names and layouts (a TriCLIP state_dict:
+    trained tensors from the fp32 masters, everything else as it was given), plus the AdamW moments - so training can be
+    checkpointed, resumed, and handed back to `TriCLIP.load_state_dict` (training/train.py checkpoints `model.state_dict()`
+    and `optimizer.state_dict()`)."""
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        out = {k: v.detach().clone() for k, v in self._base_sd.items()}
+        cfg = getattr(self.lens, "lens", None)
+        for name, m in self.masters.items():
+            for k, v in _master_to_sd(name, m.detach(), self._base_sd, cfg).items():
+                out[k] = v.to(device=self._base_sd[k].device, dtype=self._base_sd[k].dtype).clone()
+        tok = getattr(self, "tok", None)
+        if tok is not None:                                      # BatchNorm running statistics of the PointTokenizer
+            for k, (rm, rv) in tok.running.items():
+                out["visual.visual_adapter." + k + ".running_mean"] = rm.detach().cpu().clone()
+                out["visual.visual_adapter." + k + ".running_var"] = rv.detach().cpu().clone()
+        return out
+
+    def optimizer_state_dict(self):
+        return {"step": self.opt.t, "exp_avg": {k: v.detach().clone() for k, v in self.opt.m.items()},
+                "exp_avg_sq": {k: v.detach().clone() for k, v in self.opt.v.items()}}
+
+    def load_state_dict(self, sd):
+        """Re-read every TRAINABLE tensor from a reference-layout state_dict into the masters (in place: the kernels keep
+        reading the same buffers) and refresh the bf16 operands.  Frozen towers are fixed at construction."""
+        for name, m in self.masters.items():
+            m.copy_(_master_from_sd(name, sd, m))
+        tok = getattr(self, "tok", None)
+        if tok is not None:
+            for k, (rm, rv) in tok.running.items():
+                rm.copy_(sd["visual.visual_adapter." + k + ".running_mean"].float()); rv.copy_(sd["visual.visual_adapter." + k + ".running_var"].float())
+        if not self.trainers:
+            self._trainer(0)
+        self._refresh_operands()
+        self._base_sd = {k: v.detach() for k, v in sd.items()}
+
+    def load_optimizer_state_dict(self, st):
+        self.opt.t = int(st["step"])
+        for k in self.opt.m:
+            self.opt.m[k].copy_(st["exp_avg"][k]); self.opt.v[k].copy_(st["exp_avg_sq"][k])
+
+
 # ------------------------------------------------------------------------------------------------ loss core
 def pair_forward(x, y, scale: float, label_off: int = 0, w_row: float = 0.5, w_col: float = 0.5):
     """loss contribution w_row*CE(scale*x y^T) + w_col*CE(columns); returns (loss[1] tensor, ctx)."""
     xb, yb = ops.split_bf16x3(x, 0), ops.split_bf16x3(y, 1)
-    logits = ops.gemm(xb, yb, None, epi=ops.EPI_F32, alpha=scale)
+    logits = ops.logits_gemm(xb, yb, scale)
     row_lse, col_lse, diag = ops.ce_stats(logits, label_off, want_cols=(w_col != 0.0))
     loss = torch.zeros(1, device=x.device, dtype=torch.float32)
     ops.ce_loss_accum(loss, row_lse if w_row != 0.0 else None, col_lse, diag, x.shape[0], y.shape[0], label_off, w_row, w_col)
@@ -102,7 +176,7 @@ def pair_loss_and_grads(comm, rank: int, world: int, xl, yl, ax, ay, scale: floa
     return loss, (fold(dxl, d_ax) if need_x else None), (fold(dyl, d_ay) if need_y else None), ds
 
 
-class TriModalDepthStep:
+class TriModalDepthStep(_StepState):
     def __init__(self, sd: Dict[str, torch.Tensor], tower: TowerCfg, text: TextCfg, device, micro_batch: int = 256,
                  unlock_first_n: int = 4, lr: float = 5e-4, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2,
                  rank: int = 0, world_size: int = 1, gemm_cfg: int = -1, comm=None, frozen_res_dtype=torch.float32,
@@ -110,6 +184,7 @@ class TriModalDepthStep:
         self.dev, self.mb, self.rank, self.world = torch.device(device), micro_batch, rank, world_size
         self.comm = comm or TorchComm()
         self.local_loss, self.gather_with_grad = local_loss, gather_with_grad
+        self._base_sd = {k: v.detach() for k, v in sd.items()}
         # frozen towers: forward only; their residual stream may be kept in bf16 (= the reference's autocast)
         self.image = VitEngine(sd, "image.", tower, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
         self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
@@ -118,7 +193,7 @@ class TriModalDepthStep:
                                res_dtype=train_res_dtype)
         self.trainers = []            # one activation store per micro-batch (created lazily)
         self.unlock_first_n = unlock_first_n
-        self.logit_scale = sd["logit_scale"].detach().float().reshape(1).to(device)
+        self.logit_scale = sd["logit_scale"].detach().float().reshape(1).to(device).clone()
         # fp32 masters of the trainable set (reference lock recipe: adapter + first n blocks + logit_scale)
         self.masters: Dict[str, torch.Tensor] = {"logit_scale": self.logit_scale}
         self.bf16_targets = {}
@@ -128,14 +203,16 @@ class TriModalDepthStep:
             w = eng.blocks[l]
             for nm, key in (("attn.in_proj_weight", "in_w"), ("attn.out_proj.weight", "out_w"), ("mlp.c_fc.weight", "fc_w"),
                             ("mlp.c_proj.weight", "proj_w")):
-                self.masters[p + nm] = sd[p + nm].detach().float().to(device).contiguous()
+                self.masters[p + nm] = sd[p + nm].detach().float().to(device).contiguous().clone()      # never an alias of the caller's tensor
                 self.bf16_targets[p + nm] = (l, key)
             for nm, key in (("ln_1.weight", "ln1_w"), ("ln_1.bias", "ln1_b"), ("ln_2.weight", "ln2_w"), ("ln_2.bias", "ln2_b"),
                             ("attn.in_proj_bias", "in_b"), ("attn.out_proj.bias", "out_b"), ("mlp.c_fc.bias", "fc_b"),
                             ("mlp.c_proj.bias", "proj_b")):
                 self.masters[p + nm] = w[key]                   # f32 tensors the kernels read directly
         self.masters["visual.visual_adapter.pos_emb"] = self.lens.adapter_pos
-        self.masters["visual.visual_adapter.conv1.weight_gemm"] = self.lens.conv_w.float()
+        from .engine import conv_weight_as_gemm
+        self.masters["visual.visual_adapter.conv1.weight_gemm"] = conv_weight_as_gemm(       # from the fp32 weight, not the bf16 operand
+            sd["visual.visual_adapter.conv1.weight"], device, torch.float32)
         self.opt = AdamW(self.masters, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.flat_grad = None
         self.grads: Dict[str, torch.Tensor] = {}
@@ -164,6 +241,8 @@ class TriModalDepthStep:
 
     def _refresh_operands(self):
         eng = self.lens.vit
+        if not self.trainers:
+            self._trainer(0)
         for name, (l, key) in self.bf16_targets.items():
             m = self.masters[name]
             ops.cast_bf16(m, out=eng.blocks[l][key])
@@ -225,7 +304,7 @@ class TriModalDepthStep:
         return loss
 
 
-class _PerceiverLensStep:
+class _PerceiverLensStep(_StepState):
     """Shared plumbing of the steps whose trainable part is a Lens (tokenizer + Perceiver) in front of a locked ViT:
     fp32 masters of the Perceiver under the reference's parameter names, one flat fp32 gradient buffer (a single
     all-reduce per step = DDP's mean of per-rank gradients), AdamW, bf16 operand refresh, logit-scale clamp."""
@@ -235,7 +314,8 @@ class _PerceiverLensStep:
         self.comm = comm or TorchComm()
         self.local_loss, self.gather_with_grad = local_loss, gather_with_grad
         self.trainers = []
-        self.logit_scale = sd["logit_scale"].detach().float().reshape(1).to(device)
+        self._base_sd = {k: v.detach() for k, v in sd.items()}
+        self.logit_scale = sd["logit_scale"].detach().float().reshape(1).to(device).clone()
         self.masters: Dict[str, torch.Tensor] = {"logit_scale": self.logit_scale}
         self.refresh = []        # (master name, forward bf16 tensor, key path of the transposed copy in trainer.perc.wT)
         self.flat_grad, self.grads = None, {}
@@ -245,7 +325,7 @@ class _PerceiverLensStep:
         if getattr(self.lens.lens, "weight_tie_layers", False) and len(pe.layers) > 1:
             # tied layers share parameters (perceiver.py:249-254): their gradients would have to be summed into one master
             raise NotImplementedError("training a Perceiver with perceiver_weight_tie_layers=True is not implemented")
-        f32 = lambda k: sd[k].detach().float().to(self.dev).contiguous()
+        f32 = lambda k: sd[k].detach().float().to(self.dev).contiguous().clone()
         self.masters[P + "latents"] = pe.latents
         for li, lay in enumerate(pe.layers):
             q = f"{P}layers.{li}."
@@ -349,7 +429,9 @@ class DualAudioStep(_PerceiverLensStep):
         self._mk = lambda: AudioLensTrainer(self.lens)
         self.masters["visual.class_embedding"] = self.lens.vit.cls
         self.masters["visual.visual_adapter.pos_emb"] = self.lens.adapter_pos
-        self.masters["visual.visual_adapter.conv1.weight_gemm"] = self.lens.conv_w.float()
+        from .engine import conv_weight_as_gemm
+        self.masters["visual.visual_adapter.conv1.weight_gemm"] = conv_weight_as_gemm(
+            sd["visual.visual_adapter.conv1.weight"], device, torch.float32)
         self._collect_perceiver(sd)
         self.opt = AdamW(self.masters, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
 
