@@ -58,3 +58,41 @@ def test_oracle_equals_reference_at_vitl_size():
     assert res["n_params"] > 8e8
     for k in ("image", "text", "audio", "pc"):
         assert res[k] < 2e-5, res
+
+
+_FLOOR = r'''
+import json, sys, torch
+sys.path.insert(0, sys.argv[1])
+import ref_loader
+oc = ref_loader.load()
+import vitlens_oracle as O
+spec = O.TextSpec()
+g = torch.Generator().manual_seed(77)            # the weights / texts of tests/test_hip_towers.py::test_vitl_text_tower_vs_oracle
+sd = O.init_text(spec, g)
+text = O.synth_text(4, g)
+torch.manual_seed(0)
+model = oc.tri_create_model("ViT-L-14", None, precision="fp32", device="cpu", output_dict=True, args=ref_loader.lens_args("depth")).eval()
+model.load_state_dict(sd, strict=False)
+cosm = lambda a: (lambda n: n @ n.t())(torch.nn.functional.normalize(a.float(), dim=-1))
+with torch.no_grad():
+    f32 = model.encode_text(text)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        fbf = model.encode_text(text)
+print("JSON" + json.dumps({"cos_matrix": float((cosm(fbf) - cosm(f32)).abs().max()),
+                           "feature_cos": float(torch.nn.functional.cosine_similarity(fbf.float(), f32, dim=-1).min()),
+                           "mutual": float(cosm(f32)[0, 1])}))
+'''
+
+
+@pytest.mark.needs_reference
+def test_reference_amp_bf16_floor_of_the_text_tower():
+    """north_star asks for cosine matrices within 1e-3 of the fp32 CPU path.  On the random-init ViT-L text tower (features
+    with a mutual cosine of ~0.6) the REFERENCE ITSELF under its amp_bf16 autocast is 1.4e-3 away from its own fp32 path;
+    the HIP path (bf16 operands, fp32 residual stream) is held to 2e-3 on the same case (tests/test_hip_towers.py) and to
+    1e-3 on the per-feature cosine.  This test pins that floor so the relaxed bound is a measured property of bf16
+    arithmetic on this input, not a loosened criterion (DESIGN.md section 5)."""
+    r = subprocess.run([sys.executable, "-c", _FLOOR, os.path.join(ROOT, "oracle")], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads(r.stdout[r.stdout.index("JSON") + 4:])
+    assert 1.0e-3 < res["cos_matrix"] < 2.0e-3, res
+    assert res["feature_cos"] > 0.9999 and 0.5 < res["mutual"] < 0.7, res
