@@ -51,6 +51,7 @@ SIGNATURES = {
     "vl_gemm_qkv_bf16_ex": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, I, I, P],
     "vl_layernorm_bwd": [P, I, L, P, I, L, P, P, P, P, P, P, L, I, I, P],
     "vl_layernorm_bwd_g": [P, I, L, P, I, L, P, P, P, P, P, I, P, L, I, I, P],
+    "vl_colreduce_ws_floats": [I, I, I],
     "vl_layernorm_bwd_params": [P, I, L, P, I, L, P, P, P, P, I, I, P, P],
     "vl_colsum": [P, I, L, P, I, I, F, P, P],
     "vl_gelu_bf16": [P, P, L, P],
@@ -62,6 +63,10 @@ SIGNATURES = {
     "vl_axpy_f32": [P, P, F, L, P],
     "vl_batch_rowsum": [P, P, I, I, I, L, L, P],
 }
+
+
+# functions that do not return a status code
+_RET = {"vl_colreduce_ws_floats": L}
 
 
 def load_library():
@@ -80,7 +85,7 @@ def load_library():
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = args
-        fn.restype = I
+        fn.restype = _RET.get(name, I)
     _LIB = lib
     return lib
 

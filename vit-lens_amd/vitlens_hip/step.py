@@ -28,7 +28,10 @@ class TorchComm:
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         import torch.distributed as dist
-        dist.all_gather_into_tensor(out, inp)
+        if inp.is_cuda:
+            dist.all_gather_into_tensor(out, inp)
+        else:          # gloo
+            dist.all_gather(list(out.chunk(dist.get_world_size(), dim=0)), inp.contiguous())
 
     def all_reduce_sum(self, t: torch.Tensor):
         import torch.distributed as dist
@@ -37,7 +40,19 @@ class TorchComm:
     def reduce_scatter_sum(self, out: torch.Tensor, inp: torch.Tensor):
         """out [b, E] = this rank's slice of the sum over ranks of inp [W*b, E] (backward of a gather WITH grad)."""
         import torch.distributed as dist
-        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM)
+        if inp.is_cuda:
+            dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM)
+        else:          # gloo (CPU tests) has no reduce_scatter
+            t = inp.clone()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            r = dist.get_rank()
+            out.copy_(t[r * out.shape[0]:(r + 1) * out.shape[0]])
+
+    def all_reduce_sum_async(self, t: torch.Tensor):
+        """Start an all-reduce and return a handle with .wait(): on RCCL the collective runs on the communicator's own
+        stream behind the kernels already enqueued, so a gradient bucket is reduced under the rest of the backward."""
+        import torch.distributed as dist
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
 
 # ------------------------------------------------------------------------------------------------ checkpointing
@@ -216,6 +231,7 @@ class TriModalDepthStep(_StepState):
         self.opt = AdamW(self.masters, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.flat_grad = None
         self.grads: Dict[str, torch.Tensor] = {}
+        self._pending, self._reduced_upto = [], None
 
     # -------------------------------------------------------------------------------------------
     def _trainer(self, i):
@@ -257,12 +273,43 @@ class TriModalDepthStep(_StepState):
 
     def optimizer_step(self):
         if self.world > 1:
-            self.comm.all_reduce_sum(self.flat_grad)                # DDP: mean of per-rank gradients
+            # DDP semantics: mean of per-rank gradients.  Block buckets were started during the last micro-batch's backward
+            # (reverse layer order); what is left - logit_scale and the adapter, produced last - goes in one more call.
+            for h in self._pending:
+                h.wait()
+            self._pending = []
+            if self._reduced_upto is None:
+                self.comm.all_reduce_sum(self.flat_grad)
+            else:
+                lo, hi = self._rest_ranges()
+                for a, b in ((0, lo), (hi, self.flat_grad.numel())):
+                    if b > a:
+                        self.comm.all_reduce_sum(self.flat_grad[a:b])
+            self._reduced_upto = None
             self.opt.step(self.grads, grad_scale=1.0 / self.world)
         else:
             self.opt.step(self.grads)
         self._refresh_operands()
         ops.clamp_scalar(self.logit_scale, 0.0, math.log(100.0))
+
+    # ---- gradient buckets: the masters of one block are contiguous in the flat buffer ----
+    def _block_range(self, l):
+        p = f"visual.transformer.resblocks.{l}."
+        names = [k for k in self.masters if k.startswith(p)]
+        base = self.flat_grad.data_ptr()
+        lo = min((self.grads[k].data_ptr() - base) // 4 for k in names)
+        hi = max((self.grads[k].data_ptr() - base) // 4 + self.grads[k].numel() for k in names)
+        return lo, min((hi + 3) // 4 * 4, self.flat_grad.numel())          # incl. the 16-byte alignment pad of the last view
+
+    def _rest_ranges(self):
+        rs = [self._block_range(l) for l in range(self.unlock_first_n)]
+        return min(r[0] for r in rs), max(r[1] for r in rs)
+
+    def _start_block_reduce(self, l):
+        if self.world > 1 and hasattr(self.comm, "all_reduce_sum_async"):
+            lo, hi = self._block_range(l)
+            self._pending.append(self.comm.all_reduce_sum_async(self.flat_grad[lo:hi]))
+            self._reduced_upto = l
 
     def forward_backward(self, images: torch.Tensor, texts: torch.Tensor, depths: torch.Tensor) -> torch.Tensor:
         B = images.shape[0]
@@ -273,6 +320,9 @@ class TriModalDepthStep(_StepState):
             for i in range(nmb):
                 self._trainer(i)
             self._alloc_flat_grads()
+        for h in self._pending:          # (a forward_backward without optimizer_step: finish what was started)
+            h.wait()
+        self._pending, self._reduced_upto = [], None
         self.flat_grad.zero_()
         E = self.image.cfg.embed_dim
         fi = torch.empty(B, E, device=self.dev); ft = torch.empty(B, E, device=self.dev)
@@ -298,7 +348,9 @@ class TriModalDepthStep(_StepState):
         loss = l1 + l2
         dvraw = ops.l2_normalize_bwd(fv, dv1 + dv2, vnorm)
         for i in range(nmb):
-            self._trainer(i).backward(dvraw[i * mb:(i + 1) * mb].contiguous())
+            # gradients accumulate over micro-batches: a block's bucket is final once the LAST micro-batch has passed it
+            cb = self._start_block_reduce if (i == nmb - 1 and self.world > 1 and self.unlock_first_n > 0) else None
+            self._trainer(i).backward(dvraw[i * mb:(i + 1) * mb].contiguous(), cb)
         # logit_scale is exp()'d in forward (model.py:619): d/d(log-scale) = dscale * scale
         self.grads["logit_scale"] += (ds1 + ds2) * scale
         return loss

@@ -130,8 +130,10 @@ class TowerTrainer:
         xt = ops.transpose_colsum(x, rp)
         ops.gemm_dw(dyt, xt, g, cfg=self.eng.gemm_cfg)
 
-    def backward(self, dfeat: torch.Tensor) -> torch.Tensor:
-        """dfeat f32 [B, E] -> gradient w.r.t. the input tokens, f32 [B*T, D]; fills self.grads."""
+    def backward(self, dfeat: torch.Tensor, on_block_done=None) -> torch.Tensor:
+        """dfeat f32 [B, E] -> gradient w.r.t. the input tokens, f32 [B*T, D]; fills self.grads.
+        on_block_done(l) is called as soon as every gradient of trainable block l has been enqueued (the multi-GPU step
+        starts that block's gradient all-reduce there, under the backward of the blocks below it)."""
         e, D, H = self.eng, self.D, self.H
         B, L, tokens, has_pos2 = self.ctx
         dh = D // H
@@ -192,6 +194,8 @@ class TowerTrainer:
                 ops.layernorm_bwd_params(S.dh, S.X[2 * l], m1, r1, self.grad_buffer(bp + "ln_1.weight", w["ln1_w"]),
                                          self.grad_buffer(bp + "ln_1.bias", w["ln1_b"]), rows, D)
             ops.layernorm_bwd(S.dh, S.X[2 * l], m1, r1, w["ln1_w"], rows, D, dres=S.dx, dx=S.dx, dx_bf16=dxb_out)
+            if trainable and on_block_done is not None:
+                on_block_done(l)
         # ---- ln_pre and the [cls; tokens] + pos assembly ----
         dxpre = torch.empty(S.dx.shape, device=S.dx.device, dtype=torch.float32)
         if self.train_ln_pre:
@@ -227,9 +231,9 @@ class DepthLensTrainer:
         self.ctx = (cols, x.shape[0])
         return self.tower.forward(tok, x.shape[0], pos2=le.adapter_pos)
 
-    def backward(self, dfeat: torch.Tensor):
+    def backward(self, dfeat: torch.Tensor, on_block_done=None):
         cols, B = self.ctx
-        dtok = self.tower.backward(dfeat)                       # f32 [B*T, D]
+        dtok = self.tower.backward(dfeat, on_block_done)         # f32 [B*T, D]
         T, D = dtok.shape[0] // B, dtok.shape[1]
         t = self.tower
         g = t.grad_buffer("visual.visual_adapter.conv1.weight_gemm", torch.empty(D, cols.shape[1]))
