@@ -93,13 +93,16 @@ int vl_gemm_qkv_bf16_ex(const void* A, const void* Win, const float* bias, void*
 int vl_device_info(int device, char* arch, int arch_len, int* cus, int* clock_khz, long* hbm_bytes);
 
 /* Fused attention forward: softmax(q k^T [+ causal mask]) v without materialising the scores.
- * q [B,H,Lq,dh] (pre-scaled by softmax_scale*log2e), k [B,H,Lk,dh], vt [B,H,dh,Lkp];
- * out [B,Lq,H*dh] bf16 (token-major, ready for the out-projection); lse [B,H,Lq] optional
- * (natural-log LSE of the scaled scores, kept for the backward pass).  dh in {32, 64}.
+ * q, k, v are STRIDED [B,H,L,dh] views: element (b,h,l,d) of operand i at ptr_i[b*strides[3i] + h*strides[3i+1] +
+ * l*strides[3i+2] + d] (strides in elements, multiples of 8; i = 0,1,2 for q,k,v) - normally the three column blocks of
+ * the packed in-projection output [tokens, 3*width], read in place.  q is multiplied by qscale (softmax_scale*log2e;
+ * pass 1 for a pre-scaled q) as it is loaded; V is transposed while it is staged into LDS.
+ * out [B,Lq,H*dh] bf16 (token-major, ready for the out-projection); lse [B,H,Lq] optional (natural-log LSE of the
+ * scaled scores, kept for the backward pass).  dh in {32, 64}.
  * Replaces F.multi_head_attention_forward (transformer.py:241-252, causal mask :870-876) and
  * the Perceiver einsum attention (perceiver.py:128-145). */
-int vl_attn_fwd_bf16(const void* q, const void* k, const void* vt, void* out, float* lse,
-                     int B, int H, int Lq, int Lk, int Lkp, int dh, int causal, hipStream_t stream);
+int vl_attn_fwd_bf16(const void* q, const void* k, const void* v, const long* strides, void* out, float* lse,
+                     int B, int H, int Lq, int Lk, int dh, float qscale, int causal, hipStream_t stream);
 
 /* LayerNorm over the last dim (eps inside sqrt, biased variance): y = (x-mean)*rstd*w + b.
  * Source row for output row r is  r*row_mul + row_index[r]  when row_index != NULL (EOT gather,
@@ -183,15 +186,15 @@ int vl_colsum(const void* a, int a_dtype, long lda, float* out, int rows, int co
 int vl_gelu_bf16(const void* u, void* y, long n, hipStream_t stream);
 /* y[m,j] = h[m,2j] * gelu(h[m,2j+1])  (recompute of the GEGLU output from the saved pre-activation) */
 int vl_geglu_bf16(const void* h, void* y, long rows, int n_out, hipStream_t stream);
-/* delta[b,h,l] = sum_d dO[b,h,l,d] * O[b*L+l, h*dh+d] */
-int vl_attn_delta(const void* dO, const void* o, float* delta, int B, int H, int L, int dh, hipStream_t stream);
-/* Attention backward (see csrc/vl_attn_bwd.hip): dq/dk/dv are token-major bf16 destinations with row
- * strides ld_dq / ld_dkv, already offset to their column block; scale = softmax scale. */
-int vl_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* qt, const void* kt,
-                     const void* dO, const void* dOt, const float* lse, const float* delta,
-                     void* dq, void* dk, void* dv, long ld_dq, long ld_dkv,
-                     int B, int H, int Lq, int Lk, int Lqp, int Lkp, int dh, int causal, float scale,
-                     hipStream_t stream);
+/* Attention backward (see csrc/vl_attn_bwd.hip).  q, k, v, dO, o are strided [B,H,L,dh] views (strides[15]: sb, sh, sr
+ * in elements for q, k, v, dO, o in that order - multiples of 8), read in place: q/k/v out of the packed in-projection
+ * output, dO out of the out-projection's input gradient [tokens, width], o = the forward's token-major output.  q is
+ * multiplied by qscale (= scale*log2e) as it is loaded, as in the forward.  delta [B,H,Lq] fp32 is a caller workspace:
+ * rowsum(dO*o) is produced by the first kernel and consumed by the second.  dq/dk/dv are token-major bf16 destinations
+ * with row strides ld_dq / ld_dkv, already offset to their column block; scale = softmax scale. */
+int vl_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dO, const void* o, const long* strides,
+                     const float* lse, float* delta, void* dq, void* dk, void* dv, long ld_dq, long ld_dkv,
+                     int B, int H, int Lq, int Lk, int dh, float qscale, int causal, float scale, hipStream_t stream);
 /* torch.optim.AdamW step on one tensor (grad is multiplied by grad_scale first); step counts from 1. */
 /* ---- point-cloud tokenizer (PointBERT grouping) ---- */
 /* farthest point sampling: xyz [B,N,3] f32, start [B] (the reference draws it with torch.randint, misc.py:60);

@@ -119,39 +119,77 @@ def test_gelu_erf_accuracy():
     assert bool(((out - ref).abs() <= ulp).all())
 
 
-@pytest.mark.parametrize("B,L,H,dh", [(2, 257, 16, 64), (3, 77, 12, 64), (2, 17, 2, 32), (1, 600, 1, 64), (65, 257, 16, 64)])
+def _attn_reference(qf, kf, vf, causal):
+    s = qf @ kf.transpose(-1, -2)
+    if causal:
+        Lq, Lk = s.shape[-2:]
+        s = s + torch.full((Lq, Lk), float("-inf")).triu_(1)
+    return torch.softmax(s, -1) @ vf, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,L,H,dh", [(2, 257, 16, 64), (3, 77, 12, 64), (2, 17, 2, 32), (1, 600, 1, 64), (65, 257, 16, 64),
+                                      (2, 256, 8, 64), (2, 289, 4, 64), (3, 33, 2, 64), (2, 257, 4, 32), (1, 1, 2, 64)])
 @pytest.mark.parametrize("causal", [False, True])
-def test_qkv_and_attention(B, L, H, dh, causal):
-    """in_proj GEMM + head split + fused attention vs explicit softmax(QK^T/sqrt(d)+mask)V in fp32 on the
-    bf16-rounded q/k/v.  P is rounded to bf16 before P·V (flash-attention practice) => abs err <= 2e-2·max|v|."""
+def test_inproj_and_attention(B, L, H, dh, causal):
+    """in_proj GEMM (packed [tokens, 3*width] output) + fused attention reading q / k / v out of it IN PLACE vs explicit
+    softmax(QK^T/sqrt(d)+mask)V in fp32 on the same bf16-rounded operands.  P is rounded to bf16 before P.V
+    (flash-attention practice) => abs err <= 2e-2*max|v|.  L = 257 / 33 take the shared-last-row path (8 waves + one
+    row), 289 the two-workgroup path, 600 the multi-chunk path."""
     ops = _ops()
     D = H * dh
     x = rnd(B * L, D, seed=9).bfloat16().cuda()
     w = rnd(3 * D, D, seed=10, scale=D ** -0.5).bfloat16().cuda()
     bias = rnd(3 * D, seed=11, scale=0.1).cuda()
-    Lp = (L + 7) // 8 * 8
-    q = torch.empty(B, H, L, dh, dtype=torch.bfloat16, device="cuda"); k = torch.empty_like(q)
-    vt = torch.full((B, H, dh, Lp), float("nan"), dtype=torch.bfloat16, device="cuda")  # poison the pad
-    ops.gemm_qkv(x, w, bias, q, k, vt, B, L, H, dh)
-    qkv = x.float().cpu() @ w.float().cpu().t() + bias.cpu()
-    qr, kr, vr = [t.reshape(B, L, H, dh).permute(0, 2, 1, 3) for t in qkv.split(D, dim=-1)]
-    scale = dh ** -0.5 * ops.LOG2E
-    assert relerr(q, qr * scale) < 4e-3
-    assert relerr(k, kr) < 4e-3
-    assert relerr(vt[..., :L].transpose(-1, -2), vr) < 4e-3
-    out = torch.empty(B * L, D, dtype=torch.bfloat16, device="cuda")
-    lse = torch.empty(B, H, L, device="cuda")
-    ops.attn_fwd(q, k, vt, out, lse=lse, causal=causal)
-    qf, kf, vf = q.float().cpu() / ops.LOG2E, k.float().cpu(), vt[..., :L].float().cpu().transpose(-1, -2)
-    s = qf @ kf.transpose(-1, -2)
-    if causal:
-        s = s + torch.full((L, L), float("-inf")).triu_(1)
-    ref = torch.softmax(s, -1) @ vf
+    qkv = torch.empty(B * L, 3 * D, dtype=torch.bfloat16, device="cuda")
+    ops.gemm(x, w, bias, out=qkv, epi=ops.EPI_BF16)
+    ref_qkv = x.float().cpu() @ w.float().cpu().t() + bias.cpu()
+    assert relerr(qkv, ref_qkv) < 4e-3
+    q, k, v = (ops.heads_view(qkv, B, L, H, dh, i * D) for i in range(3))
+    out = torch.full((B * L, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    lse = torch.full((B, H, L), float("nan"), device="cuda")
+    qscale = dh ** -0.5 * ops.LOG2E
+    ops.attn_fwd(q, k, v, out, lse=lse, causal=causal, qscale=qscale)
+    qf = (q.float().cpu() * qscale).bfloat16().float() / ops.LOG2E          # the kernel rounds the scaled q to bf16
+    ref, ref_lse = _attn_reference(qf, k.float().cpu(), v.float().cpu(), causal)
     ref = ref.permute(0, 2, 1, 3).reshape(B * L, D)
     assert torch.isfinite(out.float()).all()
-    assert maxerr(out, ref) < 2e-2 * float(vf.abs().max()), maxerr(out, ref)
+    assert maxerr(out, ref) < 2e-2 * float(v.float().abs().max()), maxerr(out, ref)
     assert relerr(out, ref) < 1e-2
-    assert maxerr(lse, torch.logsumexp(s, -1)) < 1e-3
+    assert maxerr(lse, ref_lse) < 1e-3
+
+
+@pytest.mark.parametrize("Lq,Lk,H,dh", [(256, 600, 2, 64), (256, 512, 8, 64), (257, 100, 2, 64), (64, 257, 2, 64), (256, 289, 1, 32)])
+def test_cross_attention_contiguous_heads_and_large_scores(Lq, Lk, H, dh):
+    """Perceiver cross-attention geometry (Lq != Lk, several LDS chunks) on contiguous [B,H,L,dh] operands with a
+    pre-scaled q (qscale = 1), plus scores far from zero: the kernel keeps the running maximum lazily (rescales only when
+    it grows by more than 2^8), so rows whose maximum climbs chunk after chunk, rows that are very negative everywhere and
+    rows with one dominant key must all come out right."""
+    ops = _ops()
+    B = 2
+    g = torch.Generator().manual_seed(Lq + Lk)
+    q = torch.randn(B, H, Lq, dh, generator=g)
+    k = torch.randn(B, H, Lk, dh, generator=g)
+    v = torch.randn(B, H, Lk, dh, generator=g)
+    ramp = torch.linspace(0.0, 6.0, Lk).view(1, 1, Lk, 1)                       # later keys score higher: max keeps growing
+    k = k * (1 + ramp)
+    q[:, :, 0] *= 8.0                                                            # one very peaked row
+    k[:, :, Lk // 2] *= 4.0
+    q, k, v = q.bfloat16().cuda(), k.bfloat16().cuda(), v.bfloat16().cuda()
+    out = torch.empty(B * Lq, H * dh, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B, H, Lq, device="cuda")
+    ops.attn_fwd(q, k, v, out, lse=lse, qscale=1.0)
+    ref, ref_lse = _attn_reference(q.float().cpu() / ops.LOG2E, k.float().cpu(), v.float().cpu(), False)
+    ref = ref.permute(0, 2, 1, 3).reshape(B * Lq, H * dh)
+    assert torch.isfinite(out.float()).all()
+    assert relerr(out, ref) < 1e-2, relerr(out, ref)
+    assert maxerr(lse, ref_lse) < 2e-3 * max(1.0, float(ref_lse.abs().max()))
+    # very negative scores everywhere (offset the keys along q's direction): no underflow to 0/0
+    q2 = torch.ones(B, H, Lq, dh).bfloat16().cuda()
+    k2 = (torch.randn(B, H, Lk, dh, generator=g) * 0.1 - 3.0).bfloat16().cuda()
+    ops.attn_fwd(q2, k2, v, out, lse=lse, qscale=1.0)
+    ref, ref_lse = _attn_reference(q2.float().cpu() / ops.LOG2E, k2.float().cpu(), v.float().cpu(), False)
+    assert relerr(out, ref.permute(0, 2, 1, 3).reshape(B * Lq, H * dh)) < 1e-2
+    assert maxerr(lse, ref_lse) < 2e-3 * float(ref_lse.abs().max())
 
 
 @pytest.mark.parametrize("D", [1024, 768, 512, 384, 64, 24])

@@ -86,39 +86,72 @@ def test_vitl_block_backward_vs_oracle_autograd():
     assert len(tr.grads) == 12
 
 
-@pytest.mark.parametrize("B,L,H,dh,causal", [(2, 257, 4, 64, False), (2, 77, 3, 64, True), (1, 40, 2, 32, False)])
+@pytest.mark.parametrize("B,L,H,dh,causal", [(2, 257, 4, 64, False), (2, 77, 3, 64, True), (1, 40, 2, 32, False),
+                                             (2, 257, 2, 64, True), (1, 256, 2, 64, False), (1, 289, 2, 64, False),
+                                             (2, 33, 2, 32, False), (1, 600, 1, 64, False)])
 def test_attention_backward(B, L, H, dh, causal):
+    """dq / dk / dv (and the in-kernel delta) against autograd through explicit softmax attention on the same bf16 q, k, v,
+    all operands read in place from token-major matrices.  257 / 33 = shared last query AND key row, 289 = two
+    workgroups per (b, h), 600 = several LDS chunks."""
     from vitlens_hip import ops
     D = H * dh
     g = torch.Generator().manual_seed(5)
     x = (torch.randn(B * L, D, generator=g)).bfloat16().cuda()
     w = (torch.randn(3 * D, D, generator=g) * D ** -0.5).bfloat16().cuda()
-    Lp = (L + 7) // 8 * 8
     mk = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device="cuda")
-    q, k, v = mk(B, H, L, dh), mk(B, H, L, dh), mk(B, H, L, dh)
-    vt, qt, kt = [torch.full((B, H, dh, Lp), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(3)]
-    ops.gemm_qkv(x, w, None, q, k, vt, B, L, H, dh, qt=qt, kt=kt, v=v)
+    qkv = mk(B * L, 3 * D)
+    ops.gemm(x, w, None, out=qkv, epi=ops.EPI_BF16)
+    q, k, v = (ops.heads_view(qkv, B, L, H, dh, i * D) for i in range(3))
     o = mk(B * L, D); lse = torch.empty(B, H, L, device="cuda")
-    ops.attn_fwd(q, k, vt, o, lse=lse, causal=causal)
-    do_tok = torch.randn(B * L, D, generator=g).bfloat16()
-    dO = do_tok.reshape(B, L, H, dh).permute(0, 2, 1, 3).contiguous().cuda()
-    dOt = torch.zeros(B, H, dh, Lp, dtype=torch.bfloat16, device="cuda"); dOt[..., :L] = dO.transpose(-1, -2)
-    delta = torch.empty(B, H, L, device="cuda")
-    ops.attn_delta(dO, o, delta)
-    dqkv = mk(B * L, 3 * D)
-    ops.attn_bwd(q, k, v, qt, kt, dO, dOt, lse, delta, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D, 3 * D, causal=causal)
-    # reference: autograd through explicit softmax attention on the same bf16-rounded q,k,v (q un-scaled)
-    qr = (q.float().cpu() / (dh ** -0.5 * ops.LOG2E)).requires_grad_(True)
+    qscale = dh ** -0.5 * ops.LOG2E
+    ops.attn_fwd(q, k, v, o, lse=lse, causal=causal, qscale=qscale)
+    do_tok = torch.randn(B * L, D, generator=g).bfloat16().cuda()
+    delta = torch.full((B, H, L), float("nan"), device="cuda")
+    dqkv = torch.full((B * L, 3 * D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.attn_bwd(q, k, v, ops.heads_view(do_tok, B, L, H, dh), ops.heads_view(o, B, L, H, dh), lse, delta,
+                 dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D, 3 * D, causal=causal)
+    # reference: autograd through explicit softmax attention; the kernels use q2 = bf16(q * qscale)
+    qr = q.float().cpu().requires_grad_(True)
     kr = k.float().cpu().requires_grad_(True); vr = v.float().cpu().requires_grad_(True)
     s = (qr @ kr.transpose(-1, -2)) * dh ** -0.5
     if causal:
         s = s + torch.full((L, L), float("-inf")).triu_(1)
     out = torch.softmax(s, -1) @ vr
-    (out * dO.float().cpu()).sum().backward()
+    dO = do_tok.float().cpu().reshape(B, L, H, dh).permute(0, 2, 1, 3)
+    (out * dO).sum().backward()
     tok = lambda t: t.permute(0, 2, 1, 3).reshape(B * L, D)
+    assert torch.isfinite(dqkv.float()).all()
+    assert relerr(delta, (out.detach() * dO).sum(-1)) < 1e-2
     assert relerr(dqkv[:, :D], tok(qr.grad)) < 2e-2, relerr(dqkv[:, :D], tok(qr.grad))
     assert relerr(dqkv[:, D:2 * D], tok(kr.grad)) < 2e-2, relerr(dqkv[:, D:2 * D], tok(kr.grad))
     assert relerr(dqkv[:, 2 * D:], tok(vr.grad)) < 2e-2, relerr(dqkv[:, 2 * D:], tok(vr.grad))
+
+
+@pytest.mark.parametrize("Lq,Lk", [(256, 600), (257, 64), (64, 257)])
+def test_cross_attention_backward(Lq, Lk):
+    """Perceiver cross-attention (Lq != Lk): q from one matrix, k | v packed in another."""
+    from vitlens_hip import ops
+    B, H, dh = 2, 2, 64
+    inner = H * dh
+    g = torch.Generator().manual_seed(Lq * 7 + Lk)
+    mk = lambda *s: torch.randn(*s, generator=g).bfloat16().cuda()
+    q2, kv2, do2 = mk(B * Lq, inner), mk(B * Lk, 2 * inner), mk(B * Lq, inner)
+    q = ops.heads_view(q2, B, Lq, H, dh); k = ops.heads_view(kv2, B, Lk, H, dh); v = ops.heads_view(kv2, B, Lk, H, dh, inner)
+    o = torch.empty(B * Lq, inner, dtype=torch.bfloat16, device="cuda"); lse = torch.empty(B, H, Lq, device="cuda")
+    ops.attn_fwd(q, k, v, o, lse=lse, qscale=dh ** -0.5 * ops.LOG2E)
+    delta = torch.empty(B, H, Lq, device="cuda")
+    dq = torch.full((B * Lq, inner), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dkv = torch.full((B * Lk, 2 * inner), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.attn_bwd(q, k, v, ops.heads_view(do2, B, Lq, H, dh), ops.heads_view(o, B, Lq, H, dh), lse, delta, dq, dkv,
+                 dkv[:, inner:], inner, 2 * inner)
+    qr = q.float().cpu().requires_grad_(True); kr = k.float().cpu().requires_grad_(True); vr = v.float().cpu().requires_grad_(True)
+    out = torch.softmax((qr @ kr.transpose(-1, -2)) * dh ** -0.5, -1) @ vr
+    (out * do2.float().cpu().reshape(B, Lq, H, dh).permute(0, 2, 1, 3)).sum().backward()
+    tok = lambda t, L: t.permute(0, 2, 1, 3).reshape(B * L, inner)
+    assert relerr(o, tok(out.detach(), Lq)) < 1e-2
+    assert relerr(dq, tok(qr.grad, Lq)) < 2e-2
+    assert relerr(dkv[:, :inner], tok(kr.grad, Lk)) < 2e-2
+    assert relerr(dkv[:, inner:], tok(vr.grad, Lk)) < 2e-2
 
 
 def test_layernorm_backward_and_params():

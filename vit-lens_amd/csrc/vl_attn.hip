@@ -5,33 +5,54 @@
 // the Perceiver "Lens" (open_clip/perceiver.py:128-145).  The S = QK^T matrix and the
 // probabilities never reach HBM.
 //
-// Layout contract (produced by vl_gemm_qkv_bf16): q,k [B,H,L,DH] bf16, q already multiplied by
-// softmax_scale*log2(e); vt [B,H,DH,Lkp] = V transposed (key index contiguous).
+// Layout contract: q, k, v are strided [B,H,L,DH] views (vl_attn_common.h) -- normally column blocks of the packed
+// in-projection output [tokens, 3*width]; q is multiplied by qscale = softmax_scale*log2(e) when it is loaded (the
+// reference scales q in bf16 too, functional.py via transformer.py:241).  (Round 1 took head-split copies and V
+// transposed from the GEMM epilogue: 2-byte scattered stores that doubled the in-projection's epilogue time; the
+// transposition now happens while V is staged into LDS.)
 //
-// One workgroup = one (batch, head) x up to 16 query tiles of 32 rows (one wave per tile).  K and
-// V^T for a chunk of 288 keys sit in LDS (74 KB -> two workgroups per CU) and are shared by all
-// query waves.  Operands are swapped -- S^T = K·Q^T and O^T = V^T·P^T -- so that with the
-// 32x32x16 MFMA accumulator layout every lane owns ONE query column: the softmax row reduction is
-// 16 in-register values + one cross-half exchange, the running max / sum / rescale are per-lane
-// scalars, and P feeds the second MFMA straight from registers (the k-slot permutation of the
-// accumulator layout is absorbed by reading V^T with the same permutation).
-#include "vl_common.h"
+// One workgroup = one (batch, head) x up to 8 query tiles of 32 rows (one wave per tile), two workgroups per CU
+// (<= 80 KB LDS, <= 128 VGPRs) so that one workgroup's staging overlaps the other's MFMA/VALU work.  K and V^T for a
+// chunk of 288 keys sit in LDS and are shared by all query waves.  Operands are swapped -- S^T = K.Q^T and
+// O^T = V^T.P^T -- so that with the 32x32x16 MFMA accumulator layout every lane owns ONE query column: the softmax row
+// reduction is 16 in-register values + one cross-half exchange, the running max / sum are per-lane scalars, and P feeds
+// the second MFMA straight from registers.  The k-slot permutation of the accumulator layout is absorbed by the ORDER
+// in which V^T's key index is laid out in LDS (bits 2 and 3 of the key index swapped), so every V^T fragment is one
+// ds_read_b128.
+//
+// The kernel is VALU-bound (16 v_exp_f32 per lane per 32x32 tile against 8 MFMAs), so the softmax arithmetic is trimmed
+// to the exponentials: the running maximum enters as the MFMA's C operand (a register block holding -m), p = exp2(s)
+// needs no subtraction, and the block / the output accumulators are rescaled only when the maximum grew by more than
+// 2^8 (wave-uniform branch; p <= 256 in between, exact in fp32 / bf16 range).
+//
+// L = 257 (ViT-L/14 at 224: 8 full tiles + ONE row): the lone last query would cost a ninth wave nine tile passes for
+// one row.  Instead the 8 waves finish their own tiles and then share it: wave w computes the row's scores against key
+// tile w with the roles of the MFMA operands swapped (lane = key), reduces across lanes, multiplies by V through one
+// more MFMA and the 9 partial (max, sum, O) triples are merged through LDS.
+#include "vl_attn_common.h"
 #include "vitlens_hip.h"
 
 namespace {
+using namespace vlattn;
 
 constexpr int KC = 288;        // keys per LDS chunk (9 tiles of 32)
-constexpr int VS = KC + 4;     // V^T LDS row stride in elements: 584 B -> conflict-free ds_read_b64
+constexpr int VSP = KC + 8;    // V^T LDS row stride in elements: 592 B = 16 B x odd -> conflict-free ds_read_b128
+constexpr int NWMAX = 8;       // query waves per workgroup
+constexpr float RESCALE_THR = 8.0f;
 
 struct AttnP {
-  const bf16_t *q, *k, *vt;
+  TV q, k, v;
+  float qscale;  // applied to q at load (1 = already scaled)
   bf16_t* out;   // [B, Lq, H*DH]
   float* lse;    // [B, H, Lq] (natural-log domain of the scaled scores) or null
-  int B, H, Lq, Lk, Lkp, causal;
+  int B, H, Lq, Lk, causal;
+  int lq_main;   // queries handled by the per-wave tiles (Lq, or Lq-1 when the last row is shared)
 };
 
-template <int DH>
-__global__ void __launch_bounds__(576, 5) attn_fwd_kernel(const AttnP p) {
+// MULTI: more keys than one LDS chunk (the chunk loop restages inside the accumulation; kept out of the common
+// single-chunk instantiations, where its 12 loads in flight would push the tile loop's registers to scratch)
+template <int DH, bool TAILQ, bool MULTI>
+__global__ void __launch_bounds__(NWMAX * 64, 4) attn_fwd_kernel(const AttnP p) {
   constexpr int RB = DH * 2;          // K row bytes in LDS
   constexpr int CH = RB / 16;         // 16-byte chunks per row
   constexpr int RSH = (DH == 64) ? 1 : 2;  // rows per 256-B bank row = 2^RSH
@@ -39,7 +60,9 @@ __global__ void __launch_bounds__(576, 5) attn_fwd_kernel(const AttnP p) {
   constexpr int DT = DH / 32;         // 32-row tiles of O^T
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;                       // [KC][RB] swizzled
-  bf16_t* sV = (bf16_t*)(smem + KC * RB);         // [DH][VS]
+  bf16_t* sV = (bf16_t*)(smem + KC * RB);         // [DH][VSP], key order permuted inside 16-key slices
+  float* sP = (float*)(sV + DH * VSP);            // [NWMAX][32]   shared-row probabilities (TAILQ)
+  float* sPart = sP + NWMAX * 32;                 // [KC/32][2+DH] shared-row partials      (TAILQ)
 
   const int b = blockIdx.z, h = blockIdx.y;
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -48,82 +71,52 @@ __global__ void __launch_bounds__(576, 5) attn_fwd_kernel(const AttnP p) {
   const int nwq = nthr >> 6;
   const int fr = lane & 31, fg = lane >> 5;
   const size_t bh = (size_t)b * p.H + h;
-  const bf16_t* Kg = p.k + bh * p.Lk * DH;
-  const bf16_t* Vg = p.vt + bh * DH * (size_t)p.Lkp;
+  const bf16_t* Kg = p.k.p + b * p.k.sb + h * p.k.sh;
+  const bf16_t* Vg = p.v.p + b * p.v.sb + h * p.v.sh;
+  const bf16_t* Qb = p.q.p + b * p.q.sb + h * p.q.sh;
 
   const int q0 = (blockIdx.x * nwq + wid) * 32;
-  const bool wave_active = q0 < p.Lq;
-  int qrow = q0 + fr; if (qrow >= p.Lq) qrow = p.Lq - 1;
+  const bool wave_active = q0 < p.lq_main;
+  int qrow = q0 + fr; if (qrow >= p.lq_main) qrow = p.lq_main - 1;
   const int qidx = q0 + fr;
 
-  bf16x8 qf[KS];
+  // raw q fragments: loaded first, scaled only after the chunk is staged (the loads share one memory round trip)
+  u32x4 qraw[KS];
   {
-    const bf16_t* Qg = p.q + (bh * p.Lq + qrow) * DH;
+    const bf16_t* Qg = Qb + (long)qrow * p.q.sr;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(Qg + ks * 16 + fg * 8);
+    for (int ks = 0; ks < KS; ++ks) qraw[ks] = *(const u32x4*)(Qg + ks * 16 + fg * 8);
   }
+  // first chunk: staged before the accumulators exist (12 x 16-byte loads in flight per thread need the registers)
+  stage2<DH, KC, true, false, false, true>(StageSrc{sK, nullptr, Kg, p.k.sr, 1.f}, StageSrc{nullptr, sV, Vg, p.v.sr, 1.f},
+                                           0, p.Lk, tid, nthr);
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    qf[ks] = __builtin_bit_cast(bf16x8, p.qscale != 1.0f ? scale_bf16x8(qraw[ks], p.qscale) : qraw[ks]);
 
-  float m_run = -1e30f, l_run = 0.f;
+  float m_run = 0.f;               // the running maximum (valid after the first tile)
+  vl_f32x2 l2 = {0.f, 0.f};        // running sum, two partial accumulators
+  f32x16 negm;                     // -m_run in every accumulator slot: the C operand of the score MFMA
   f32x16 o[DT];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = 0.f;
 #pragma unroll
   for (int t = 0; t < DT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  bool first = true;
 
   const int q_hi = q0 + 31;  // last query row of this wave's tile
-  const int blk_q_hi = min(p.Lq - 1, (int)(blockIdx.x * nwq + nwq) * 32 - 1);
+  const int blk_q_hi = min(p.lq_main - 1, (int)(blockIdx.x * nwq + nwq) * 32 - 1);
 
-  for (int kc0 = 0; kc0 < p.Lk; kc0 += KC) {
-    if (p.causal && kc0 > blk_q_hi) break;   // uniform across the workgroup
-    __syncthreads();
-    // ---- stage K chunk + V^T chunk: issue 4+4 independent 16-byte loads per thread, then store ----
-    // (one load->store at a time exposes the full memory latency 8x per workgroup)
-    constexpr int NPK = KC * CH, NPV = DH * (KC / 8);
-    for (int base = 0; base < NPK; base += 4 * nthr) {
-      u32x4 kv[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = base + u * nthr + tid;
-        const int row = i / CH, c = i % CH;
-        kv[u] = u32x4{0u, 0u, 0u, 0u};
-        if (i < NPK && kc0 + row < p.Lk) kv[u] = *(const u32x4*)(Kg + (size_t)(kc0 + row) * DH + c * 8);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = base + u * nthr + tid;
-        const int row = i / CH, c = i % CH;
-        if (i < NPK) *(u32x4*)(sK + row * RB + ((c ^ ((row >> RSH) & (CH - 1))) * 16)) = kv[u];
-      }
-    }
-    for (int base = 0; base < NPV; base += 4 * nthr) {
-      u32x4 vv[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = base + u * nthr + tid;
-        const int d = i / (KC / 8), kp = i % (KC / 8);
-        const int key = kc0 + kp * 8;
-        vv[u] = u32x4{0u, 0u, 0u, 0u};
-        if (i < NPV && key + 8 <= p.Lkp) vv[u] = *(const u32x4*)(Vg + (size_t)d * p.Lkp + key);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = base + u * nthr + tid;
-        if (i >= NPV) continue;
-        const int d = i / (KC / 8), kp = i % (KC / 8);
-        const int key = kc0 + kp * 8;
-        u32x4 v = vv[u];
-        if (key + 8 > p.Lk) {  // boundary / pad piece: clear keys >= Lk (pad columns are uninitialised)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            unsigned int w = v[e];
-            if (key + 2 * e >= p.Lk) w &= 0xffff0000u;
-            if (key + 2 * e + 1 >= p.Lk) w &= 0x0000ffffu;
-            v[e] = w;
-          }
-        }
-        u32x2* dst = (u32x2*)(sV + d * VS + kp * 8);
-        u32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
-        dst[0] = lo; dst[1] = hi;
+  for (int kc0 = 0; kc0 < (MULTI ? p.Lk : 1); kc0 += KC) {
+    if (MULTI && p.causal && kc0 > blk_q_hi) break;   // uniform across the workgroup
+    if constexpr (MULTI) {
+      if (kc0 > 0) {
+        __syncthreads();
+        stage2<DH, KC, true, false, false, true>(StageSrc{sK, nullptr, Kg, p.k.sr, 1.f}, StageSrc{nullptr, sV, Vg, p.v.sr, 1.f},
+                                                 kc0, p.Lk, tid, nthr);
       }
     }
     __syncthreads();
@@ -131,18 +124,22 @@ __global__ void __launch_bounds__(576, 5) attn_fwd_kernel(const AttnP p) {
 
     int ntile = (min(p.Lk - kc0, KC) + 31) >> 5;
     if (p.causal) ntile = min(ntile, ((q_hi - kc0) >> 5) + 1);
+    const int ksw = (fr >> RSH) & (CH - 1);
     for (int kt = 0; kt < ntile; ++kt) {
-      // ---- S^T tile: rows = keys, cols = queries ----
-      f32x16 s;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      // ---- S^T tile (rows = keys, cols = queries), relative to the running maximum ----
       const unsigned char* kbase = sK + (kt * 32 + fr) * RB;
-      const int ksw = (fr >> RSH) & (CH - 1);
+      bf16x8 kf[KS];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(kbase + (((ks * 2 + fg) ^ ksw) * 16));
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
-      }
+      for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8*)(kbase + (((ks * 2 + fg) ^ ksw) * 16));
+      f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], negm, 0, 0, 0);
+#pragma unroll
+      for (int ks = 1; ks < KS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+      // V^T fragments of this tile: issued before the softmax arithmetic so that they land under it
+      bf16x8 vf[2][DT];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < DT; ++t) vf[c][t] = *(const bf16x8*)(sV + (t * 32 + fr) * VSP + kt * 32 + c * 16 + fg * 8);
       const int key0 = kc0 + kt * 32 + fg * 4;
       const bool need_mask = (key0 - fg * 4 + 32 > p.Lk) || (p.causal && key0 - fg * 4 + 31 > q0);
       if (need_mask) {
@@ -152,59 +149,133 @@ __global__ void __launch_bounds__(576, 5) attn_fwd_kernel(const AttnP p) {
           if (key >= p.Lk || (p.causal && key > qidx)) s[r] = -INFINITY;
         }
       }
-      float mx = s[0];
+      float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);      // v_max3_f32 chain (file is built with -fno-honor-nans)
 #pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      float ps = 0.f;
+      for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+      mx = fmaxf(mx, s[15]);
+      mx = xhalf_max(mx);
+      if (__builtin_amdgcn_ballot_w64(first || mx > RESCALE_THR) != 0) {
+        // the maximum moved: shift this tile's scores, the C block and the accumulated sums (rare after the first tiles)
+        const float d = first ? mx : fmaxf(mx, 0.f);
+        const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-d);
+        m_run += d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] -= d; negm[r] -= d; }
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        l2 *= alpha;
+        first = false;
+      }
       float pv[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { pv[r] = __builtin_amdgcn_exp2f(s[r] - m_new); ps += pv[r]; }
-      l_run = l_run * alpha + ps;
-#pragma unroll
-      for (int t = 0; t < DT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-      // ---- O^T += V^T · P^T ----
+      for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r]);
+      {
+        vl_f32x2 a0 = {pv[0], pv[1]}, a1 = {pv[2], pv[3]}, a2 = {pv[4], pv[5]}, a3 = {pv[6], pv[7]};
+        const vl_f32x2 a4 = {pv[8], pv[9]}, a5 = {pv[10], pv[11]}, a6 = {pv[12], pv[13]}, a7 = {pv[14], pv[15]};
+        a0 += a4; a1 += a5; a2 += a6; a3 += a7;
+        a0 += a2; a1 += a3;
+        l2 += a0 + a1;
+      }
+      // ---- O^T += V^T . P^T ----
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         bf16x8 pf;
 #pragma unroll
         for (int e = 0; e < 8; ++e) pf[e] = (__bf16)pv[c * 8 + e];
 #pragma unroll
-        for (int t = 0; t < DT; ++t) {
-          const bf16_t* vrow = sV + (t * 32 + fr) * VS + kt * 32 + c * 16 + fg * 4;
-          const bf16x4 v0 = *(const bf16x4*)(vrow);
-          const bf16x4 v1 = *(const bf16x4*)(vrow + 8);
-          bf16x8 vf;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
-          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[t], 0, 0, 0);
-        }
+        for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[c][t], pf, o[t], 0, 0, 0);
       }
     }
   }
 
-  if (!wave_active) return;
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  if (qidx < p.Lq) {
-    bf16_t* og = p.out + ((size_t)b * p.Lq + qidx) * (p.H * DH) + h * DH;
-#pragma unroll
-    for (int t = 0; t < DT; ++t)
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int d = t * 32 + qd * 8 + fg * 4;
-        u32x2 w;
-        w[0] = pack2bf(o[t][qd * 4 + 0] * inv, o[t][qd * 4 + 1] * inv);
-        w[1] = pack2bf(o[t][qd * 4 + 2] * inv, o[t][qd * 4 + 3] * inv);
-        *(u32x2*)(og + d) = w;
-      }
-    if (p.lse && fg == 0)
+  if (wave_active) {
+    const float l_tot = xhalf_sum(l2[0] + l2[1]);
+    const float inv = 1.0f / l_tot;
+    store_rows_t<DT>(o, inv, p.out + ((size_t)b * p.Lq + qrow) * (p.H * DH) + h * DH, fg, qidx < p.lq_main);
+    if (p.lse && fg == 0 && qidx < p.lq_main)
       p.lse[bh * p.Lq + qidx] = (m_run + __log2f(l_tot)) * 0.6931471805599453f;
+  }
+
+  if constexpr (TAILQ) {
+    // ---- the shared last row (query Lq-1, sees every key; host guarantees Lk <= KC and one workgroup per (b,h)) ----
+    const int qT = p.Lq - 1;
+    const int ntile = (p.Lk + 31) >> 5;
+    const int ksw = (fr >> RSH) & (CH - 1);
+    bf16x8 qa[KS];                         // A operand: row 0 = the query, rows 1..31 zero
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qa[ks][e] = (__bf16)0.f;
+      if (fr == 0) {
+        u32x4 raw = *(const u32x4*)(Qb + (long)qT * p.q.sr + ks * 16 + fg * 8);
+        if (p.qscale != 1.0f) raw = scale_bf16x8(raw, p.qscale);
+        qa[ks] = __builtin_bit_cast(bf16x8, raw);
+      }
+    }
+    for (int kt = wid; kt < ntile; kt += nwq) {
+      f32x16 st;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = 0.f;
+      const unsigned char* kbase = sK + (kt * 32 + fr) * RB;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], *(const bf16x8*)(kbase + (((ks * 2 + fg) ^ ksw) * 16)), st, 0, 0, 0);
+      // D[i = query row][j = key]: row 0 is accumulator slot 0 of the lanes with fg == 0; lane fr <-> key kt*32 + fr
+      const bool valid = fg == 0 && kt * 32 + fr < p.Lk;
+      const float sv = valid ? st[0] : -INFINITY;
+      const float mw = wave_max_dpp(sv);
+      const float pw = valid ? __builtin_amdgcn_exp2f(sv - mw) : 0.f;
+      const float lw = wave_sum_dpp(pw);
+      float* myP = sP + wid * 32;
+      if (fg == 0) myP[fr] = pw;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      f32x16 ot[DT];
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[t][r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        bf16x8 pa;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pa[e] = (__bf16)0.f;
+        if (fr == 0) {
+          const f32x4 lo = *(const f32x4*)(myP + c * 16 + fg * 4);
+          const f32x4 hi = *(const f32x4*)(myP + c * 16 + 8 + fg * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { pa[e] = (__bf16)lo[e]; pa[4 + e] = (__bf16)hi[e]; }
+        }
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+          ot[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              pa, *(const bf16x8*)(sV + (t * 32 + fr) * VSP + kt * 32 + c * 16 + fg * 8), ot[t], 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+      float* part = sPart + kt * (2 + DH);
+      if (lane == 0) { part[0] = mw; part[1] = lw; }
+      if (fg == 0) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t) part[2 + t * 32 + fr] = ot[t][0];
+      }
+    }
+    __syncthreads();
+    if (wid == 0 && lane < DH) {
+      float M = -INFINITY;
+      for (int kt = 0; kt < ntile; ++kt) M = fmaxf(M, sPart[kt * (2 + DH)]);
+      float L = 0.f, acc = 0.f;
+      for (int kt = 0; kt < ntile; ++kt) {
+        const float* part = sPart + kt * (2 + DH);
+        const float w = __builtin_amdgcn_exp2f(part[0] - M);
+        L = fmaf(part[1], w, L);
+        acc = fmaf(part[2 + lane], w, acc);
+      }
+      p.out[((size_t)b * p.Lq + qT) * (p.H * DH) + h * DH + lane] = f2bf(acc / L);
+      if (p.lse && lane == 0) p.lse[bh * p.Lq + qT] = (M + __log2f(L)) * 0.6931471805599453f;
+    }
   }
 }
 
@@ -212,26 +283,37 @@ __global__ void __launch_bounds__(576, 5) attn_fwd_kernel(const AttnP p) {
 
 extern "C" int vl_set_error(const char* msg);
 
-extern "C" int vl_attn_fwd_bf16(const void* q, const void* k, const void* vt, void* out, float* lse,
-                                int B, int H, int Lq, int Lk, int Lkp, int dh, int causal,
-                                hipStream_t stream) {
+template <int DH, bool TAILQ, bool MULTI>
+static int launch_fwd(const AttnP& p, int gx, int nwq, hipStream_t stream) {
+  const size_t smem = (size_t)KC * DH * 2 + (size_t)DH * VSP * 2 + (size_t)NWMAX * 32 * 4 + (size_t)(KC / 32) * (2 + DH) * 4;
+  static const hipError_t attr = hipFuncSetAttribute((const void*)attn_fwd_kernel<DH, TAILQ, MULTI>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (attr != hipSuccess) return vl_set_error(hipGetErrorString(attr));
+  hipLaunchKernelGGL((attn_fwd_kernel<DH, TAILQ, MULTI>), dim3(gx, p.H, p.B), dim3(nwq * 64), smem, stream, p);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : vl_set_error(hipGetErrorString(e));
+}
+
+extern "C" int vl_attn_fwd_bf16(const void* q, const void* k, const void* v, const long* strides, void* out, float* lse,
+                                int B, int H, int Lq, int Lk, int dh, float qscale, int causal, hipStream_t stream) {
   if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return vl_set_error("vl_attn_fwd_bf16: empty problem");
   if (dh != 64 && dh != 32) return vl_set_error("vl_attn_fwd_bf16: head dim must be 32 or 64");
-  if (Lkp < Lk || (Lkp & 7)) return vl_set_error("vl_attn_fwd_bf16: Lkp must be >= Lk and a multiple of 8");
-  AttnP p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, lse, B, H, Lq, Lk, Lkp, causal};
-  const int qtiles = (Lq + 31) / 32;
-  const int nwq = qtiles <= 9 ? qtiles : 8;   // one wave per 32-query tile; 257 tokens -> 9 waves, one workgroup per (b,h)
+  if (!strides) return vl_set_error("vl_attn_fwd_bf16: strides required");
+  for (int i = 0; i < 9; ++i)
+    if (strides[i] & 7) return vl_set_error("vl_attn_fwd_bf16: operand strides must be multiples of 8 elements (16-byte rows)");
+  if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) return vl_set_error("vl_attn_fwd_bf16: operands must be 16-byte aligned");
+  AttnP p{TV{(const bf16_t*)q, strides[0], strides[1], strides[2]}, TV{(const bf16_t*)k, strides[3], strides[4], strides[5]},
+          TV{(const bf16_t*)v, strides[6], strides[7], strides[8]}, qscale, (bf16_t*)out, lse, B, H, Lq, Lk, causal, Lq};
+  // one row beyond whole tiles (257 tokens): shared by the waves of the single workgroup instead of a ninth wave
+  const bool tailq = (Lq % 32 == 1) && Lq > 32 && Lq - 1 <= NWMAX * 32 && Lk <= KC && (!causal || Lk <= Lq);
+  if (tailq) p.lq_main = Lq - 1;
+  const int qtiles = (p.lq_main + 31) / 32;
+  const int nwq = qtiles < NWMAX ? qtiles : NWMAX;
   const int gx = (qtiles + nwq - 1) / nwq;
-  const size_t smem = (size_t)KC * dh * 2 + (size_t)dh * VS * 2;
-  hipError_t e;
-  if (dh == 64) {
-    static bool set64 = false;
-    if (!set64) { e = hipFuncSetAttribute((const void*)attn_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); if (e != hipSuccess) return vl_set_error(hipGetErrorString(e)); set64 = true; }
-    hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3(gx, H, B), dim3(nwq * 64), smem, stream, p);
-  } else {
-    hipLaunchKernelGGL(attn_fwd_kernel<32>, dim3(gx, H, B), dim3(nwq * 64), smem, stream, p);
-  }
-  e = hipGetLastError();
-  if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
-  return 0;
+  const bool multi = Lk > KC;
+#define VL_FWD(DHV)                                                                  \
+  (tailq ? launch_fwd<DHV, true, false>(p, gx, nwq, stream)                          \
+         : (multi ? launch_fwd<DHV, false, true>(p, gx, nwq, stream) : launch_fwd<DHV, false, false>(p, gx, nwq, stream)))
+  return dh == 64 ? VL_FWD(64) : VL_FWD(32);
+#undef VL_FWD
 }

@@ -2,319 +2,380 @@
 //
 // Autograd of F.multi_head_attention_forward / the Perceiver einsum attention
 // (open_clip/transformer.py:241-252, open_clip/perceiver.py:128-145) for the trainable towers.
-//   kernel A: one wave per 32 QUERIES  ->  dQ      (loops over key tiles)
-//   kernel B: one wave per 32 KEYS     ->  dK, dV  (loops over query tiles)
-// Both recompute P = exp2(S2 - lse2) from the forward's log-sum-exp and use the same swapped-operand
-// trick as the forward: the wave's own index (query in A, key in B) is the MFMA column, so P / dS
-// live 16-per-lane in accumulator layout and feed the next MFMA as its column operand straight from
-// registers, while the row operand (K^T / Q^T / dO^T, stored transposed) is read with the matching
-// k-slot permutation.
-//   inputs : q (pre-scaled by scale*log2e), k, v   [B,H,L,64|32] row-major
-//            qt, kt                               [B,H,dh,Lp]   transposed copies
-//            dO [B,H,Lq,dh], dOt [B,H,dh,Lqp], lse [B,H,Lq] (natural log), delta [B,H,Lq] = rowsum(dO*O)
-//   outputs: dq -> dQKV[(b*Lq+q), 0*D + h*dh + d], dk -> [.., 1*D ..], dv -> [.., 2*D ..]  (token-major, bf16)
-#include "vl_common.h"
+//   kernel A: one wave per 32 QUERIES  ->  dQ, delta = rowsum(dO * O)   (loops over key tiles)
+//   kernel B: one wave per 32 KEYS     ->  dK, dV                       (loops over query tiles)
+// Both recompute P = exp2(S2 - lse2) from the forward's log-sum-exp and use the same swapped-operand trick as the
+// forward: the wave's own index (query in A, key in B) is the MFMA column, so P / dS live 16-per-lane in accumulator
+// layout and feed the next MFMA as its column operand straight from registers, while the row operand (K^T / Q^T / dO^T)
+// is read from a transposed LDS image whose row order already matches the accumulator layout (vl_attn_common.h).
+//
+//   inputs : q, k, v, dO, O  strided [B,H,L,dh] views - column blocks of the packed in-projection output, the
+//            out-projection's input gradient and the forward's token-major output, all read in place (round 1 needed
+//            head-split AND transposed copies of q, k, dO written by GEMM epilogues and a separate delta kernel);
+//            q is multiplied by qscale = scale*log2(e) as it is loaded, exactly as in the forward; lse [B,H,Lq].
+//   outputs: dq -> dQKV[(b*Lq+q), 0*D + h*dh + d], dk -> [.., 1*D ..], dv -> [.., 2*D ..]  (token-major, bf16);
+//            delta [B,H,Lq] fp32 is produced by kernel A and consumed by kernel B (same stream).
+//
+// VALU trimming (the kernels were VALU/latency bound, MFMA 18-25 % busy): -lse2 and -delta enter as the C operands of the
+// S and dP MFMAs (register blocks in A; four ds_read_b128 per tile from LDS in B, where padded query rows carry -inf /
+// 0 and need no masking), so the elementwise work per 32x32 tile is 16 exp2, 16 multiplies and the bf16 packing.
+//
+// L = 257 (8 whole tiles + one row): the lone last query (A) / key (B) is not given a ninth wave; the 8 waves share it
+// after their own tiles - wave w takes tile w with the MFMA operand roles swapped (the lone row is row 0 of the A
+// operand), pushes p / dS through a 128-byte LDS scratch to make them an A operand, and the per-wave partial dQ (or
+// dK, dV) rows are summed in a fixed order through LDS.
+#include "vl_attn_common.h"
 #include "vitlens_hip.h"
 
 namespace {
+using namespace vlattn;
 
-constexpr int KC = 288;
-constexpr int VS = KC + 4;
+constexpr int NC = 288;        // keys (A) / queries (B) per LDS chunk: 9 tiles of 32
+constexpr int NWMAX = 8;
+constexpr float LOG2E = 1.4426950408889634f;
 
 struct AttnBwdP {
-  const bf16_t *q, *k, *v, *qt, *kt, *dO, *dOt;
-  const float *lse, *delta;
+  TV q, k, v, dO, o;
+  const float* lse;
+  float* delta;
   bf16_t *dq, *dk, *dv;     // token-major destinations (already offset to the q / k / v column block)
   long ld_dq, ld_dkv;       // row strides (elements) of the dq and dk/dv destinations
-  int B, H, Lq, Lk, Lqp, Lkp, causal;
+  int B, H, Lq, Lk, causal;
+  float qscale;             // q is multiplied by this at load (softmax scale * log2 e)
   float scale;              // softmax scale (dq = scale * dS K ; dk = ln2 * dS^T Q2)
+  int l_main;               // queries (A) / keys (B) handled by per-wave tiles (L, or L-1 when the last row is shared)
 };
 
-// stage `KC` rows of a row-major [L, DH] matrix into a swizzled LDS image (rows >= nvalid zero-filled)
-template <int DH>
-__device__ __forceinline__ void stage_rows(unsigned char* dst, const bf16_t* src, int row0, int L, int tid, int nthr) {
-  constexpr int RB = DH * 2, CH = RB / 16, RSH = (DH == 64) ? 1 : 2, NP = KC * CH;
-  for (int base = 0; base < NP; base += 4 * nthr) {
-    u32x4 t[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = base + u * nthr + tid;
-      const int row = i / CH, c = i % CH;
-      t[u] = u32x4{0u, 0u, 0u, 0u};
-      if (i < NP && row0 + row < L) t[u] = *(const u32x4*)(src + (size_t)(row0 + row) * DH + c * 8);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = base + u * nthr + tid;
-      const int row = i / CH, c = i % CH;
-      if (i < NP) *(u32x4*)(dst + row * RB + ((c ^ ((row >> RSH) & (CH - 1))) * 16)) = t[u];
-    }
-  }
-}
-// stage KC columns [col0, col0+KC) of a transposed [DH, Lp] matrix into LDS rows of stride VS (cols >= L zeroed)
-template <int DH>
-__device__ __forceinline__ void stage_cols(bf16_t* dst, const bf16_t* src, int col0, int L, int Lp, int tid, int nthr) {
-  constexpr int NP = DH * (KC / 8);
-  for (int base = 0; base < NP; base += 4 * nthr) {
-    u32x4 t[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = base + u * nthr + tid;
-      const int d = i / (KC / 8), kp = i % (KC / 8);
-      const int c = col0 + kp * 8;
-      t[u] = u32x4{0u, 0u, 0u, 0u};
-      if (i < NP && c + 8 <= Lp) t[u] = *(const u32x4*)(src + (size_t)d * Lp + c);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = base + u * nthr + tid;
-      if (i >= NP) continue;
-      const int d = i / (KC / 8), kp = i % (KC / 8);
-      const int c = col0 + kp * 8;
-      u32x4 w = t[u];
-      if (c + 8 > L) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          unsigned int x = w[e];
-          if (c + 2 * e >= L) x &= 0xffff0000u;
-          if (c + 2 * e + 1 >= L) x &= 0x0000ffffu;
-          w[e] = x;
-        }
-      }
-      u32x2* o = (u32x2*)(dst + d * VS + kp * 8);
-      u32x2 lo = {w[0], w[1]}, hi = {w[2], w[3]};
-      o[0] = lo; o[1] = hi;
-    }
-  }
+__device__ __forceinline__ bf16x8 load_frag(const bf16_t* row, int ks, int fg, float scale) {
+  u32x4 raw = *(const u32x4*)(row + ks * 16 + fg * 8);
+  if (scale != 1.0f) raw = scale_bf16x8(raw, scale);
+  return __builtin_bit_cast(bf16x8, raw);
 }
 
-template <int DH>
-__device__ __forceinline__ bf16x8 frag_rows(const unsigned char* base, int row, int ks, int fg) {
-  constexpr int RB = DH * 2, CH = RB / 16, RSH = (DH == 64) ? 1 : 2;
-  return *(const bf16x8*)(base + row * RB + (((ks * 2 + fg) ^ ((row >> RSH) & (CH - 1))) * 16));
-}
-__device__ __forceinline__ bf16x8 frag_cols(const bf16_t* base, int d, int col) {
-  const bf16x4 a = *(const bf16x4*)(base + d * VS + col);
-  const bf16x4 b = *(const bf16x4*)(base + d * VS + col + 8);
-  bf16x8 r;
+// the 8 values of an accumulator-layout row vector that lane (fr == 0, fg) of an A operand needs for slice c
+__device__ __forceinline__ bf16x8 gather_row0(const float* scratch, int c, int fr, int fg) {
+  bf16x8 r = zero_bf8();
+  if (fr == 0) {
+    const f32x4 lo = *(const f32x4*)(scratch + c * 16 + fg * 4);
+    const f32x4 hi = *(const f32x4*)(scratch + c * 16 + 8 + fg * 4);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { r[e] = a[e]; r[4 + e] = b[e]; }
+    for (int e = 0; e < 4; ++e) { r[e] = (__bf16)lo[e]; r[4 + e] = (__bf16)hi[e]; }
+  }
   return r;
 }
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
-// ------------------------------------------------------------------------------------------- kernel A: dQ
-template <int DH>
-__global__ void __launch_bounds__(576) attn_bwd_dq_kernel(const AttnBwdP p) {
-  constexpr int RB = DH * 2, KS = DH / 16, DT = DH / 32;
+// ------------------------------------------------------------------------------------------- kernel A: dQ (+ delta)
+template <int DH, bool TAILQ>
+__global__ void __launch_bounds__(NWMAX * 64, 2) attn_bwd_dq_kernel(const AttnBwdP p) {
+  constexpr int RB = DH * 2, KS = DH / 16, DT = DH / 32, TS = NC + 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
-  unsigned char* sV = smem + KC * RB;
-  bf16_t* sKt = (bf16_t*)(smem + 2 * KC * RB);
+  unsigned char* sV = smem + NC * RB;
+  bf16_t* sKt = (bf16_t*)(smem + 2 * NC * RB);
+  float* sP = (float*)(sKt + DH * TS);            // [NWMAX][32]  (TAILQ)
+  float* sPart = sP + NWMAX * 32;                 // [NWMAX][DH]  (TAILQ)
 
   const int b = blockIdx.z, h = blockIdx.y;
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), nwq = nthr >> 6;
   const int fr = lane & 31, fg = lane >> 5;
   const size_t bh = (size_t)b * p.H + h;
+  const bf16_t* Qb = p.q.p + b * p.q.sb + h * p.q.sh;
+  const bf16_t* Kb = p.k.p + b * p.k.sb + h * p.k.sh;
+  const bf16_t* Vb = p.v.p + b * p.v.sb + h * p.v.sh;
+  const bf16_t* Gb = p.dO.p + b * p.dO.sb + h * p.dO.sh;
+  const bf16_t* Ob = p.o.p + b * p.o.sb + h * p.o.sh;
   const int q0 = (blockIdx.x * nwq + wid) * 32;
-  const bool active = q0 < p.Lq;
+  const bool active = q0 < p.l_main;
   const int qidx = q0 + fr;
-  const int qrow = qidx < p.Lq ? qidx : p.Lq - 1;
+  const int qrow = qidx < p.l_main ? qidx : p.l_main - 1;
 
   bf16x8 qf[KS], dof[KS];
+  float dlt = 0.f;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    qf[ks] = *(const bf16x8*)(p.q + (bh * p.Lq + qrow) * DH + ks * 16 + fg * 8);
-    dof[ks] = *(const bf16x8*)(p.dO + (bh * p.Lq + qrow) * DH + ks * 16 + fg * 8);
+    qf[ks] = load_frag(Qb + (long)qrow * p.q.sr, ks, fg, p.qscale);
+    dof[ks] = load_frag(Gb + (long)qrow * p.dO.sr, ks, fg, 1.f);
+    dlt = dot8(dof[ks], load_frag(Ob + (long)qrow * p.o.sr, ks, fg, 1.f), dlt);
   }
-  const float lse2 = p.lse[bh * p.Lq + qrow] * 1.4426950408889634f;
-  const float dlt = p.delta[bh * p.Lq + qrow];
+  dlt = xhalf_sum(dlt);
+  if (active && fg == 0 && qidx < p.l_main) p.delta[bh * p.Lq + qidx] = dlt;
+  const float lse2 = p.lse[bh * p.Lq + qrow] * LOG2E;
+  f32x16 negl, negd;          // C operands: S2 - lse2 and dP - delta come out of the MFMAs directly
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { negl[r] = -lse2; negd[r] = -dlt; }
 
   f32x16 dq[DT];
 #pragma unroll
-  for (int t = 0; t < DT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dq[t][r] = 0.f;
+  for (int t = 0; t < DT; ++t) dq[t] = zero16();
 
-  const int blk_q_hi = min(p.Lq - 1, (int)(blockIdx.x * nwq + nwq) * 32 - 1);
-  for (int kc0 = 0; kc0 < p.Lk; kc0 += KC) {
+  const int blk_q_hi = min(p.l_main - 1, (int)(blockIdx.x * nwq + nwq) * 32 - 1);
+  for (int kc0 = 0; kc0 < p.Lk; kc0 += NC) {
     if (p.causal && kc0 > blk_q_hi) break;
     __syncthreads();
-    stage_rows<DH>(sK, p.k + bh * p.Lk * DH, kc0, p.Lk, tid, nthr);
-    stage_rows<DH>(sV, p.v + bh * p.Lk * DH, kc0, p.Lk, tid, nthr);
-    stage_cols<DH>(sKt, p.kt + bh * DH * (size_t)p.Lkp, kc0, p.Lk, p.Lkp, tid, nthr);
+    stage2<DH, NC, true, true, true, false>(StageSrc{sK, sKt, Kb, p.k.sr, 1.f}, StageSrc{sV, nullptr, Vb, p.v.sr, 1.f},
+                                            kc0, p.Lk, tid, nthr);
     __syncthreads();
     if (!active) continue;
-    int ntile = (min(p.Lk - kc0, KC) + 31) >> 5;
+    int ntile = (min(p.Lk - kc0, NC) + 31) >> 5;
     if (p.causal) ntile = min(ntile, ((q0 + 31 - kc0) >> 5) + 1);
     for (int kt = 0; kt < ntile; ++kt) {
-      f32x16 s, dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      f32x16 s = negl, dp = negd;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(sK, kt * 32 + fr, ks, fg), qf[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(sV, kt * 32 + fr, ks, fg), dof[ks], dp, 0, 0, 0);
       }
+      bf16x8 ktf[2][DT];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < DT; ++t) ktf[c][t] = frag_t<NC>(sKt, t * 32 + fr, kt, c, fg);
       const int key0 = kc0 + kt * 32 + fg * 4;
+      const bool need_mask = (key0 - fg * 4 + 32 > p.Lk) || (p.causal && key0 - fg * 4 + 31 > q0);
+      if (need_mask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + (r & 3) + 8 * (r >> 2);
+          if (key >= p.Lk || (p.causal && key > qidx)) s[r] = -INFINITY;
+        }
+      }
       float ds[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = key0 + (r & 3) + 8 * (r >> 2);
-        float pr = __builtin_amdgcn_exp2f(s[r] - lse2);
-        if (key >= p.Lk || (p.causal && key > qidx)) pr = 0.f;
-        ds[r] = pr * (dp[r] - dlt);
-      }
+      for (int r = 0; r < 16; ++r) ds[r] = __builtin_amdgcn_exp2f(s[r]) * dp[r];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        bf16x8 df;
+        const bf16x8 df = pack8(ds + c * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) df[e] = (__bf16)ds[c * 8 + e];
-#pragma unroll
-        for (int t = 0; t < DT; ++t)
-          dq[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(sKt, t * 32 + fr, kt * 32 + c * 16 + fg * 4), df, dq[t], 0, 0, 0);
+        for (int t = 0; t < DT; ++t) dq[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[c][t], df, dq[t], 0, 0, 0);
       }
     }
   }
-  if (!active || qidx >= p.Lq) return;
-  bf16_t* og = p.dq + ((size_t)b * p.Lq + qidx) * p.ld_dq + h * DH;
+  if (active)
+    store_rows_t<DT>(dq, p.scale, p.dq + ((size_t)b * p.Lq + qrow) * p.ld_dq + h * DH, fg, qidx < p.l_main);
+
+  if constexpr (TAILQ) {
+    // ---- the shared last query row (host guarantees Lk <= NC, one workgroup per (b,h), the row sees every key) ----
+    const int qT = p.Lq - 1;
+    const int ntile = (p.Lk + 31) >> 5;
+    bf16x8 qa[KS], ga[KS];
+    float dT = 0.f;
 #pragma unroll
-  for (int t = 0; t < DT; ++t)
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      u32x2 w;
-      w[0] = pack2bf(dq[t][qd * 4 + 0] * p.scale, dq[t][qd * 4 + 1] * p.scale);
-      w[1] = pack2bf(dq[t][qd * 4 + 2] * p.scale, dq[t][qd * 4 + 3] * p.scale);
-      *(u32x2*)(og + t * 32 + qd * 8 + fg * 4) = w;
+    for (int ks = 0; ks < KS; ++ks) {
+      qa[ks] = zero_bf8(); ga[ks] = zero_bf8();
+      if (fr == 0) {
+        qa[ks] = load_frag(Qb + (long)qT * p.q.sr, ks, fg, p.qscale);
+        ga[ks] = load_frag(Gb + (long)qT * p.dO.sr, ks, fg, 1.f);
+        dT = dot8(ga[ks], load_frag(Ob + (long)qT * p.o.sr, ks, fg, 1.f), dT);
+      }
     }
+    dT = __shfl(dT, 0, 64) + __shfl(dT, 32, 64);
+    if (wid == 0 && lane == 0) p.delta[bh * p.Lq + qT] = dT;
+    const float lT = p.lse[bh * p.Lq + qT] * LOG2E;
+    float dqT[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) dqT[t] = 0.f;
+    float* myP = sP + wid * 32;
+    for (int kt = wid; kt < ntile; kt += nwq) {
+      f32x16 st = zero16(), dpt = zero16();
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], frag_rows<DH>(sK, kt * 32 + fr, ks, fg), st, 0, 0, 0);
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[ks], frag_rows<DH>(sV, kt * 32 + fr, ks, fg), dpt, 0, 0, 0);
+      }
+      // row 0 of D = slot 0 of the lanes with fg == 0; lane fr <-> key kt*32 + fr
+      const bool valid = fg == 0 && kt * 32 + fr < p.Lk;
+      const float dsv = valid ? __builtin_amdgcn_exp2f(st[0] - lT) * (dpt[0] - dT) : 0.f;
+      wave_lds_sync();
+      if (fg == 0) myP[fr] = dsv;
+      wave_lds_sync();
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const bf16x8 pa = gather_row0(myP, c, fr, fg);
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+          dqT[t] += __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_t<NC>(sKt, t * 32 + fr, kt, c, fg), zero16(), 0, 0, 0)[0];
+      }
+    }
+    if (fg == 0) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) sPart[wid * DH + t * 32 + fr] = dqT[t];
+    }
+    __syncthreads();
+    if (wid == 0 && lane < DH) {
+      float acc = 0.f;
+      for (int w = 0; w < nwq; ++w) acc += sPart[w * DH + lane];
+      p.dq[((size_t)b * p.Lq + qT) * p.ld_dq + h * DH + lane] = f2bf(acc * p.scale);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------- kernel B: dK, dV
-template <int DH>
-__global__ void __launch_bounds__(576) attn_bwd_dkv_kernel(const AttnBwdP p) {
-  constexpr int RB = DH * 2, KS = DH / 16, DT = DH / 32;
+template <int DH, bool TAILK>
+__global__ void __launch_bounds__(NWMAX * 64, 2) attn_bwd_dkv_kernel(const AttnBwdP p) {
+  constexpr int RB = DH * 2, KS = DH / 16, DT = DH / 32, TS = NC + 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sQ = smem;
-  unsigned char* sdO = smem + KC * RB;
-  bf16_t* sQt = (bf16_t*)(smem + 2 * KC * RB);
-  bf16_t* sdOt = sQt + DH * VS;
-  float* sLse = (float*)(sdOt + DH * VS);
-  float* sDel = sLse + KC;
+  unsigned char* sdO = smem + NC * RB;
+  bf16_t* sQt = (bf16_t*)(smem + 2 * NC * RB);
+  bf16_t* sdOt = sQt + DH * TS;
+  float* sNegL = (float*)(sdOt + DH * TS);        // -lse2 per query of the chunk (-inf on padded rows)
+  float* sNegD = sNegL + NC;                      // -delta                       (0 on padded rows)
+  float* sP = sNegD + NC;                         // [NWMAX][2][32]   (TAILK)
+  float* sPart = sP + NWMAX * 64;                 // [NWMAX][2*DH]    (TAILK)
 
   const int b = blockIdx.z, h = blockIdx.y;
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), nwk = nthr >> 6;
   const int fr = lane & 31, fg = lane >> 5;
   const size_t bh = (size_t)b * p.H + h;
+  const bf16_t* Qb = p.q.p + b * p.q.sb + h * p.q.sh;
+  const bf16_t* Kb = p.k.p + b * p.k.sb + h * p.k.sh;
+  const bf16_t* Vb = p.v.p + b * p.v.sb + h * p.v.sh;
+  const bf16_t* Gb = p.dO.p + b * p.dO.sb + h * p.dO.sh;
   const int k0 = (blockIdx.x * nwk + wid) * 32;
-  const bool active = k0 < p.Lk;
+  const bool active = k0 < p.l_main;
   const int kidx = k0 + fr;
-  const int krow = kidx < p.Lk ? kidx : p.Lk - 1;
+  const int krow = kidx < p.l_main ? kidx : p.l_main - 1;
 
   bf16x8 kf[KS], vf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    kf[ks] = *(const bf16x8*)(p.k + (bh * p.Lk + krow) * DH + ks * 16 + fg * 8);
-    vf[ks] = *(const bf16x8*)(p.v + (bh * p.Lk + krow) * DH + ks * 16 + fg * 8);
+    kf[ks] = load_frag(Kb + (long)krow * p.k.sr, ks, fg, 1.f);
+    vf[ks] = load_frag(Vb + (long)krow * p.v.sr, ks, fg, 1.f);
   }
   f32x16 dk[DT], dv[DT];
 #pragma unroll
-  for (int t = 0; t < DT; ++t)
+  for (int t = 0; t < DT; ++t) { dk[t] = zero16(); dv[t] = zero16(); }
+  [[maybe_unused]] float dkT[DT], dvT[DT];        // the shared last key's partial rows: slot 0 of per-tile MFMAs (TAILK)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { dk[t][r] = 0.f; dv[t][r] = 0.f; }
+  for (int t = 0; t < DT; ++t) { dkT[t] = 0.f; dvT[t] = 0.f; }
 
-  for (int qc0 = 0; qc0 < p.Lq; qc0 += KC) {
+  for (int qc0 = 0; qc0 < p.Lq; qc0 += NC) {
     __syncthreads();
-    stage_rows<DH>(sQ, p.q + bh * p.Lq * DH, qc0, p.Lq, tid, nthr);
-    stage_rows<DH>(sdO, p.dO + bh * p.Lq * DH, qc0, p.Lq, tid, nthr);
-    stage_cols<DH>(sQt, p.qt + bh * DH * (size_t)p.Lqp, qc0, p.Lq, p.Lqp, tid, nthr);
-    stage_cols<DH>(sdOt, p.dOt + bh * DH * (size_t)p.Lqp, qc0, p.Lq, p.Lqp, tid, nthr);
-    for (int i = tid; i < KC; i += nthr) {
+    stage2<DH, NC, true, true, true, true>(StageSrc{sQ, sQt, Qb, p.q.sr, p.qscale}, StageSrc{sdO, sdOt, Gb, p.dO.sr, 1.f},
+                                           qc0, p.Lq, tid, nthr);
+    for (int i = tid; i < NC; i += nthr) {
       const bool ok = qc0 + i < p.Lq;
-      sLse[i] = ok ? p.lse[bh * p.Lq + qc0 + i] * 1.4426950408889634f : 0.f;
-      sDel[i] = ok ? p.delta[bh * p.Lq + qc0 + i] : 0.f;
+      sNegL[i] = ok ? -p.lse[bh * p.Lq + qc0 + i] * LOG2E : -INFINITY;
+      sNegD[i] = ok ? -p.delta[bh * p.Lq + qc0 + i] : 0.f;
     }
     __syncthreads();
-    if (!active) continue;
-    const int ntile = (min(p.Lq - qc0, KC) + 31) >> 5;
-    int t0 = 0;
-    if (p.causal) t0 = max(0, (k0 - qc0) >> 5);      // queries before this key tile never see it
-    for (int qt = t0; qt < ntile; ++qt) {
-      f32x16 s, dp;
+    const int ntile = (min(p.Lq - qc0, NC) + 31) >> 5;
+    if (active) {
+      int t0 = 0;
+      if (p.causal) t0 = max(0, (k0 - qc0) >> 5);      // queries before this key tile never see it
+      for (int qt = t0; qt < ntile; ++qt) {
+        // rows of the accumulator = queries (r&3) + 8*(r>>2) + 4*fg of this tile; column = this lane's key
+        f32x16 s, dp;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        for (int qd = 0; qd < 4; ++qd) {
+          const f32x4 l4 = *(const f32x4*)(sNegL + qt * 32 + qd * 8 + fg * 4);
+          const f32x4 d4 = *(const f32x4*)(sNegD + qt * 32 + qd * 8 + fg * 4);
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(sQ, qt * 32 + fr, ks, fg), kf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(sdO, qt * 32 + fr, ks, fg), vf[ks], dp, 0, 0, 0);
-      }
-      // rows of the accumulator = queries  (r&3) + 8*(r>>2) + 4*fg of this tile; column = this lane's key
-      float pv[16], ds[16];
+          for (int e = 0; e < 4; ++e) { s[qd * 4 + e] = l4[e]; dp[qd * 4 + e] = d4[e]; }
+        }
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int ql = qt * 32 + qd * 8 + fg * 4;
-        const f32x4 l4 = *(const f32x4*)(sLse + ql);
-        const f32x4 d4 = *(const f32x4*)(sDel + ql);
+        for (int ks = 0; ks < KS; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(sQ, qt * 32 + fr, ks, fg), kf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(sdO, qt * 32 + fr, ks, fg), vf[ks], dp, 0, 0, 0);
+        }
+        bf16x8 gtf[2][DT], qtf[2][DT];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = qd * 4 + e;
-          const int qg = qc0 + ql + e;
-          float pr = __builtin_amdgcn_exp2f(s[r] - l4[e]);
-          if (qg >= p.Lq || (p.causal && kidx > qg)) pr = 0.f;
-          pv[r] = pr;
-          ds[r] = pr * (dp[r] - d4[e]);
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int t = 0; t < DT; ++t) {
+            gtf[c][t] = frag_t<NC>(sdOt, t * 32 + fr, qt, c, fg);
+            qtf[c][t] = frag_t<NC>(sQt, t * 32 + fr, qt, c, fg);
+          }
+        if (p.causal && qc0 + qt * 32 < k0 + 31) {      // diagonal tile: key > query is masked
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int qg = qc0 + qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
+            if (kidx > qg) s[r] = -INFINITY;
+          }
+        }
+        float pv[16], ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { pv[r] = __builtin_amdgcn_exp2f(s[r]); ds[r] = pv[r] * dp[r]; }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const bf16x8 pf = pack8(pv + c * 8), df = pack8(ds + c * 8);
+#pragma unroll
+          for (int t = 0; t < DT; ++t) {
+            dv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gtf[c][t], pf, dv[t], 0, 0, 0);
+            dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[c][t], df, dk[t], 0, 0, 0);
+          }
         }
       }
+    }
+    if constexpr (TAILK) {
+      // ---- the shared last key against query tile(s) wid, wid + 8, ... (lane = query) ----
+      const int kT = p.Lk - 1;
+      float* myP = sP + wid * 64;
+      bf16x8 ka[KS], va[KS];                        // A operands: row 0 = the key / value row, rows 1..31 zero
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        bf16x8 pf, df;
+      for (int ks = 0; ks < KS; ++ks) {
+        ka[ks] = zero_bf8(); va[ks] = zero_bf8();
+        if (fr == 0) {
+          ka[ks] = load_frag(Kb + (long)kT * p.k.sr, ks, fg, 1.f);
+          va[ks] = load_frag(Vb + (long)kT * p.v.sr, ks, fg, 1.f);
+        }
+      }
+      for (int qt = wid; qt < ntile; qt += nwk) {
+        if (p.causal && qc0 + qt * 32 + 31 < kT) continue;
+        f32x16 st = zero16(), dpt = zero16();
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { pf[e] = (__bf16)pv[c * 8 + e]; df[e] = (__bf16)ds[c * 8 + e]; }
+        for (int ks = 0; ks < KS; ++ks) {
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], frag_rows<DH>(sQ, qt * 32 + fr, ks, fg), st, 0, 0, 0);
+          dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[ks], frag_rows<DH>(sdO, qt * 32 + fr, ks, fg), dpt, 0, 0, 0);
+        }
+        float pT = 0.f, dsT = 0.f;
+        if (fg == 0 && !(p.causal && qc0 + qt * 32 + fr < kT)) {
+          pT = __builtin_amdgcn_exp2f(st[0] + sNegL[qt * 32 + fr]);      // padded rows: -inf -> 0
+          dsT = pT * (dpt[0] + sNegD[qt * 32 + fr]);
+        }
+        wave_lds_sync();
+        if (fg == 0) { myP[fr] = pT; myP[32 + fr] = dsT; }
+        wave_lds_sync();
 #pragma unroll
-        for (int t = 0; t < DT; ++t) {
-          const int col = qt * 32 + c * 16 + fg * 4;
-          dv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(sdOt, t * 32 + fr, col), pf, dv[t], 0, 0, 0);
-          dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(sQt, t * 32 + fr, col), df, dk[t], 0, 0, 0);
+        for (int c = 0; c < 2; ++c) {
+          const bf16x8 pa = gather_row0(myP, c, fr, fg), da = gather_row0(myP + 32, c, fr, fg);
+#pragma unroll
+          for (int t = 0; t < DT; ++t) {
+            dvT[t] += __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_t<NC>(sdOt, t * 32 + fr, qt, c, fg), zero16(), 0, 0, 0)[0];
+            dkT[t] += __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, frag_t<NC>(sQt, t * 32 + fr, qt, c, fg), zero16(), 0, 0, 0)[0];
+          }
         }
       }
     }
   }
-  if (!active || kidx >= p.Lk) return;
   const float ln2 = 0.6931471805599453f;
-  bf16_t* gk = p.dk + ((size_t)b * p.Lk + kidx) * p.ld_dkv + h * DH;
-  bf16_t* gv = p.dv + ((size_t)b * p.Lk + kidx) * p.ld_dkv + h * DH;
+  if (active) {
+    store_rows_t<DT>(dk, ln2, p.dk + ((size_t)b * p.Lk + krow) * p.ld_dkv + h * DH, fg, kidx < p.l_main);
+    store_rows_t<DT>(dv, 1.f, p.dv + ((size_t)b * p.Lk + krow) * p.ld_dkv + h * DH, fg, kidx < p.l_main);
+  }
+  if constexpr (TAILK) {
+    if (fg == 0) {
 #pragma unroll
-  for (int t = 0; t < DT; ++t)
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      const int d = t * 32 + qd * 8 + fg * 4;
-      u32x2 w;
-      w[0] = pack2bf(dk[t][qd * 4 + 0] * ln2, dk[t][qd * 4 + 1] * ln2);
-      w[1] = pack2bf(dk[t][qd * 4 + 2] * ln2, dk[t][qd * 4 + 3] * ln2);
-      *(u32x2*)(gk + d) = w;
-      w[0] = pack2bf(dv[t][qd * 4 + 0], dv[t][qd * 4 + 1]);
-      w[1] = pack2bf(dv[t][qd * 4 + 2], dv[t][qd * 4 + 3]);
-      *(u32x2*)(gv + d) = w;
-    }
-}
-
-// delta[b,h,l] = sum_d dO[b,h,l,d] * O[b*L+l, h*dh+d]
-__global__ void __launch_bounds__(256) attn_delta_kernel(const bf16_t* dO, const bf16_t* o, float* delta, int B, int H, int L, int dh) {
-  const long n = (long)B * H * L;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const int l = (int)(i % L); const long bh = i / L; const int h = (int)(bh % H); const long b = bh / H;
-    const bf16_t* a = dO + i * dh;
-    const bf16_t* c = o + (b * L + l) * (long)(H * dh) + h * dh;
-    float s = 0.f;
-    for (int d = 0; d < dh; d += 8) {
-      const u32x4 x = *(const u32x4*)(a + d), y = *(const u32x4*)(c + d);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        s = fmaf(bf2f((bf16_t)(x[e] & 0xffff)), bf2f((bf16_t)(y[e] & 0xffff)), s);
-        s = fmaf(bf2f((bf16_t)(x[e] >> 16)), bf2f((bf16_t)(y[e] >> 16)), s);
+      for (int t = 0; t < DT; ++t) {
+        sPart[wid * 2 * DH + t * 32 + fr] = dvT[t];
+        sPart[wid * 2 * DH + DH + t * 32 + fr] = dkT[t];
       }
     }
-    delta[i] = s;
+    __syncthreads();
+    if (wid == 0 && lane < DH) {
+      float av = 0.f, ak = 0.f;
+      for (int w = 0; w < nwk; ++w) { av += sPart[w * 2 * DH + lane]; ak += sPart[w * 2 * DH + DH + lane]; }
+      const size_t row = ((size_t)b * p.Lk + p.Lk - 1) * p.ld_dkv + h * DH + lane;
+      p.dv[row] = f2bf(av);
+      p.dk[row] = f2bf(ak * ln2);
+    }
   }
 }
 
@@ -322,45 +383,53 @@ __global__ void __launch_bounds__(256) attn_delta_kernel(const bf16_t* dO, const
 
 extern "C" int vl_set_error(const char* msg);
 
-extern "C" int vl_attn_delta(const void* dO, const void* o, float* delta, int B, int H, int L, int dh, hipStream_t stream) {
-  if (B <= 0 || H <= 0 || L <= 0 || (dh & 7)) return vl_set_error("vl_attn_delta: bad shape");
-  long n = (long)B * H * L; long g = (n + 255) / 256; if (g > 8192) g = 8192;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((int)g), dim3(256), 0, stream, (const bf16_t*)dO, (const bf16_t*)o, delta, B, H, L, dh);
-  hipError_t e = hipGetLastError();
+template <int DH, bool TQ, bool TK>
+static int launch_bwd(const AttnBwdP& pin, int lq_main, int lk_main, hipStream_t stream) {
+  const size_t smA = (size_t)2 * NC * DH * 2 + (size_t)DH * (NC + 8) * 2 + (size_t)NWMAX * 32 * 4 + (size_t)NWMAX * DH * 4;
+  const size_t smB = (size_t)2 * NC * DH * 2 + (size_t)2 * DH * (NC + 8) * 2 + (size_t)2 * NC * 4 + (size_t)NWMAX * 64 * 4 +
+                     (size_t)NWMAX * 2 * DH * 4;
+  static const hipError_t attrA = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DH, TQ>,
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smA);
+  static const hipError_t attrB = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DH, TK>,
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smB);
+  if (attrA != hipSuccess) return vl_set_error(hipGetErrorString(attrA));
+  if (attrB != hipSuccess) return vl_set_error(hipGetErrorString(attrB));
+  AttnBwdP p = pin;
+  const int qtiles = (lq_main + 31) / 32, ktiles = (lk_main + 31) / 32;
+  const int nwq = qtiles < NWMAX ? qtiles : NWMAX, nwk = ktiles < NWMAX ? ktiles : NWMAX;
+  p.l_main = lq_main;
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, TQ>), dim3((qtiles + nwq - 1) / nwq, p.H, p.B), dim3(nwq * 64), smA, stream, p);
+  p.l_main = lk_main;
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, TK>), dim3((ktiles + nwk - 1) / nwk, p.H, p.B), dim3(nwk * 64), smB, stream, p);
+  const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : vl_set_error(hipGetErrorString(e));
 }
 
-extern "C" int vl_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* qt, const void* kt,
-                                const void* dO, const void* dOt, const float* lse, const float* delta,
-                                void* dq, void* dk, void* dv, long ld_dq, long ld_dkv,
-                                int B, int H, int Lq, int Lk, int Lqp, int Lkp, int dh, int causal, float scale,
-                                hipStream_t stream) {
+extern "C" int vl_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dO, const void* o,
+                                const long* strides, const float* lse, float* delta, void* dq, void* dk, void* dv,
+                                long ld_dq, long ld_dkv, int B, int H, int Lq, int Lk, int dh, float qscale, int causal,
+                                float scale, hipStream_t stream) {
   if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return vl_set_error("vl_attn_bwd_bf16: empty problem");
   if (dh != 64 && dh != 32) return vl_set_error("vl_attn_bwd_bf16: head dim must be 32 or 64");
-  if ((Lqp & 7) || (Lkp & 7) || Lqp < Lq || Lkp < Lk) return vl_set_error("vl_attn_bwd_bf16: bad padded lengths");
-  AttnBwdP p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)qt, (const bf16_t*)kt,
-             (const bf16_t*)dO, (const bf16_t*)dOt, lse, delta, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv,
-             ld_dq, ld_dkv, B, H, Lq, Lk, Lqp, Lkp, causal, scale};
-  const int qtiles = (Lq + 31) / 32, ktiles = (Lk + 31) / 32;
-  const int nwq = qtiles <= 9 ? qtiles : 8, nwk = ktiles <= 9 ? ktiles : 8;
-  const size_t smA = (size_t)2 * KC * dh * 2 + (size_t)dh * VS * 2;
-  const size_t smB = (size_t)2 * KC * dh * 2 + (size_t)2 * dh * VS * 2 + 2 * KC * sizeof(float);
-  hipError_t e;
-#define VL_LAUNCH_BWD(DHV)                                                                                                   \
-  do {                                                                                                                        \
-    static bool set_##DHV = false;                                                                                            \
-    if (!set_##DHV) {                                                                                                         \
-      e = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DHV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smA);    \
-      if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));                                                         \
-      e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DHV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smB);   \
-      if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));                                                         \
-      set_##DHV = true;                                                                                                       \
-    }                                                                                                                         \
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<DHV>, dim3((qtiles + nwq - 1) / nwq, H, B), dim3(nwq * 64), smA, stream, p);        \
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<DHV>, dim3((ktiles + nwk - 1) / nwk, H, B), dim3(nwk * 64), smB, stream, p);       \
-  } while (0)
-  if (dh == 64) VL_LAUNCH_BWD(64); else VL_LAUNCH_BWD(32);
-#undef VL_LAUNCH_BWD
-  e = hipGetLastError();
-  return e == hipSuccess ? 0 : vl_set_error(hipGetErrorString(e));
+  if (!strides || !delta || !lse) return vl_set_error("vl_attn_bwd_bf16: strides, lse and the delta workspace are required");
+  for (int i = 0; i < 15; ++i)
+    if (strides[i] & 7) return vl_set_error("vl_attn_bwd_bf16: operand strides must be multiples of 8 elements (16-byte rows)");
+  if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)dO) | ((uintptr_t)o)) & 15)
+    return vl_set_error("vl_attn_bwd_bf16: operands must be 16-byte aligned");
+  if ((((uintptr_t)dq) | ((uintptr_t)dk) | ((uintptr_t)dv)) & 15 || (ld_dq & 7) || (ld_dkv & 7))
+    return vl_set_error("vl_attn_bwd_bf16: gradient destinations must be 16-byte aligned with row strides multiple of 8");
+  const long* s = strides;
+  AttnBwdP p{TV{(const bf16_t*)q, s[0], s[1], s[2]},   TV{(const bf16_t*)k, s[3], s[4], s[5]},
+             TV{(const bf16_t*)v, s[6], s[7], s[8]},   TV{(const bf16_t*)dO, s[9], s[10], s[11]},
+             TV{(const bf16_t*)o, s[12], s[13], s[14]}, lse, delta, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv,
+             ld_dq, ld_dkv, B, H, Lq, Lk, causal, qscale, scale, 0};
+  // one row beyond whole tiles (257 tokens): shared by the 8 waves of the single workgroup instead of a ninth wave
+  const bool tq = (Lq % 32 == 1) && Lq > 32 && Lq - 1 <= NWMAX * 32 && Lk <= NC && (!causal || Lk <= Lq);
+  const bool tk = (Lk % 32 == 1) && Lk > 32 && Lk - 1 <= NWMAX * 32 && Lq <= NC;
+  const int lqm = tq ? Lq - 1 : Lq, lkm = tk ? Lk - 1 : Lk;
+#define VL_BWD(DHV)                                                                       \
+  (tq ? (tk ? launch_bwd<DHV, true, true>(p, lqm, lkm, stream) : launch_bwd<DHV, true, false>(p, lqm, lkm, stream)) \
+      : (tk ? launch_bwd<DHV, false, true>(p, lqm, lkm, stream) : launch_bwd<DHV, false, false>(p, lqm, lkm, stream)))
+  return dh == 64 ? VL_BWD(64) : VL_BWD(32);
+#undef VL_BWD
 }

@@ -23,7 +23,7 @@ SIGNATURES = {
     "vl_gemm_bf16": [P, P, P, P, P, I, I, I, I, I, I, F, I, I, I, P],
     "vl_gemm_qkv_bf16": [P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, I, I, P],
     "vl_gemm_splitk_accum_f32": [P, P, P, I, I, I, I, I, L, F, I, P, P],
-    "vl_attn_fwd_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "vl_attn_fwd_bf16": [P, P, P, P, P, P, I, I, I, I, I, F, I, P],
     "vl_layernorm_fwd": [P, I, L, P, L, P, P, P, I, L, P, P, I, I, F, P],
     "vl_assemble_ln_pre": [P, I, P, P, P, P, P, P, I, P, P, P, I, I, I, F, P],
     "vl_l2_normalize": [P, P, P, P, I, I, F, P],
@@ -56,8 +56,7 @@ SIGNATURES = {
     "vl_colsum": [P, I, L, P, I, I, F, P, P],
     "vl_gelu_bf16": [P, P, L, P],
     "vl_geglu_bf16": [P, P, L, I, P],
-    "vl_attn_delta": [P, P, P, I, I, I, I, P],
-    "vl_attn_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, I, I, I, I, I, F, P],
+    "vl_attn_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, I, I, F, I, F, P],
     "vl_adamw_step": [P, P, P, P, L, F, F, F, F, F, I, F, P],
     "vl_clamp_scalar": [P, F, F, P],
     "vl_axpy_f32": [P, P, F, L, P],

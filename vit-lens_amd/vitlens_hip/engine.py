@@ -78,9 +78,9 @@ class _Workspace:
         self.Lp = (L + 7) // 8 * 8
         self.x = torch.empty(B * L, D, device=device, dtype=res_dtype)
         self.h = torch.empty(B * L, D, device=device, dtype=bf)
-        self.q = torch.empty(B, H, L, dh, device=device, dtype=bf)
-        self.k = torch.empty(B, H, L, dh, device=device, dtype=bf)
-        self.vt = torch.zeros(B, H, dh, self.Lp, device=device, dtype=bf)
+        self.qkv = torch.empty(B * L, 3 * D, device=device, dtype=bf)     # packed in-projection output, read in place
+        hv = lambda i: ops.heads_view(self.qkv, B, L, H, dh, i * D)
+        self.q, self.k, self.v = hv(0), hv(1), hv(2)
         self.a = torch.empty(B * L, D, device=device, dtype=bf)
         self.hid = torch.empty(B * L, hidden, device=device, dtype=bf)
 
@@ -91,8 +91,8 @@ def run_blocks(blocks, ws: _Workspace, B, L, D, H, causal=False, cfg=-1):
     res_epi = ops.EPI_RES_F32 if ws.x.dtype == torch.float32 else ops.EPI_RES_BF16
     for w in blocks:
         ops.layernorm(ws.x, w["ln1_w"], w["ln1_b"], ws.h, B * L, D)
-        ops.gemm_qkv(ws.h, w["in_w"], w["in_b"], ws.q, ws.k, ws.vt, B, L, H, dh, cfg=cfg)
-        ops.attn_fwd(ws.q, ws.k, ws.vt, ws.a, causal=causal)
+        ops.gemm(ws.h, w["in_w"], w["in_b"], out=ws.qkv, epi=ops.EPI_BF16, cfg=cfg)
+        ops.attn_fwd(ws.q, ws.k, ws.v, ws.a, causal=causal, qscale=dh ** -0.5 * ops.LOG2E)
         ops.gemm(ws.a, w["out_w"], w["out_b"], out=ws.x, res=ws.x, epi=res_epi, cfg=cfg)
         ops.layernorm(ws.x, w["ln2_w"], w["ln2_b"], ws.h, B * L, D)
         ops.gemm(ws.h, w["fc_w"], w["fc_b"], out=ws.hid, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg)
@@ -268,13 +268,17 @@ class PerceiverEngine:
         f = lambda *s, dt=bf: torch.empty(*s, device=dev, dtype=dt)
         ws = {
             "x": f(B * n, D, dt=torch.float32), "h": f(B * n, D), "ctx": f(B * Tc, c.input_chan),
-            "xq": f(B, c.cross_heads, n, c.cross_dim_head), "xk": f(B, c.cross_heads, Tc, c.cross_dim_head),
-            "xvt": torch.zeros(B, c.cross_heads, c.cross_dim_head, (Tc + 7) // 8 * 8, device=dev, dtype=bf),
+            "xq2": f(B * n, c.cross_heads * c.cross_dim_head), "xkv2": f(B * Tc, 2 * c.cross_heads * c.cross_dim_head),
             "xa": f(B * n, c.cross_heads * c.cross_dim_head),
-            "sq": f(B, c.latent_heads, n, c.latent_dim_head), "sk": f(B, c.latent_heads, n, c.latent_dim_head),
-            "svt": torch.zeros(B, c.latent_heads, c.latent_dim_head, (n + 7) // 8 * 8, device=dev, dtype=bf),
+            "sqkv2": f(B * n, 3 * c.latent_heads * c.latent_dim_head),
             "sa": f(B * n, c.latent_heads * c.latent_dim_head), "hid": f(B * n, 4 * D),
         }
+        xi, si = c.cross_heads * c.cross_dim_head, c.latent_heads * c.latent_dim_head
+        ws["xq"] = ops.heads_view(ws["xq2"], B, n, c.cross_heads, c.cross_dim_head)
+        ws["xk"] = ops.heads_view(ws["xkv2"], B, Tc, c.cross_heads, c.cross_dim_head)
+        ws["xv"] = ops.heads_view(ws["xkv2"], B, Tc, c.cross_heads, c.cross_dim_head, xi)
+        for i, nm in enumerate(("sq", "sk", "sv")):
+            ws[nm] = ops.heads_view(ws["sqkv2"], B, n, c.latent_heads, c.latent_dim_head, i * si)
         self._ws[key] = ws
         return ws
 
@@ -294,19 +298,16 @@ class PerceiverEngine:
             a = lay["x_attn"]
             ops.layernorm(ws["x"], lay["x_norm"][0], lay["x_norm"][1], ws["h"], rows, D)
             ops.layernorm(data, lay["x_norm_ctx"][0], lay["x_norm_ctx"][1], ws["ctx"], B * Tc, c.input_chan)
-            ops.gemm_qkv(ws["h"], a["q_w"], None, ws["xq"], None, None, B, n, c.cross_heads, c.cross_dim_head,
-                         first=0, count=1, cfg=self.gemm_cfg)
-            ops.gemm_qkv(ws["ctx"], a["kv_w"], None, None, ws["xk"], ws["xvt"], B, Tc, c.cross_heads, c.cross_dim_head,
-                         first=1, count=2, cfg=self.gemm_cfg)
-            ops.attn_fwd(ws["xq"], ws["xk"], ws["xvt"], ws["xa"])
+            ops.gemm(ws["h"], a["q_w"], None, out=ws["xq2"], epi=ops.EPI_BF16, cfg=self.gemm_cfg)
+            ops.gemm(ws["ctx"], a["kv_w"], None, out=ws["xkv2"], epi=ops.EPI_BF16, cfg=self.gemm_cfg)
+            ops.attn_fwd(ws["xq"], ws["xk"], ws["xv"], ws["xa"], qscale=c.cross_dim_head ** -0.5 * ops.LOG2E)
             ops.gemm(ws["xa"], a["to_out_w"], a["to_out_b"], out=ws["x"], res=ws["x"], epi=ops.EPI_RES_F32, cfg=self.gemm_cfg)
             self._ff(ws, lay["x_ff_norm"], lay["x_ff"], rows, D)
             for sl in lay["selfs"]:
                 a = sl["attn"]
                 ops.layernorm(ws["x"], sl["norm"][0], sl["norm"][1], ws["h"], rows, D)
-                ops.gemm_qkv(ws["h"], a["qkv_w"], None, ws["sq"], ws["sk"], ws["svt"], B, n, c.latent_heads,
-                             c.latent_dim_head, cfg=self.gemm_cfg)
-                ops.attn_fwd(ws["sq"], ws["sk"], ws["svt"], ws["sa"])
+                ops.gemm(ws["h"], a["qkv_w"], None, out=ws["sqkv2"], epi=ops.EPI_BF16, cfg=self.gemm_cfg)
+                ops.attn_fwd(ws["sq"], ws["sk"], ws["sv"], ws["sa"], qscale=c.latent_dim_head ** -0.5 * ops.LOG2E)
                 ops.gemm(ws["sa"], a["to_out_w"], a["to_out_b"], out=ws["x"], res=ws["x"], epi=ops.EPI_RES_F32, cfg=self.gemm_cfg)
                 self._ff(ws, sl["ff_norm"], sl["ff"], rows, D)
         return ws["x"]

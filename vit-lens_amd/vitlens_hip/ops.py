@@ -127,12 +127,30 @@ def gemm_qkv(a, w, bias, q, k, vt, B, L, H, dh, softmax_scale=None, cfg=-1, firs
                                    a.shape[1], a.stride(0), float(scale), first, count, cfg, _stream()))
 
 
-def attn_fwd(q, k, vt, out, lse=None, causal=False):
-    """q [B,H,Lq,dh] (pre-scaled), k [B,H,Lk,dh], vt [B,H,dh,Lkp] -> out [B*Lq, H*dh] bf16."""
+def _bhld_strides(*views):
+    """(batch, head, row) element strides of [B,H,L,dh] views (last stride 1) as a ctypes long array."""
+    import ctypes
+    vals = []
+    for t in views:
+        if t.dim() != 4 or t.stride(3) != 1 or t.dtype != torch.bfloat16:
+            raise ValueError("attention operands must be bf16 [B,H,L,dh] views with unit last stride")
+        vals += [t.stride(0), t.stride(1), t.stride(2)]
+    return (ctypes.c_long * len(vals))(*vals)
+
+
+def heads_view(x2d, B, L, H, dh, col0=0):
+    """[B*L, W] token-major matrix -> the [B,H,L,dh] view of its column block [col0, col0 + H*dh) (no copy)."""
+    W = x2d.stride(0)
+    return x2d.as_strided((B, H, L, dh), (L * W, dh, W, 1), x2d.storage_offset() + col0)
+
+
+def attn_fwd(q, k, v, out, lse=None, causal=False, qscale=1.0):
+    """q [B,H,Lq,dh], k, v [B,H,Lk,dh] strided bf16 views (see heads_view) -> out [B*Lq, H*dh] bf16.
+    q is multiplied by qscale (softmax_scale*log2e) inside the kernel; pass 1 for a pre-scaled q."""
     B, H, Lq, dh = q.shape
     Lk = k.shape[2]
-    Lkp = vt.shape[3]
-    check(_lib.vl_attn_fwd_bf16(_p(q), _p(k), _p(vt), _p(out), _p(lse), B, H, Lq, Lk, Lkp, dh,
+    st = _bhld_strides(q, k, v)
+    check(_lib.vl_attn_fwd_bf16(_p(q), _p(k), _p(v), st, _p(out), _p(lse), B, H, Lq, Lk, dh, float(qscale),
                                 1 if causal else 0, _stream()))
     return out
 
@@ -325,19 +343,16 @@ def gelu_bf16(u, out):
     return out
 
 
-def attn_delta(dO, o, delta):
-    B, H, L, dh = dO.shape
-    check(_lib.vl_attn_delta(_p(dO), _p(o), _p(delta), B, H, L, dh, _stream()))
-    return delta
-
-
-def attn_bwd(q, k, v, qt, kt, dO, dOt, lse, delta, dq, dk, dv, ld_dq, ld_dkv, causal=False, softmax_scale=None):
+def attn_bwd(q, k, v, dO, o, lse, delta, dq, dk, dv, ld_dq, ld_dkv, causal=False, softmax_scale=None, qscale=None):
+    """q, k, v, dO, o: strided [B,H,L,dh] bf16 views read in place (o = the forward's token-major output viewed by
+    heads_view); delta [B,H,Lq] f32 workspace (filled here); dq/dk/dv token-major destinations."""
     B, H, Lq, dh = q.shape
     Lk = k.shape[2]
     scale = dh ** -0.5 if softmax_scale is None else softmax_scale
-    check(_lib.vl_attn_bwd_bf16(_p(q), _p(k), _p(v), _p(qt), _p(kt), _p(dO), _p(dOt), _p(lse), _p(delta), _p(dq), _p(dk),
-                                _p(dv), ld_dq, ld_dkv, B, H, Lq, Lk, qt.shape[3], kt.shape[3], dh, 1 if causal else 0,
-                                float(scale), _stream()))
+    qs = scale * LOG2E if qscale is None else qscale
+    st = _bhld_strides(q, k, v, dO, o)
+    check(_lib.vl_attn_bwd_bf16(_p(q), _p(k), _p(v), _p(dO), _p(o), st, _p(lse), _p(delta), _p(dq), _p(dk), _p(dv),
+                                ld_dq, ld_dkv, B, H, Lq, Lk, dh, float(qs), 1 if causal else 0, float(scale), _stream()))
 
 
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):

@@ -32,16 +32,16 @@ class _Saved:
         xres = f32 if res_dtype == torch.float32 else bf
         self.X = [xres(T, D) for _ in range(2 * layers + 1)]          # X[2l]=block input, X[2l+1]=after attention
         self.stats = [[f32(T) for _ in range(4)] for _ in range(layers)]   # mean1, rstd1, mean2, rstd2
-        self.q = [bf(B, H, L, dh) for _ in range(layers)]
-        self.k = [bf(B, H, L, dh) for _ in range(layers)]
-        self.v = [bf(B, H, L, dh) for _ in range(layers)]
-        self.qt = [torch.zeros(B, H, dh, Lp, device=device, dtype=BF) for _ in range(layers)]
-        self.kt = [torch.zeros(B, H, dh, Lp, device=device, dtype=BF) for _ in range(layers)]
+        # the packed in-projection output of every block; the attention kernels read q / k / v out of it in place
+        self.qkv = [bf(T, 3 * D) for _ in range(layers)]
+        hv = lambda m, i=0: ops.heads_view(m, B, L, H, dh, i * D)
+        self.q = [hv(m, 0) for m in self.qkv]; self.k = [hv(m, 1) for m in self.qkv]; self.v = [hv(m, 2) for m in self.qkv]
         self.a = [bf(T, D) for _ in range(layers)]
+        self.av = [hv(m) for m in self.a]
         self.lse = [f32(B, H, L) for _ in range(layers)]
         self.u = [bf(T, hidden) for _ in range(layers)]
         # temporaries shared by all blocks
-        self.h = bf(T, D); self.vt = torch.zeros(B, H, dh, Lp, device=device, dtype=BF); self.hid = bf(T, hidden)
+        self.h = bf(T, D); self.hid = bf(T, hidden)
         self.xpre = f32(T, D); self.pre_stats = [f32(T), f32(T)]
         self.post_stats = [f32(B), f32(B)]
         self.pooled = bf(B, D)
@@ -50,7 +50,7 @@ class _Saved:
         # with an f32 stream the GEMM operand is a separate bf16 copy
         self.dx = xres(T, D); self.dxb = bf(T, D) if res_dtype == torch.float32 else self.dx
         self.du = bf(T, hidden); self.dh = bf(T, D)
-        self.dO = bf(B, H, L, dh); self.dOt = torch.zeros(B, H, dh, Lp, device=device, dtype=BF)
+        self.dOm = bf(T, D); self.dO = hv(self.dOm)          # out-projection input gradient, read by heads in place
         self.delta = f32(B, H, L); self.dqkv = bf(T, 3 * D)
 
 
@@ -105,9 +105,8 @@ class TowerTrainer:
         for l, w in enumerate(e.blocks):
             m1, r1, m2, r2 = S.stats[l]
             ops.layernorm(S.X[2 * l], w["ln1_w"], w["ln1_b"], S.h, B * L, D, mean=m1, rstd=r1)
-            ops.gemm_qkv(S.h, w["in_w"], w["in_b"], S.q[l], S.k[l], S.vt, B, L, H, dh, cfg=cfg,
-                         qt=S.qt[l], kt=S.kt[l], v=S.v[l])
-            ops.attn_fwd(S.q[l], S.k[l], S.vt, S.a[l], lse=S.lse[l])
+            ops.gemm(S.h, w["in_w"], w["in_b"], out=S.qkv[l], epi=ops.EPI_BF16, cfg=cfg)
+            ops.attn_fwd(S.q[l], S.k[l], S.v[l], S.a[l], lse=S.lse[l], qscale=dh ** -0.5 * ops.LOG2E)
             ops.gemm(S.a[l], w["out_w"], w["out_b"], out=S.X[2 * l + 1], res=S.X[2 * l], epi=res_epi, cfg=cfg)
             ops.layernorm(S.X[2 * l + 1], w["ln2_w"], w["ln2_b"], S.h, B * L, D, mean=m2, rstd=r2)
             ops.gemm(S.h, w["fc_w"], w["fc_b"], out=S.hid, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg, out2=S.u[l])
@@ -181,10 +180,8 @@ class TowerTrainer:
             # ---- attention branch: x1 = x0 + out(attn(qkv(ln1(x0)))) ----
             if trainable:
                 self._dw(bp + "attn.out_proj.weight", S.dx, S.a[l], rows, bp + "attn.out_proj.bias")
-            ops.gemm_qkv(S.dxb, wT["out_w"], None, S.dO, None, None, B, L, H, dh, cfg=cfg, first=0, count=1,
-                         qt=S.dOt, raw_scale=1.0)                                                           # dO (+ transposed)
-            ops.attn_delta(S.dO, S.a[l], S.delta)
-            ops.attn_bwd(S.q[l], S.k[l], S.v[l], S.qt[l], S.kt[l], S.dO, S.dOt, S.lse[l], S.delta,
+            ops.gemm(S.dxb, wT["out_w"], None, out=S.dOm, epi=ops.EPI_BF16, cfg=cfg)                        # dO
+            ops.attn_bwd(S.q[l], S.k[l], S.v[l], S.dO, S.av[l], S.lse[l], S.delta,
                          S.dqkv, S.dqkv[:, D:], S.dqkv[:, 2 * D:], 3 * D, 3 * D)
             if trainable:
                 ops.layernorm(S.X[2 * l], w["ln1_w"], w["ln1_b"], S.h, rows, D)
@@ -302,15 +299,25 @@ class AdamW:
 # Perceiver ("Lens") training: autograd of Perceiver.forward (open_clip/perceiver.py:289-328)
 # ------------------------------------------------------------------------------------------------
 class _AttnSaved:
-    def __init__(self, B, H, Lq, Lk, dh, device):
+    """Saved operands of one Perceiver attention.  The projections' outputs are kept as token-major matrices (packed
+    [q|k|v] for latent self-attention, q and [k|v] for cross-attention); the kernels read them by heads in place."""
+
+    def __init__(self, B, H, Lq, Lk, dh, device, packed: bool):
         bf = lambda *s: torch.empty(*s, device=device, dtype=BF)
-        z = lambda *s: torch.zeros(*s, device=device, dtype=BF)
-        Lqp, Lkp = (Lq + 7) // 8 * 8, (Lk + 7) // 8 * 8
-        self.q, self.k, self.v = bf(B, H, Lq, dh), bf(B, H, Lk, dh), bf(B, H, Lk, dh)
-        self.qt, self.kt, self.vt = z(B, H, dh, Lqp), z(B, H, dh, Lkp), z(B, H, dh, Lkp)
-        self.a = bf(B * Lq, H * dh)
+        inner = H * dh
+        if packed:
+            self.qkv2 = bf(B * Lq, 3 * inner)
+            self.q2, self.kv2 = self.qkv2, None
+            self.q, self.k, self.v = (ops.heads_view(self.qkv2, B, Lq, H, dh, i * inner) for i in range(3))
+        else:
+            self.q2, self.kv2 = bf(B * Lq, inner), bf(B * Lk, 2 * inner)
+            self.q = ops.heads_view(self.q2, B, Lq, H, dh)
+            self.k, self.v = ops.heads_view(self.kv2, B, Lk, H, dh), ops.heads_view(self.kv2, B, Lk, H, dh, inner)
+        self.a = bf(B * Lq, inner)
+        self.av = ops.heads_view(self.a, B, Lq, H, dh)
         self.lse = torch.empty(B, H, Lq, device=device, dtype=torch.float32)
-        self.dO, self.dOt = bf(B, H, Lq, dh), z(B, H, dh, Lqp)
+        self.dOm = bf(B * Lq, inner)
+        self.dO = ops.heads_view(self.dOm, B, Lq, H, dh)
         self.delta = torch.empty(B, H, Lq, device=device, dtype=torch.float32)
 
 
@@ -358,10 +365,10 @@ class PerceiverTrainer:
               "dctx": bf(B * Tc, c.input_chan), "ddata": f32(B * Tc, c.input_chan), "layers": []}
         for _ in range(c.depth):
             lay = {"x_stats": [f32(R), f32(R)], "c_stats": [f32(B * Tc), f32(B * Tc)],
-                   "x_attn": _AttnSaved(B, c.cross_heads, n, Tc, c.cross_dim_head, dev),
+                   "x_attn": _AttnSaved(B, c.cross_heads, n, Tc, c.cross_dim_head, dev, packed=False),
                    "xff_stats": [f32(R), f32(R)], "xff_h": bf(R, 8 * D), "selfs": []}
             for _ in range(c.self_per_cross):
-                lay["selfs"].append({"stats": [f32(R), f32(R)], "attn": _AttnSaved(B, c.latent_heads, n, n, c.latent_dim_head, dev),
+                lay["selfs"].append({"stats": [f32(R), f32(R)], "attn": _AttnSaved(B, c.latent_heads, n, n, c.latent_dim_head, dev, packed=True),
                                      "ff_stats": [f32(R), f32(R)], "ff_h": bf(R, 8 * D)})
             st["layers"].append(lay)
         self._st[key] = st
@@ -387,11 +394,9 @@ class PerceiverTrainer:
             ops.layernorm(X[xi], lay["x_norm"][0], lay["x_norm"][1], st["h"], rows, D, mean=S["x_stats"][0], rstd=S["x_stats"][1])
             ops.layernorm(data, lay["x_norm_ctx"][0], lay["x_norm_ctx"][1], st["ctx"], B * Tc, c.input_chan,
                           mean=S["c_stats"][0], rstd=S["c_stats"][1])
-            ops.gemm_qkv(st["h"], a["q_w"], None, A.q, None, None, B, n, c.cross_heads, c.cross_dim_head, first=0, count=1,
-                         cfg=cfg, qt=A.qt)
-            ops.gemm_qkv(st["ctx"], a["kv_w"], None, None, A.k, A.vt, B, Tc, c.cross_heads, c.cross_dim_head, first=1, count=2,
-                         cfg=cfg, kt=A.kt, v=A.v)
-            ops.attn_fwd(A.q, A.k, A.vt, A.a, lse=A.lse)
+            ops.gemm(st["h"], a["q_w"], None, out=A.q2, epi=ops.EPI_BF16, cfg=cfg)
+            ops.gemm(st["ctx"], a["kv_w"], None, out=A.kv2, epi=ops.EPI_BF16, cfg=cfg)
+            ops.attn_fwd(A.q, A.k, A.v, A.a, lse=A.lse, qscale=c.cross_dim_head ** -0.5 * ops.LOG2E)
             ops.gemm(A.a, a["to_out_w"], a["to_out_b"], out=X[xi + 1], res=X[xi], epi=ops.EPI_RES_F32, cfg=cfg)
             xi += 1
             self._ff_fwd(st, xi, lay["x_ff_norm"], lay["x_ff"], S["xff_stats"], S["xff_h"], rows, D)
@@ -400,9 +405,8 @@ class PerceiverTrainer:
                 T = S["selfs"][sj]
                 a, A = sl["attn"], T["attn"]
                 ops.layernorm(X[xi], sl["norm"][0], sl["norm"][1], st["h"], rows, D, mean=T["stats"][0], rstd=T["stats"][1])
-                ops.gemm_qkv(st["h"], a["qkv_w"], None, A.q, A.k, A.vt, B, n, c.latent_heads, c.latent_dim_head, cfg=cfg,
-                             qt=A.qt, kt=A.kt, v=A.v)
-                ops.attn_fwd(A.q, A.k, A.vt, A.a, lse=A.lse)
+                ops.gemm(st["h"], a["qkv_w"], None, out=A.qkv2, epi=ops.EPI_BF16, cfg=cfg)
+                ops.attn_fwd(A.q, A.k, A.v, A.a, lse=A.lse, qscale=c.latent_dim_head ** -0.5 * ops.LOG2E)
                 ops.gemm(A.a, a["to_out_w"], a["to_out_b"], out=X[xi + 1], res=X[xi], epi=ops.EPI_RES_F32, cfg=cfg)
                 xi += 1
                 self._ff_fwd(st, xi, sl["ff_norm"], sl["ff"], T["ff_stats"], T["ff_h"], rows, D)
@@ -459,10 +463,9 @@ class PerceiverTrainer:
                 inner = H * dh
                 self._dw(pn + "0.fn.to_out.weight", st["dx"], A.a, rows)
                 ops.colsum(st["dx"], self.grad_buffer(pn + "0.fn.to_out.bias", (D,)))
-                ops.gemm_qkv(st["dxb"], w["out"], None, A.dO, None, None, B, n, H, dh, cfg=cfg, first=0, count=1, qt=A.dOt, raw_scale=1.0)
-                ops.attn_delta(A.dO, A.a, A.delta)
+                ops.gemm(st["dxb"], w["out"], None, out=A.dOm, epi=ops.EPI_BF16, cfg=cfg)
                 dqkv = st["dqkv"]
-                ops.attn_bwd(A.q, A.k, A.v, A.qt, A.kt, A.dO, A.dOt, A.lse, A.delta, dqkv, dqkv[:, inner:], dqkv[:, 2 * inner:],
+                ops.attn_bwd(A.q, A.k, A.v, A.dO, A.av, A.lse, A.delta, dqkv, dqkv[:, inner:], dqkv[:, 2 * inner:],
                              3 * inner, 3 * inner)
                 ops.layernorm(X[xi], sl["norm"][0], sl["norm"][1], st["h"], rows, D)
                 self._dw(pn + "0.fn.to_qkv.weight", dqkv, st["h"], rows)            # rows [to_q ; to_kv]
@@ -479,10 +482,9 @@ class PerceiverTrainer:
             inner = H * dh
             self._dw(pn + "0.fn.to_out.weight", st["dx"], A.a, rows)
             ops.colsum(st["dx"], self.grad_buffer(pn + "0.fn.to_out.bias", (D,)))
-            ops.gemm_qkv(st["dxb"], w["out"], None, A.dO, None, None, B, n, H, dh, cfg=cfg, first=0, count=1, qt=A.dOt, raw_scale=1.0)
-            ops.attn_delta(A.dO, A.a, A.delta)
+            ops.gemm(st["dxb"], w["out"], None, out=A.dOm, epi=ops.EPI_BF16, cfg=cfg)
             dkv = st["dkv"]
-            ops.attn_bwd(A.q, A.k, A.v, A.qt, A.kt, A.dO, A.dOt, A.lse, A.delta, st["dq"], dkv, dkv[:, inner:], inner, 2 * inner)
+            ops.attn_bwd(A.q, A.k, A.v, A.dO, A.av, A.lse, A.delta, st["dq"], dkv, dkv[:, inner:], inner, 2 * inner)
             # query side: LN(x) -> to_q
             ops.layernorm(X[xi], lay["x_norm"][0], lay["x_norm"][1], st["h"], rows, D)
             self._dw(pn + "0.fn.to_q.weight", st["dq"], st["h"], rows)
