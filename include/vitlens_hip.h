@@ -63,15 +63,6 @@ int vl_gemm_bf16(const void* A, const void* W, const float* bias, void* out, con
                  int M, int N, int K, int lda, int ldw, int ldo, float alpha, int epi, int act,
                  int cfg, hipStream_t stream);
 
-/* Packed in-projection of nn.MultiheadAttention (transformer.py:215,252) with the head split
- * fused into the epilogue: A[B*L,K] · Win[count*H*dh,K]^T + bias ->
- *   q [B,H,L,dh] (pre-multiplied by qscale), k [B,H,L,dh], vt [B,H,dh,Lp] (V transposed,
- *   key index contiguous, rows padded to Lp >= L; pad columns are never written). dh % 8 == 0.
- * (first,count) select which of (q,k,v) the rows of Win produce: (0,3) packed in_proj_weight /
- * [to_q;to_kv]; (0,1) Perceiver to_q; (1,2) Perceiver to_kv (perceiver.py:115-116,124-126). */
-int vl_gemm_qkv_bf16(const void* A, const void* Win, const float* bias, void* q, void* k, void* vt,
-                     int B, int L, int H, int dh, int Lp, int K, int lda, float qscale, int first,
-                     int count, int cfg, hipStream_t stream);
 /* Split-K accumulate for weight-gradient GEMMs (tiny M x N, K = token count): out[M,N] f32 (row stride ldo) +=
  * alpha * A[M,K] . W[N,K]^T.  The K range is cut into `splits` slices computed by separate workgroups into the
  * caller's workspace ws (splits*M*N floats) and summed in a fixed order (deterministic, no atomics).
@@ -80,15 +71,13 @@ int vl_gemm_splitk_accum_f32(const void* A, const void* W, float* out, int M, in
                              float alpha, int splits, float* ws, hipStream_t stream);
 /* vl_gemm_bf16 + `out2` (with VL_EPI_BF16/VL_ACT_GELU also stores the pre-activation, bf16, for the
  * backward) + `res_div` (VL_EPI_RES_BF16: residual row = m / res_div, i.e. one row broadcast over a group:
- * the PointNet concat([global, local]) conv of dvae.py:207-210 split into two GEMMs). */
+ * the PointNet concat([global, local]) conv of dvae.py:207-210 split into two GEMMs).
+ * The packed in-projection of nn.MultiheadAttention (transformer.py:215,252) and the Perceiver's to_q / to_kv
+ * (perceiver.py:115-116,124-126) are plain calls of this entry point: the attention kernels read q, k, v out of the
+ * [tokens, 3*width] result in place (rounds 1-2a had a head-scatter epilogue and transposed copies instead). */
 int vl_gemm_bf16_ex(const void* A, const void* W, const float* bias, void* out, const void* res, void* out2,
                     int M, int N, int K, int lda, int ldw, int ldo, float alpha, int epi, int act,
                     int res_div, int cfg, hipStream_t stream);
-/* vl_gemm_qkv_bf16 + optional extra layouts kept for the attention backward:
- * qt,kt [B,H,dh,Lp] (transposed q/k), v [B,H,L,dh] (row-major v).  Any output pointer may be NULL. */
-int vl_gemm_qkv_bf16_ex(const void* A, const void* Win, const float* bias, void* q, void* k, void* vt,
-                        void* qt, void* kt, void* v, int B, int L, int H, int dh, int Lp, int K, int lda,
-                        float qscale, int first, int count, int cfg, hipStream_t stream);
 
 int vl_device_info(int device, char* arch, int arch_len, int* cus, int* clock_khz, long* hbm_bytes);
 

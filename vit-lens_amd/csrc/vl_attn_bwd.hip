@@ -30,7 +30,8 @@
 namespace {
 using namespace vlattn;
 
-constexpr int NC = 288;        // keys (A) / queries (B) per LDS chunk: 9 tiles of 32
+constexpr int NC = 288;        // queries per LDS chunk of kernel B: 9 tiles of 32
+constexpr int NCA = 160;       // keys per LDS chunk of kernel A: 5 tiles (two workgroups per CU)
 constexpr int NWMAX = 8;
 constexpr float LOG2E = 1.4426950408889634f;
 
@@ -43,6 +44,7 @@ struct AttnBwdP {
   int B, H, Lq, Lk, causal;
   float qscale;             // q is multiplied by this at load (softmax scale * log2 e)
   float scale;              // softmax scale (dq = scale * dS K ; dk = ln2 * dS^T Q2)
+  VL_PROF_FIELD
   int l_main;               // queries (A) / keys (B) handled by per-wave tiles (L, or L-1 when the last row is shared)
 };
 
@@ -70,15 +72,19 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // ------------------------------------------------------------------------------------------- kernel A: dQ (+ delta)
-template <int DH, bool TAILQ>
-__global__ void __launch_bounds__(NWMAX * 64, 2) attn_bwd_dq_kernel(const AttnBwdP p) {
-  constexpr int RB = DH * 2, KS = DH / 16, DT = DH / 32, TS = NC + 8;
+// NCA keys per LDS chunk.  NCA = 160 (62 KB of LDS, <= 128 VGPRs) puts TWO workgroups on a CU, so one workgroup's staging
+// (a memory round trip that is bandwidth-bound chip-wide: every workgroup asks for its 40 KB at once) overlaps the
+// other's MFMA work; measured against the single-chunk 1-workgroup-per-CU version (load + compute strictly serial).
+template <int DH, int NCA, bool TAILQ>
+__global__ void __launch_bounds__(NWMAX * 64, 4) attn_bwd_dq_kernel(const AttnBwdP p) {
+  constexpr int RB = DH * 2, KS = DH / 16, DT = DH / 32, TS = NCA + 8, CH = DH / 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
-  unsigned char* sV = smem + NC * RB;
-  bf16_t* sKt = (bf16_t*)(smem + 2 * NC * RB);
+  unsigned char* sV = smem + NCA * RB;
+  bf16_t* sKt = (bf16_t*)(smem + 2 * NCA * RB);
   float* sP = (float*)(sKt + DH * TS);            // [NWMAX][32]  (TAILQ)
   float* sPart = sP + NWMAX * 32;                 // [NWMAX][DH]  (TAILQ)
+  bf16_t* sTail = (bf16_t*)(sPart + NWMAX * DH);  // [3][DH] the shared row of q, dO, O, fetched with the first chunk (TAILQ)
 
   const int b = blockIdx.z, h = blockIdx.y;
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
@@ -95,124 +101,157 @@ __global__ void __launch_bounds__(NWMAX * 64, 2) attn_bwd_dq_kernel(const AttnBw
   const int qidx = q0 + fr;
   const int qrow = qidx < p.l_main ? qidx : p.l_main - 1;
 
+  VL_PROF_STAMP(p, 0);
+  // one memory round trip for everything the workgroup needs first: the per-lane q / dO / O rows and the log-sum-exp
+  // are requested BEFORE the first chunk is staged and consumed after it (loads return in order)
+  u32x4 qraw[KS], graw[KS], oraw[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    qraw[ks] = *(const u32x4*)(Qb + (long)qrow * p.q.sr + ks * 16 + fg * 8);
+    graw[ks] = *(const u32x4*)(Gb + (long)qrow * p.dO.sr + ks * 16 + fg * 8);
+    oraw[ks] = *(const u32x4*)(Ob + (long)qrow * p.o.sr + ks * 16 + fg * 8);
+  }
+  const float lse_raw = p.lse[bh * p.Lq + qrow];
+  [[maybe_unused]] const float lse_tail = TAILQ ? p.lse[bh * p.Lq + p.Lq - 1] : 0.f;   // (uniform: a scalar load)
+  [[maybe_unused]] u32x4 tailraw = {0u, 0u, 0u, 0u};
+  if constexpr (TAILQ) {
+    if (tid < 3 * CH) {
+      const int m = tid / CH, c = tid % CH;
+      const bf16_t* src = m == 0 ? Qb + (long)(p.Lq - 1) * p.q.sr : (m == 1 ? Gb + (long)(p.Lq - 1) * p.dO.sr : Ob + (long)(p.Lq - 1) * p.o.sr);
+      tailraw = *(const u32x4*)(src + c * 8);
+    }
+  }
+  stage2<DH, NCA, true, true, true, false, 2>(StageSrc{sK, sKt, Kb, p.k.sr, 1.f}, StageSrc{sV, nullptr, Vb, p.v.sr, 1.f},
+                                              0, p.Lk, tid, nthr);
+  if constexpr (TAILQ) {
+    if (tid < 3 * CH) *(u32x4*)(sTail + tid * 8) = tailraw;
+  }
+  VL_PROF_STAMP(p, 1);
   bf16x8 qf[KS], dof[KS];
   float dlt = 0.f;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    qf[ks] = load_frag(Qb + (long)qrow * p.q.sr, ks, fg, p.qscale);
-    dof[ks] = load_frag(Gb + (long)qrow * p.dO.sr, ks, fg, 1.f);
-    dlt = dot8(dof[ks], load_frag(Ob + (long)qrow * p.o.sr, ks, fg, 1.f), dlt);
+    qf[ks] = __builtin_bit_cast(bf16x8, p.qscale != 1.0f ? scale_bf16x8(qraw[ks], p.qscale) : qraw[ks]);
+    dof[ks] = __builtin_bit_cast(bf16x8, graw[ks]);
+    dlt = dot8(dof[ks], __builtin_bit_cast(bf16x8, oraw[ks]), dlt);
   }
   dlt = xhalf_sum(dlt);
   if (active && fg == 0 && qidx < p.l_main) p.delta[bh * p.Lq + qidx] = dlt;
-  const float lse2 = p.lse[bh * p.Lq + qrow] * LOG2E;
-  f32x16 negl, negd;          // C operands: S2 - lse2 and dP - delta come out of the MFMAs directly
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { negl[r] = -lse2; negd[r] = -dlt; }
+  const float lse2 = lse_raw * LOG2E;
 
   f32x16 dq[DT];
 #pragma unroll
   for (int t = 0; t < DT; ++t) dq[t] = zero16();
+  if constexpr (TAILQ) {                           // the shared last query's partial rows accumulate in LDS (per wave)
+    if (fg == 0) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) sPart[wid * DH + t * 32 + fr] = 0.f;
+    }
+  }
 
   const int blk_q_hi = min(p.l_main - 1, (int)(blockIdx.x * nwq + nwq) * 32 - 1);
-  for (int kc0 = 0; kc0 < p.Lk; kc0 += NC) {
-    if (p.causal && kc0 > blk_q_hi) break;
+  for (int kc0 = 0; kc0 < p.Lk; kc0 += NCA) {
+    if (p.causal && kc0 > blk_q_hi && !TAILQ) break;
+    if (kc0 > 0) {
+      __syncthreads();
+      // (fewer loads in flight here: the accumulators are live)
+      stage2<DH, NCA, true, true, true, false, 1>(StageSrc{sK, sKt, Kb, p.k.sr, 1.f}, StageSrc{sV, nullptr, Vb, p.v.sr, 1.f},
+                                                  kc0, p.Lk, tid, nthr);
+    }
     __syncthreads();
-    stage2<DH, NC, true, true, true, false>(StageSrc{sK, sKt, Kb, p.k.sr, 1.f}, StageSrc{sV, nullptr, Vb, p.v.sr, 1.f},
-                                            kc0, p.Lk, tid, nthr);
-    __syncthreads();
-    if (!active) continue;
-    int ntile = (min(p.Lk - kc0, NC) + 31) >> 5;
-    if (p.causal) ntile = min(ntile, ((q0 + 31 - kc0) >> 5) + 1);
-    for (int kt = 0; kt < ntile; ++kt) {
-      f32x16 s = negl, dp = negd;
+    VL_PROF_STAMP(p, 2);
+    const int ctile = (min(p.Lk - kc0, NCA) + 31) >> 5;
+    if (active) {
+      int ntile = ctile;
+      if (p.causal) ntile = min(ntile, ((q0 + 31 - kc0) >> 5) + 1);
+      for (int kt = 0; kt < ntile; ++kt) {
+        f32x16 s = zero16(), dp = zero16();
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(sK, kt * 32 + fr, ks, fg), qf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(sV, kt * 32 + fr, ks, fg), dof[ks], dp, 0, 0, 0);
-      }
-      bf16x8 ktf[2][DT];
+        for (int ks = 0; ks < KS; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(sK, kt * 32 + fr, ks, fg), qf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(sV, kt * 32 + fr, ks, fg), dof[ks], dp, 0, 0, 0);
+        }
+        const int key0 = kc0 + kt * 32 + fg * 4;
+        const bool need_mask = (key0 - fg * 4 + 32 > p.Lk) || (p.causal && key0 - fg * 4 + 31 > q0);
+        if (need_mask) {
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+          for (int r = 0; r < 16; ++r) {
+            const int key = key0 + (r & 3) + 8 * (r >> 2);
+            if (key >= p.Lk || (p.causal && key > qidx)) s[r] = -INFINITY;
+          }
+        }
+        float ds[16];
 #pragma unroll
-        for (int t = 0; t < DT; ++t) ktf[c][t] = frag_t<NC>(sKt, t * 32 + fr, kt, c, fg);
-      const int key0 = kc0 + kt * 32 + fg * 4;
-      const bool need_mask = (key0 - fg * 4 + 32 > p.Lk) || (p.causal && key0 - fg * 4 + 31 > q0);
-      if (need_mask) {
+        for (int r = 0; r < 16; r += 2) {          // packed adds / multiplies: (s - lse2), (dp - delta), p * (dp - delta)
+          vl_f32x2 sv = {s[r], s[r + 1]}, dv = {dp[r], dp[r + 1]};
+          sv -= lse2; dv -= dlt;
+          const vl_f32x2 pv = {__builtin_amdgcn_exp2f(sv[0]), __builtin_amdgcn_exp2f(sv[1])};
+          dv *= pv;
+          ds[r] = dv[0]; ds[r + 1] = dv[1];
+        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = key0 + (r & 3) + 8 * (r >> 2);
-          if (key >= p.Lk || (p.causal && key > qidx)) s[r] = -INFINITY;
+        for (int c = 0; c < 2; ++c) {
+          const bf16x8 df = pack8(ds + c * 8);
+#pragma unroll
+          for (int t = 0; t < DT; ++t)
+            dq[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_t<NCA>(sKt, t * 32 + fr, kt, c, fg), df, dq[t], 0, 0, 0);
         }
       }
-      float ds[16];
+    }
+    if constexpr (TAILQ) {
+      // ---- the shared last query row against key tile(s) wid, wid + 8, ... of this chunk (lane = key; the row sees
+      //      every key: host guarantees no causal cut) ----
+      if (wid < ctile) {
+        // delta of the row: lane d multiplies dO[d] * O[d], summed over the wave
+        const float dT = wave_sum_dpp(lane < DH ? bf2f(sTail[DH + lane]) * bf2f(sTail[2 * DH + lane]) : 0.f);
+        if (kc0 == 0 && wid == 0 && lane == 0) p.delta[bh * p.Lq + p.Lq - 1] = dT;
+        const float lT = lse_tail * LOG2E;
+        float* myP = sP + wid * 32;
+        for (int kt = wid; kt < ctile; kt += nwq) {
+          // A operands: row 0 = the row of q / dO (lanes fr == 0), rows 1..31 zero; S then dP, one accumulator at a time
+          f32x16 acc = zero16();
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ds[r] = __builtin_amdgcn_exp2f(s[r]) * dp[r];
+          for (int ks = 0; ks < KS; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr == 0 ? load_frag(sTail, ks, fg, p.qscale) : zero_bf8(),
+                                                          frag_rows<DH>(sK, kt * 32 + fr, ks, fg), acc, 0, 0, 0);
+          const float s0 = acc[0];
+          acc = zero16();
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const bf16x8 df = pack8(ds + c * 8);
+          for (int ks = 0; ks < KS; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr == 0 ? load_frag(sTail + DH, ks, fg, 1.f) : zero_bf8(),
+                                                          frag_rows<DH>(sV, kt * 32 + fr, ks, fg), acc, 0, 0, 0);
+          // row 0 of D = slot 0 of the lanes with fg == 0; lane fr <-> key kc0 + kt*32 + fr
+          const bool valid = fg == 0 && kc0 + kt * 32 + fr < p.Lk;
+          const float dsv = valid ? __builtin_amdgcn_exp2f(s0 - lT) * (acc[0] - dT) : 0.f;
+          wave_lds_sync();
+          if (fg == 0) myP[fr] = dsv;
+          wave_lds_sync();
 #pragma unroll
-        for (int t = 0; t < DT; ++t) dq[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[c][t], df, dq[t], 0, 0, 0);
+          for (int t = 0; t < DT; ++t) {
+            acc = zero16();
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gather_row0(myP, c, fr, fg), frag_t<NCA>(sKt, t * 32 + fr, kt, c, fg),
+                                                            acc, 0, 0, 0);
+            if (fg == 0) sPart[wid * DH + t * 32 + fr] += acc[0];
+          }
+        }
       }
     }
   }
+  VL_PROF_STAMP(p, 3);
   if (active)
     store_rows_t<DT>(dq, p.scale, p.dq + ((size_t)b * p.Lq + qrow) * p.ld_dq + h * DH, fg, qidx < p.l_main);
-
+  VL_PROF_STAMP(p, 4);
   if constexpr (TAILQ) {
-    // ---- the shared last query row (host guarantees Lk <= NC, one workgroup per (b,h), the row sees every key) ----
-    const int qT = p.Lq - 1;
-    const int ntile = (p.Lk + 31) >> 5;
-    bf16x8 qa[KS], ga[KS];
-    float dT = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      qa[ks] = zero_bf8(); ga[ks] = zero_bf8();
-      if (fr == 0) {
-        qa[ks] = load_frag(Qb + (long)qT * p.q.sr, ks, fg, p.qscale);
-        ga[ks] = load_frag(Gb + (long)qT * p.dO.sr, ks, fg, 1.f);
-        dT = dot8(ga[ks], load_frag(Ob + (long)qT * p.o.sr, ks, fg, 1.f), dT);
-      }
-    }
-    dT = __shfl(dT, 0, 64) + __shfl(dT, 32, 64);
-    if (wid == 0 && lane == 0) p.delta[bh * p.Lq + qT] = dT;
-    const float lT = p.lse[bh * p.Lq + qT] * LOG2E;
-    float dqT[DT];
-#pragma unroll
-    for (int t = 0; t < DT; ++t) dqT[t] = 0.f;
-    float* myP = sP + wid * 32;
-    for (int kt = wid; kt < ntile; kt += nwq) {
-      f32x16 st = zero16(), dpt = zero16();
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], frag_rows<DH>(sK, kt * 32 + fr, ks, fg), st, 0, 0, 0);
-        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[ks], frag_rows<DH>(sV, kt * 32 + fr, ks, fg), dpt, 0, 0, 0);
-      }
-      // row 0 of D = slot 0 of the lanes with fg == 0; lane fr <-> key kt*32 + fr
-      const bool valid = fg == 0 && kt * 32 + fr < p.Lk;
-      const float dsv = valid ? __builtin_amdgcn_exp2f(st[0] - lT) * (dpt[0] - dT) : 0.f;
-      wave_lds_sync();
-      if (fg == 0) myP[fr] = dsv;
-      wave_lds_sync();
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const bf16x8 pa = gather_row0(myP, c, fr, fg);
-#pragma unroll
-        for (int t = 0; t < DT; ++t)
-          dqT[t] += __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_t<NC>(sKt, t * 32 + fr, kt, c, fg), zero16(), 0, 0, 0)[0];
-      }
-    }
-    if (fg == 0) {
-#pragma unroll
-      for (int t = 0; t < DT; ++t) sPart[wid * DH + t * 32 + fr] = dqT[t];
-    }
     __syncthreads();
     if (wid == 0 && lane < DH) {
       float acc = 0.f;
       for (int w = 0; w < nwq; ++w) acc += sPart[w * DH + lane];
-      p.dq[((size_t)b * p.Lq + qT) * p.ld_dq + h * DH + lane] = f2bf(acc * p.scale);
+      p.dq[((size_t)b * p.Lq + p.Lq - 1) * p.ld_dq + h * DH + lane] = f2bf(acc * p.scale);
     }
   }
+  VL_PROF_STAMP(p, 5);
 }
 
 // ------------------------------------------------------------------------------------- kernel B: dK, dV
@@ -228,6 +267,8 @@ __global__ void __launch_bounds__(NWMAX * 64, 2) attn_bwd_dkv_kernel(const AttnB
   float* sNegD = sNegL + NC;                      // -delta                       (0 on padded rows)
   float* sP = sNegD + NC;                         // [NWMAX][2][32]   (TAILK)
   float* sPart = sP + NWMAX * 64;                 // [NWMAX][2*DH]    (TAILK)
+  bf16_t* sTail = (bf16_t*)(sPart + NWMAX * 2 * DH);   // [2][DH] the shared key's K and V rows, fetched up front (TAILK)
+  constexpr int CH = DH / 8;
 
   const int b = blockIdx.z, h = blockIdx.y;
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
@@ -243,6 +284,12 @@ __global__ void __launch_bounds__(NWMAX * 64, 2) attn_bwd_dkv_kernel(const AttnB
   const int kidx = k0 + fr;
   const int krow = kidx < p.l_main ? kidx : p.l_main - 1;
 
+  VL_PROF_STAMP(p, 0);
+  [[maybe_unused]] u32x4 tailraw = {0u, 0u, 0u, 0u};
+  if constexpr (TAILK) {
+    if (tid < 2 * CH)
+      tailraw = *(const u32x4*)((tid < CH ? Kb + (long)(p.Lk - 1) * p.k.sr : Vb + (long)(p.Lk - 1) * p.v.sr) + (tid % CH) * 8);
+  }
   bf16x8 kf[KS], vf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
@@ -258,14 +305,38 @@ __global__ void __launch_bounds__(NWMAX * 64, 2) attn_bwd_dkv_kernel(const AttnB
 
   for (int qc0 = 0; qc0 < p.Lq; qc0 += NC) {
     __syncthreads();
+    // (log-sum-exp / delta of the chunk requested before the staging loads: one round trip)
+    float lraw[(NC + NWMAX * 64 - 1) / (NWMAX * 64)], draw[(NC + NWMAX * 64 - 1) / (NWMAX * 64)];
+    if (nthr == NWMAX * 64) {
+#pragma unroll
+      for (int j = 0; j < (NC + NWMAX * 64 - 1) / (NWMAX * 64); ++j) {
+        const int i = tid + j * NWMAX * 64;
+        const bool ok = i < NC && qc0 + i < p.Lq;
+        lraw[j] = ok ? p.lse[bh * p.Lq + qc0 + i] : INFINITY;
+        draw[j] = ok ? p.delta[bh * p.Lq + qc0 + i] : 0.f;
+      }
+    }
     stage2<DH, NC, true, true, true, true>(StageSrc{sQ, sQt, Qb, p.q.sr, p.qscale}, StageSrc{sdO, sdOt, Gb, p.dO.sr, 1.f},
                                            qc0, p.Lq, tid, nthr);
-    for (int i = tid; i < NC; i += nthr) {
-      const bool ok = qc0 + i < p.Lq;
-      sNegL[i] = ok ? -p.lse[bh * p.Lq + qc0 + i] * LOG2E : -INFINITY;
-      sNegD[i] = ok ? -p.delta[bh * p.Lq + qc0 + i] : 0.f;
+    if constexpr (TAILK) {
+      if (qc0 == 0 && tid < 2 * CH) *(u32x4*)(sTail + tid * 8) = tailraw;
     }
+    if (nthr == NWMAX * 64) {
+#pragma unroll
+      for (int j = 0; j < (NC + NWMAX * 64 - 1) / (NWMAX * 64); ++j) {
+        const int i = tid + j * NWMAX * 64;
+        if (i < NC) { sNegL[i] = -lraw[j] * LOG2E; sNegD[i] = -draw[j]; }
+      }
+    } else {
+      for (int i = tid; i < NC; i += nthr) {
+        const bool ok = qc0 + i < p.Lq;
+        sNegL[i] = ok ? -p.lse[bh * p.Lq + qc0 + i] * LOG2E : -INFINITY;
+        sNegD[i] = ok ? -p.delta[bh * p.Lq + qc0 + i] : 0.f;
+      }
+    }
+    VL_PROF_STAMP(p, 1);
     __syncthreads();
+    VL_PROF_STAMP(p, 2);
     const int ntile = (min(p.Lq - qc0, NC) + 31) >> 5;
     if (active) {
       int t0 = 0;
@@ -314,6 +385,7 @@ __global__ void __launch_bounds__(NWMAX * 64, 2) attn_bwd_dkv_kernel(const AttnB
         }
       }
     }
+    VL_PROF_STAMP(p, 3);
     if constexpr (TAILK) {
       // ---- the shared last key against query tile(s) wid, wid + 8, ... (lane = query) ----
       const int kT = p.Lk - 1;
@@ -323,8 +395,8 @@ __global__ void __launch_bounds__(NWMAX * 64, 2) attn_bwd_dkv_kernel(const AttnB
       for (int ks = 0; ks < KS; ++ks) {
         ka[ks] = zero_bf8(); va[ks] = zero_bf8();
         if (fr == 0) {
-          ka[ks] = load_frag(Kb + (long)kT * p.k.sr, ks, fg, 1.f);
-          va[ks] = load_frag(Vb + (long)kT * p.v.sr, ks, fg, 1.f);
+          ka[ks] = load_frag(sTail, ks, fg, 1.f);
+          va[ks] = load_frag(sTail + DH, ks, fg, 1.f);
         }
       }
       for (int qt = wid; qt < ntile; qt += nwk) {
@@ -355,6 +427,7 @@ __global__ void __launch_bounds__(NWMAX * 64, 2) attn_bwd_dkv_kernel(const AttnB
       }
     }
   }
+  VL_PROF_STAMP(p, 4);
   const float ln2 = 0.6931471805599453f;
   if (active) {
     store_rows_t<DT>(dk, ln2, p.dk + ((size_t)b * p.Lk + krow) * p.ld_dkv + h * DH, fg, kidx < p.l_main);
@@ -377,6 +450,7 @@ __global__ void __launch_bounds__(NWMAX * 64, 2) attn_bwd_dkv_kernel(const AttnB
       p.dk[row] = f2bf(ak * ln2);
     }
   }
+  VL_PROF_STAMP(p, 5);
 }
 
 }  // namespace
@@ -385,10 +459,11 @@ extern "C" int vl_set_error(const char* msg);
 
 template <int DH, bool TQ, bool TK>
 static int launch_bwd(const AttnBwdP& pin, int lq_main, int lk_main, hipStream_t stream) {
-  const size_t smA = (size_t)2 * NC * DH * 2 + (size_t)DH * (NC + 8) * 2 + (size_t)NWMAX * 32 * 4 + (size_t)NWMAX * DH * 4;
+  const size_t smA = (size_t)2 * NCA * DH * 2 + (size_t)DH * (NCA + 8) * 2 + (size_t)NWMAX * 32 * 4 + (size_t)NWMAX * DH * 4 +
+                     (size_t)3 * DH * 2;
   const size_t smB = (size_t)2 * NC * DH * 2 + (size_t)2 * DH * (NC + 8) * 2 + (size_t)2 * NC * 4 + (size_t)NWMAX * 64 * 4 +
-                     (size_t)NWMAX * 2 * DH * 4;
-  static const hipError_t attrA = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DH, TQ>,
+                     (size_t)NWMAX * 2 * DH * 4 + (size_t)2 * DH * 2;
+  static const hipError_t attrA = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DH, NCA, TQ>,
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smA);
   static const hipError_t attrB = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DH, TK>,
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smB);
@@ -398,8 +473,11 @@ static int launch_bwd(const AttnBwdP& pin, int lq_main, int lk_main, hipStream_t
   const int qtiles = (lq_main + 31) / 32, ktiles = (lk_main + 31) / 32;
   const int nwq = qtiles < NWMAX ? qtiles : NWMAX, nwk = ktiles < NWMAX ? ktiles : NWMAX;
   p.l_main = lq_main;
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, TQ>), dim3((qtiles + nwq - 1) / nwq, p.H, p.B), dim3(nwq * 64), smA, stream, p);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, NCA, TQ>), dim3((qtiles + nwq - 1) / nwq, p.H, p.B), dim3(nwq * 64), smA, stream, p);
   p.l_main = lk_main;
+#ifdef VL_ATTN_PROF
+  if (p.prof) p.prof += (size_t)p.B * p.H * ((qtiles + nwq - 1) / nwq) * 8;     // kernel B's stamps follow kernel A's
+#endif
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, TK>), dim3((ktiles + nwk - 1) / nwk, p.H, p.B), dim3(nwk * 64), smB, stream, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : vl_set_error(hipGetErrorString(e));
@@ -422,9 +500,13 @@ extern "C" int vl_attn_bwd_bf16(const void* q, const void* k, const void* v, con
   AttnBwdP p{TV{(const bf16_t*)q, s[0], s[1], s[2]},   TV{(const bf16_t*)k, s[3], s[4], s[5]},
              TV{(const bf16_t*)v, s[6], s[7], s[8]},   TV{(const bf16_t*)dO, s[9], s[10], s[11]},
              TV{(const bf16_t*)o, s[12], s[13], s[14]}, lse, delta, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv,
-             ld_dq, ld_dkv, B, H, Lq, Lk, causal, qscale, scale, 0};
+             ld_dq, ld_dkv, B, H, Lq, Lk, causal, qscale, scale,
+#ifdef VL_ATTN_PROF
+             vl_attn_prof_buf,
+#endif
+             0};
   // one row beyond whole tiles (257 tokens): shared by the 8 waves of the single workgroup instead of a ninth wave
-  const bool tq = (Lq % 32 == 1) && Lq > 32 && Lq - 1 <= NWMAX * 32 && Lk <= NC && (!causal || Lk <= Lq);
+  const bool tq = (Lq % 32 == 1) && Lq > 32 && Lq - 1 <= NWMAX * 32 && (!causal || Lk <= Lq);
   const bool tk = (Lk % 32 == 1) && Lk > 32 && Lk - 1 <= NWMAX * 32 && Lq <= NC;
   const int lqm = tq ? Lq - 1 : Lq, lkm = tk ? Lk - 1 : Lk;
 #define VL_BWD(DHV)                                                                       \

@@ -16,6 +16,21 @@
 #pragma once
 #include "vl_common.h"
 
+// Phase timeline for tools/attn_phase_prof.hip (built with -DVL_ATTN_PROF): wave 0 of every workgroup stamps the shader
+// clock at the phase boundaries.  Compiles to nothing in the library.
+#ifdef VL_ATTN_PROF
+extern "C" long* vl_attn_prof_buf;     // [workgroups][8] on the device, set by the tool
+#define VL_PROF_FIELD long* prof;
+#define VL_PROF_STAMP(p, i)                                                                                    \
+  do {                                                                                                         \
+    if ((p).prof && threadIdx.x == 0)                                                                          \
+      (p).prof[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define VL_PROF_FIELD
+#define VL_PROF_STAMP(p, i) do { } while (0)
+#endif
+
 namespace vlattn {
 
 struct TV {            // element (b, h, l, d) at p[b*sb + h*sh + l*sr + d]
@@ -65,9 +80,9 @@ __device__ __forceinline__ void stage_write(const StageSrc& m, int i, u32x4 a, u
   }
 }
 
-template <int DH, int NR, bool ROWS0, bool TRANS0, bool ROWS1, bool TRANS1>
+template <int DH, int NR, bool ROWS0, bool TRANS0, bool ROWS1, bool TRANS1, int U = 3>
 __device__ __forceinline__ void stage2(const StageSrc& m0, const StageSrc& m1, int row0, int L, int tid, int nthr) {
-  constexpr int CH = DH / 8, NP = (NR / 2) * CH, U = 3;
+  constexpr int CH = DH / 8, NP = (NR / 2) * CH;
   for (int base = 0; base < NP; base += U * nthr) {
     u32x4 a0[U], b0[U], a1[U], b1[U];
 #pragma unroll
@@ -77,13 +92,15 @@ __device__ __forceinline__ void stage2(const StageSrc& m0, const StageSrc& m1, i
       const int row = row0 + 2 * rp;
       const u32x4 z = {0u, 0u, 0u, 0u};
       a0[u] = z; b0[u] = z; a1[u] = z; b1[u] = z;
+      // 32-bit byte offsets from the uniform base pointers: global_load ... saddr + voffset, one VGPR per address
+      const unsigned o0 = ((unsigned)row * (unsigned)m0.sr + c * 8) * 2u, o1 = ((unsigned)row * (unsigned)m1.sr + c * 8) * 2u;
       if (i < NP && row < L) {
-        a0[u] = *(const u32x4*)(m0.src + (long)row * m0.sr + c * 8);
-        a1[u] = *(const u32x4*)(m1.src + (long)row * m1.sr + c * 8);
+        a0[u] = *(const u32x4*)((const unsigned char*)m0.src + o0);
+        a1[u] = *(const u32x4*)((const unsigned char*)m1.src + o1);
       }
       if (i < NP && row + 1 < L) {
-        b0[u] = *(const u32x4*)(m0.src + (long)(row + 1) * m0.sr + c * 8);
-        b1[u] = *(const u32x4*)(m1.src + (long)(row + 1) * m1.sr + c * 8);
+        b0[u] = *(const u32x4*)((const unsigned char*)m0.src + (o0 + (unsigned)m0.sr * 2u));
+        b1[u] = *(const u32x4*)((const unsigned char*)m1.src + (o1 + (unsigned)m1.sr * 2u));
       }
     }
 #pragma unroll

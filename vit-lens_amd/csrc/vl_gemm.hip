@@ -21,20 +21,10 @@ template <int EPI, int MT, int NTL>
 __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL], int mrow0, int ncol0, int fr, int fg) {
   // rows OUTER: a lane writes the 8 column groups of one row back to back, so the 128-byte lines of that row
   // are completed while still in the write-combining window (columns-outer order cost the fc GEMM 40 %).
-  // (pointer fields are copied to locals: selecting among struct members by index forces the struct to scratch)
-  [[maybe_unused]] bf16_t* const pq = p.q; [[maybe_unused]] bf16_t* const pk = p.k; [[maybe_unused]] bf16_t* const pv = p.v;
-  [[maybe_unused]] bf16_t* const pqt = p.qt; [[maybe_unused]] bf16_t* const pkt = p.kt; [[maybe_unused]] bf16_t* const pvt = p.vt;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = mrow0 + i * 32 + fr;
     if (m >= p.M) continue;
-    [[maybe_unused]] int qb = 0, ql = 0, vz = 0;
-    if constexpr (EPI == EPI_QKV) {
-      const int ma = m + p.m_off; qb = ma / p.L; ql = ma - qb * p.L;
-      // opaque per-lane zero: keeps the (part, head, offset) arithmetic below in VGPRs inside this loop;
-      // as hoisted wave-uniform values it needed ~60 SGPRs and spilled them into the k-loop.
-      asm volatile("" : "+v"(vz));
-    }
 #pragma unroll
     for (int j = 0; j < NTL; ++j) {
 #pragma unroll
@@ -86,31 +76,6 @@ __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL
           v[2] *= gelu_erf_grad(bf2f((bf16_t)(r[1] & 0xffff))); v[3] *= gelu_erf_grad(bf2f((bf16_t)(r[1] >> 16)));
           u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
           *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
-        } else if constexpr (EPI == EPI_QKV) {
-          // column -> (part, head, offset); D = H*dh, dh a power of two (dh_shift), at most 3 parts
-          const int D = p.H << p.dh_shift;
-          const int nv = n + vz;
-          const int wq = (nv >= D) + (nv >= 2 * D);
-          const int c = nv - wq * D;
-          const int which = wq + p.which0;
-          const int hh = c >> p.dh_shift, dd = c & ((1 << p.dh_shift) - 1);
-          const size_t bh = (size_t)qb * p.H + hh;
-          const size_t row_off = ((bh * p.L + ql) << p.dh_shift) + dd;          // [B,H,L,dh] layouts
-          const size_t col_off = ((bh << p.dh_shift) + dd) * p.Lp + ql;         // [B,H,dh,Lp] layouts
-          bf16_t* rowp = which == 0 ? pq : (which == 1 ? pk : pv);
-          bf16_t* colp = which == 0 ? pqt : (which == 1 ? pkt : pvt);
-          if (which == 0) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= p.qscale;
-          }
-          if (rowp) {
-            u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-            *(u32x2*)(rowp + row_off) = o;
-          }
-          if (colp) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) colp[col_off + (size_t)e * p.Lp] = f2bf(v[e]);
-          }
         } else if constexpr (EPI == EPI_GEGLU) {
           // interleaved rows: (a_j, gate_j, a_j+1, gate_j+1)
           if (p.out2) {   // pre-activation kept for the backward: bf16 [M, N], row stride 2*ldo
@@ -154,19 +119,6 @@ __device__ __forceinline__ void store_tile_lds16(const GemmP& p, f32x16 (&acc)[M
   const int n8 = ncol0 + c * 8;
   const bool col_ok = n8 < p.N;
   const bool gelu_pre = (EPI == EPI_BF16) && p.act == 1 && !p.out2;
-  // per-lane destination of the read-back chunk (QKV: column -> part, head, offset)
-  [[maybe_unused]] bf16_t* rowp = nullptr; [[maybe_unused]] int hh = 0, dd = 0;
-  if constexpr (EPI == EPI_QKV) {
-    // (pointer fields copied to locals first: selecting among struct members by index forces the struct to scratch)
-    bf16_t* const pq = p.q; bf16_t* const pk = p.k; bf16_t* const pv = p.v;
-    const int D = p.H << p.dh_shift;
-    const int nn = col_ok ? n8 : 0;
-    const int wq = (nn >= D) + (nn >= 2 * D);
-    const int cc = nn - wq * D;
-    const int which = wq + p.which0;
-    hh = cc >> p.dh_shift; dd = cc & ((1 << p.dh_shift) - 1);
-    rowp = which == 0 ? pq : (which == 1 ? pk : pv);
-  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -177,10 +129,6 @@ __device__ __forceinline__ void store_tile_lds16(const GemmP& p, f32x16 (&acc)[M
         f32x4 v = {acc[i][j0 + j][q * 4 + 0], acc[i][j0 + j][q * 4 + 1], acc[i][j0 + j][q * 4 + 2], acc[i][j0 + j][q * 4 + 3]};
         v = v * p.alpha;
         if (p.bias && n < p.N) v = v + *(const f32x4*)(p.bias + n);
-        if constexpr (EPI == EPI_QKV) {
-          const int D = p.H << p.dh_shift;
-          if (p.which0 == 0 && n < D) v = v * p.qscale;
-        }
         if constexpr (EPI == EPI_BF16) {
           if (gelu_pre) {
 #pragma unroll
@@ -196,12 +144,6 @@ __device__ __forceinline__ void store_tile_lds16(const GemmP& p, f32x16 (&acc)[M
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int mb = mrow0 + i * 32;
-    [[maybe_unused]] int sb = 0, sl = 0;
-    if constexpr (EPI == EPI_QKV) {
-      int vz = 0;
-      asm volatile("" : "+v"(vz));
-      const int ma = mb + p.m_off + vz; sb = ma / p.L; sl = ma - sb * p.L;
-    }
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int r = pass * 8 + rsub;
@@ -233,12 +175,6 @@ __device__ __forceinline__ void store_tile_lds16(const GemmP& p, f32x16 (&acc)[M
           w[e] = pack2bf(bf2f((bf16_t)(w[e] & 0xffff)) * gelu_erf_grad(bf2f((bf16_t)(rr[e] & 0xffff))),
                          bf2f((bf16_t)(w[e] >> 16)) * gelu_erf_grad(bf2f((bf16_t)(rr[e] >> 16))));
         *(u32x4*)((bf16_t*)p.out + (size_t)m * p.ldo + n8) = w;
-      } else if constexpr (EPI == EPI_QKV) {
-        if (rowp) {
-          int qb = sb, ql = sl + r;
-          while (ql >= p.L) { ql -= p.L; ++qb; }
-          *(u32x4*)(rowp + ((((size_t)qb * p.H + hh) * p.L + ql) << p.dh_shift) + dd) = w;
-        }
       }
     }
     asm volatile("" ::: "memory");
@@ -263,61 +199,37 @@ __device__ __forceinline__ void store_tile_lds(const GemmP& p, f32x16 (&acc)[MT]
     store_tile<EPI, MT, NTL>(p, acc, mrow0, ncol0, fr, fg);
     return;
   } else {
-    [[maybe_unused]] bool done16 = false;
-    if constexpr ((EPI == EPI_BF16 || EPI == EPI_RES_BF16 || EPI == EPI_DGELU || EPI == EPI_QKV) && (NTL & 1) == 0) {
-      // bf16 outputs: 16-byte path when rows stay 16-byte aligned (QKV destinations are [.., dh] rows with dh % 8 == 0)
-      const bool al = EPI == EPI_QKV ? (p.dh_shift >= 3) : ((p.ldo & 7) == 0);
-      if ((p.N & 7) == 0 && al) {
+    if constexpr ((EPI == EPI_BF16 || EPI == EPI_RES_BF16 || EPI == EPI_DGELU) && (NTL & 1) == 0) {
+      // bf16 outputs: 16-byte path when rows stay 16-byte aligned
+      if ((p.N & 7) == 0 && (p.ldo & 7) == 0) {
 #pragma unroll
         for (int j0 = 0; j0 < NTL; j0 += 2)
           store_tile_lds16<EPI, MT, NTL>(p, acc, j0, mrow0, ncol0 + j0 * 32, fr, fg, lane, wl);
-        if constexpr (EPI != EPI_QKV) return;
-        done16 = true;
+        return;
       }
     }
-    if (!done16) {
     const int rsub = lane >> 3, c = lane & 7;
     unsigned char* const wr = wl + fr * 128;
     const int wsw = (fr >> 1) & 7;
-    [[maybe_unused]] bf16_t* const pq = p.q; [[maybe_unused]] bf16_t* const pk = p.k; [[maybe_unused]] bf16_t* const pv = p.v;
-    // per-column-block constants (bias, QKV destination) first; then ROW blocks outermost so that the two 64-byte
+    // per-column-block constants (bias) first; then ROW blocks outermost so that the two 64-byte
     // halves of a bf16 output line (j = 0, 1) are written back to back - with the column block outermost they were
     // four row blocks apart and WRITE_SIZE rose to 1.5x the output bytes (partial lines evicted before completion).
     int nj[NTL]; bool okj[NTL]; f32x4 bvj[NTL];
-    [[maybe_unused]] bf16_t* rowpj[NTL]; [[maybe_unused]] int hhj[NTL], ddj[NTL]; [[maybe_unused]] float qsj[NTL];
 #pragma unroll
     for (int j = 0; j < NTL; ++j) {
       nj[j] = ncol0 + j * 32 + c * 4;
       okj[j] = nj[j] < p.N;
       bvj[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (p.bias && okj[j]) bvj[j] = *(const f32x4*)(p.bias + nj[j]);
-      if constexpr (EPI == EPI_QKV) {
-        const int D = p.H << p.dh_shift;
-        const int nn = okj[j] ? nj[j] : 0;
-        const int wq = (nn >= D) + (nn >= 2 * D);
-        const int cc = nn - wq * D;
-        const int which = wq + p.which0;
-        hhj[j] = cc >> p.dh_shift; ddj[j] = cc & ((1 << p.dh_shift) - 1);
-        rowpj[j] = which == 0 ? pq : (which == 1 ? pk : pv);
-        qsj[j] = which == 0 ? p.qscale : 1.f;
-      }
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int mb = mrow0 + i * 32;
-      [[maybe_unused]] int sb = 0, sl = 0;
-      if constexpr (EPI == EPI_QKV) {
-        int vz = 0;
-        asm volatile("" : "+v"(vz));        // per-lane opaque zero: keeps the division in VGPRs (SGPR pressure, see store_tile)
-        const int ma = mb + p.m_off + vz; sb = ma / p.L; sl = ma - sb * p.L;
-      }
 #pragma unroll
       for (int j = 0; j < NTL; ++j) {
         const int n = nj[j];
         const bool col_ok = okj[j];
         const f32x4 bv = bvj[j];
-        [[maybe_unused]] bf16_t* rowp = nullptr; [[maybe_unused]] int hh = 0, dd = 0; [[maybe_unused]] float qs = 1.f;
-        if constexpr (EPI == EPI_QKV) { rowp = rowpj[j]; hh = hhj[j]; dd = ddj[j]; qs = qsj[j]; }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 t = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
@@ -366,56 +278,9 @@ __device__ __forceinline__ void store_tile_lds(const GemmP& p, f32x16 (&acc)[MT]
             v[2] *= gelu_erf_grad(bf2f((bf16_t)(rr[1] & 0xffff))); v[3] *= gelu_erf_grad(bf2f((bf16_t)(rr[1] >> 16)));
             u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
             *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
-          } else if constexpr (EPI == EPI_QKV) {
-            if (rowp) {
-              int qb = sb, ql = sl + r;
-              while (ql >= p.L) { ql -= p.L; ++qb; }
-              v = v * qs;
-              u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-              *(u32x2*)(rowp + ((((size_t)qb * p.H + hh) * p.L + ql) << p.dh_shift) + dd) = o;
-            }
           }
         }
         asm volatile("" ::: "memory");
-      }
-    }
-    }   // !done16
-    // transposed attention operands straight from the accumulator layout (lanes = consecutive tokens = contiguous)
-    if constexpr (EPI == EPI_QKV) {
-      if (p.qt || p.kt || p.vt) {
-        [[maybe_unused]] bf16_t* const pqt = p.qt; [[maybe_unused]] bf16_t* const pkt = p.kt; [[maybe_unused]] bf16_t* const pvt = p.vt;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int m = mrow0 + i * 32 + fr;
-          if (m >= p.M) continue;
-          int vz = 0;
-          const int ma = m + p.m_off; const int qb = ma / p.L; const int ql = ma - qb * p.L;
-          asm volatile("" : "+v"(vz));
-#pragma unroll
-          for (int j = 0; j < NTL; ++j) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int n = ncol0 + j * 32 + q * 8 + fg * 4;
-              if (n >= p.N) continue;
-              const int D = p.H << p.dh_shift;
-              const int nv = n + vz;
-              const int wq = (nv >= D) + (nv >= 2 * D);
-              const int cc = nv - wq * D;
-              const int which = wq + p.which0;
-              bf16_t* colp = which == 0 ? pqt : (which == 1 ? pkt : pvt);
-              if (!colp) continue;
-              const int h2 = cc >> p.dh_shift, d2 = cc & ((1 << p.dh_shift) - 1);
-              const size_t col_off = ((((size_t)qb * p.H + h2) << p.dh_shift) + d2) * p.Lp + ql;
-              f32x4 bq = {0.f, 0.f, 0.f, 0.f};
-              if (p.bias) bq = *(const f32x4*)(p.bias + n);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float t = (acc[i][j][q * 4 + e] * p.alpha + bq[e]) * (which == 0 ? p.qscale : 1.f);
-                colp[col_off + (size_t)e * p.Lp] = f2bf(t);
-              }
-            }
-          }
-        }
       }
     }
   }
@@ -971,29 +836,3 @@ extern "C" int vl_gemm_splitk_accum_f32(const void* A, const void* W, float* out
   return 0;
 }
 
-extern "C" int vl_gemm_qkv_bf16_ex(const void* A, const void* W, const float* bias, void* q, void* k, void* vt,
-                                   void* qt, void* kt, void* v, int B, int L, int H, int dh, int Lp, int K, int lda,
-                                   float qscale, int first, int count, int cfg, hipStream_t stream);
-extern "C" int vl_gemm_qkv_bf16(const void* A, const void* W, const float* bias, void* q, void* k, void* vt,
-                                int B, int L, int H, int dh, int Lp, int K, int lda, float qscale, int first,
-                                int count, int cfg, hipStream_t stream) {
-  return vl_gemm_qkv_bf16_ex(A, W, bias, q, k, vt, nullptr, nullptr, nullptr, B, L, H, dh, Lp, K, lda, qscale, first, count,
-                             cfg, stream);
-}
-
-extern "C" int vl_gemm_qkv_bf16_ex(const void* A, const void* W, const float* bias, void* q, void* k, void* vt,
-                                   void* qt, void* kt, void* v, int B, int L, int H, int dh, int Lp, int K, int lda,
-                                   float qscale, int first, int count, int cfg, hipStream_t stream) {
-  VL_CHECK_ARG(first >= 0 && count >= 1 && first + count <= 3, "vl_gemm_qkv_bf16: bad (first, count)");
-  VL_CHECK_ARG(B > 0 && L > 0 && H > 0, "vl_gemm_qkv_bf16: empty problem");
-  VL_CHECK_ARG((K & 63) == 0, "vl_gemm_qkv_bf16: K must be a multiple of 64");
-  VL_CHECK_ARG(dh >= 8 && (dh & (dh - 1)) == 0, "vl_gemm_qkv_bf16: head dim must be a power of two >= 8");
-  VL_CHECK_ARG(Lp >= L, "vl_gemm_qkv_bf16: Lp < L");
-  GemmP p{};
-  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = bias;
-  p.M = B * L; p.N = count * H * dh; p.K = K; p.which0 = first; p.res_div = 1; p.lda = lda; p.ldw = K; p.ldo = 0; p.alpha = 1.f;
-  p.q = (bf16_t*)q; p.k = (bf16_t*)k; p.vt = (bf16_t*)vt; p.qt = (bf16_t*)qt; p.kt = (bf16_t*)kt; p.v = (bf16_t*)v; p.L = L; p.H = H; p.dh = dh; p.Lp = Lp; p.qscale = qscale; p.dh_shift = __builtin_ctz((unsigned)dh);
-  hipError_t e = run_gemm<EPI_QKV>(p, cfg, stream);
-  if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
-  return 0;
-}

@@ -11,7 +11,7 @@ enum Epi : int {
   EPI_F32 = 1,    // out f32  = acc*alpha + bias
   EPI_RES_F32 = 2,   // out f32  = res f32 + acc + bias      (in-place allowed)
   EPI_RES_BF16 = 3,  // out bf16 = res bf16 + acc + bias
-  EPI_QKV = 4,    // scatter to q[B,H,L,dh], k[B,H,L,dh], vt[B,H,dh,Lp]
+  // (4 was the head-scatter epilogue of rounds 1-2a: the attention kernels now read the packed projection in place)
   EPI_GEGLU = 5,  // rows interleaved (a_j, gate_j): out bf16[M, N/2] = a * gelu(gate)
   EPI_DGELU = 6,  // out bf16 = acc * gelu'(aux[m,n])   (backward through GELU fused into the dX GEMM)
   EPI_DGEGLU = 7, // acc = dy[M,N]; res = h[M,2N] interleaved (a,g): out[M,2N] = (dy*gelu(g), dy*a*gelu'(g)) interleaved
@@ -29,13 +29,7 @@ struct GemmP {
   float alpha;
   int act;           // 0 none, 1 gelu(erf), 2 relu
   int res_div;       // residual row = m / res_div (>=1): broadcast one row over a group of res_div rows
-  // QKV scatter
-  bf16_t *q, *k, *vt;
-  bf16_t *qt, *kt, *v;   // optional extra layouts for the attention backward (transposed q/k, row-major v)
-  int L, H, dh, Lp, dh_shift;
-  int which0;        // first part produced by this GEMM: 0 = q, 1 = k, 2 = v
-  float qscale;
-  int m_off;         // absolute row of local row 0 (QKV scatter of a row-split launch)
+  int m_off;         // absolute row of local row 0 of a row-split launch (EPI_RES_BF16 indexes its residual with it)
   // split-K (gemm_nt_kernel only): blockIdx.y owns k-slabs [y*ksplit_len, (y+1)*ksplit_len) and writes its
   // partial product to out + y*split_stride (f32 elements); ksplit_len == 0 -> whole K, no offset
   int ksplit_len;
@@ -59,7 +53,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // The epilogue parameters (pointers, strides, scatter geometry) are re-read from the kernarg segment through an
 // opaque pointer at the moment a tile is stored.  Without this the compiler keeps ~40 scalars live across
-// the whole k-loop and spills SGPRs to scratch INSIDE it (measured: QKV-scatter GEMM 0.60 -> 2.49 ms).
+// the whole k-loop and spills SGPRs to scratch INSIDE it (measured on the round-1 head-scatter GEMM: 0.60 -> 2.49 ms).
 typedef const __attribute__((address_space(4))) GemmP* KernargP;
 __device__ __forceinline__ GemmP reload_params() {
   GemmP r;

@@ -130,7 +130,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int prow = lane >> 3, pcol = (lane & 7) * 8;
   const unsigned lo_out = (unsigned)((prow * p.ldo + pcol) * 2);     // lane part of an output / aux address (row-major outputs)
   const int ldo2 = p.ldo * 2;
-  [[maybe_unused]] const float inv_L = EPI == EPI_QKV ? 1.0f / (float)p.L : 0.f;
   auto chunk_row = [](int ci) { return (ci >> 2) * 32 + (ci & 3) * 8; };
   [[maybe_unused]] const unsigned char* aux_src = nullptr;      // &aux[tile row 0 of this wave][tile col 0 of this wave] (current tile)
   auto load_pair = [&](auto GI) {
@@ -230,22 +229,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       // branch-free optional bias: read SOMETHING valid (the weight matrix) and select zero
       const bool has_bias = pe.bias != nullptr;
       const float* const bsrc = has_bias ? pe.bias : (const float*)pe.W;
-      [[maybe_unused]] const int Dm = pe.H << pe.dh_shift;
       // destination of this lane's chunks
-      [[maybe_unused]] unsigned char* out_base = nullptr;
-      [[maybe_unused]] bf16_t* qkv_base = nullptr;       // QKV: per-lane &part[0, head(lane's columns), 0, dd]
-      if constexpr (EPI == EPI_QKV) {
-        bf16_t* const pq = pe.q; bf16_t* const pk = pe.k; bf16_t* const pv = pe.v;
-        const int n8 = ncol0 + pcol;
-        const int wq = (n8 >= Dm) + (n8 >= 2 * Dm);
-        const int cc = n8 - wq * Dm;
-        const int which = wq + pe.which0;
-        bf16_t* rowp = which == 0 ? pq : (which == 1 ? pk : pv);
-        const int hh = cc >> pe.dh_shift, dd = cc & ((1 << pe.dh_shift) - 1);
-        qkv_base = rowp ? rowp + (((size_t)hh * pe.L) << pe.dh_shift) + dd : nullptr;
-      } else {
-        out_base = (unsigned char*)pe.out + ((size_t)mrow0 * pe.ldo + ncol0) * 2 + lo_out;
-      }
+      unsigned char* const out_base = (unsigned char*)pe.out + ((size_t)mrow0 * pe.ldo + ncol0) * 2 + lo_out;
       if constexpr (EPI == EPI_F32) {
         // fp32 partial product of a k-slice: 32x32 blocks through the slab, 16-byte stores (8 lanes per 128-byte line)
         float* const fout = (float*)pe.out + (size_t)cur_sp * pe.split_stride + (size_t)mrow0 * pe.ldo + ncol0;
@@ -280,9 +265,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
             for (int e = 0; e < 4; ++e) bv[e] = has_bias ? bv[e] : 0.f;
             v = v * pe.alpha + bv;
-            if constexpr (EPI == EPI_QKV) {
-              if (pe.which0 == 0 && n < Dm) v = v * pe.qscale;
-            }
             if constexpr (EPI == EPI_BF16 && ACT == 1) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
@@ -292,24 +274,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
             u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
             *(u32x2*)(wr + (((j * 4 + q) ^ wsw) << 4)) = o;
-            if constexpr (EPI == EPI_QKV) {
-              // transposed attention operands (token index contiguous) straight from the accumulator layout
-              const int wq = (n >= Dm) + (n >= 2 * Dm);
-              const int which = wq + pe.which0;
-              bf16_t* const pqt = pe.qt; bf16_t* const pkt = pe.kt; bf16_t* const pvt = pe.vt;
-              bf16_t* colp = which == 0 ? pqt : (which == 1 ? pkt : pvt);
-              if (colp) {
-                const int cc = n - wq * Dm;
-                const int h2 = cc >> pe.dh_shift, d2 = cc & ((1 << pe.dh_shift) - 1);
-                const int ma = mrow0 + i * 32 + fr + pe.m_off;
-                int qb = (int)(((float)ma + 0.5f) * inv_L);          // floor(ma / L) (exact for ma < 2^22; one correction step anyway)
-                int ql = ma - qb * pe.L;
-                if (ql < 0) { ql += pe.L; --qb; } else if (ql >= pe.L) { ql -= pe.L; ++qb; }
-                const size_t col_off = ((((size_t)qb * pe.H + h2) << pe.dh_shift) + d2) * pe.Lp + ql;
-                colp[col_off] = (bf16_t)(o[0] & 0xffff); colp[col_off + pe.Lp] = (bf16_t)(o[0] >> 16);
-                colp[col_off + 2 * (size_t)pe.Lp] = (bf16_t)(o[1] & 0xffff); colp[col_off + 3 * (size_t)pe.Lp] = (bf16_t)(o[1] >> 16);
-              }
-            }
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -337,17 +301,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
               w[e] = pack2bf(bf2f((bf16_t)(w[e] & 0xffff)) * gelu_erf_grad(bf2f((bf16_t)(rr[e] & 0xffff))),
                              bf2f((bf16_t)(w[e] >> 16)) * gelu_erf_grad(bf2f((bf16_t)(rr[e] >> 16))));
           }
-          if constexpr (EPI == EPI_QKV) {
-            if (qkv_base) {
-              const int m = mrow0 + pe.m_off + i * 32 + pass * 8 + prow;
-              int qb = (int)(((float)m + 0.5f) * inv_L);
-              int ql = m - qb * pe.L;
-              if (ql < 0) { ql += pe.L; --qb; } else if (ql >= pe.L) { ql -= pe.L; ++qb; }
-              __builtin_nontemporal_store(w, (u32x4*)(qkv_base + ((((size_t)qb * pe.H) * pe.L + ql) << pe.dh_shift)));
-            }
-          } else {
-            __builtin_nontemporal_store(w, (u32x4*)(out_base + (size_t)((i * 32 + pass * 8) * ldo2)));
-          }
+          __builtin_nontemporal_store(w, (u32x4*)(out_base + (size_t)((i * 32 + pass * 8) * ldo2)));
         }
       }
       zero_acc();
@@ -379,17 +333,16 @@ bool vl_gemm_park_supported(int epi, const void* params) {
     if (p.ksplit_len < 2 || nk % p.ksplit_len) return false;
     return !((((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.out) & 15));
   }
-  if (!(epi == EPI_BF16 || epi == EPI_RES_BF16 || epi == EPI_DGELU || epi == EPI_QKV)) return false;
+  if (!(epi == EPI_BF16 || epi == EPI_RES_BF16 || epi == EPI_DGELU)) return false;
   // whole tiles; the DMA prologue issues two k-steps of tile 0 up front
   if ((p.M & 255) || (p.N & 255) || (p.K & 63) || p.K < 512 || p.M <= 0 || p.N <= 0) return false;
   if (p.res_div != 1) return false;
   if (epi == EPI_RES_BF16 && p.act != 0) return false;
   if (epi == EPI_BF16 && p.out2 && p.act != 1) return false;
-  if (epi != EPI_QKV && (p.ldo & 7)) return false;
-  if (epi == EPI_QKV && (p.dh_shift < 3 || ((p.H << p.dh_shift) & 63) || (size_t)p.M + p.m_off >= (1u << 22))) return false;
+  if (p.ldo & 7) return false;
   // 16-byte accesses on every operand
   if (((uintptr_t)p.A | (uintptr_t)p.W) & 15) return false;
-  if (epi != EPI_QKV && (((uintptr_t)p.out | (uintptr_t)p.res | (uintptr_t)p.out2) & 15)) return false;
+  if (((uintptr_t)p.out | (uintptr_t)p.res | (uintptr_t)p.out2) & 15) return false;
   return true;
 }
 
@@ -401,7 +354,6 @@ int vl_gemm_park_launch(int epi, const void* params, int ncu, hipStream_t s) {
       return p.act == 2 ? (int)launch_pk<EPI_BF16, 2>(p, ncu, s) : (int)launch_pk<EPI_BF16, 0>(p, ncu, s);
     case EPI_RES_BF16: return (int)launch_pk<EPI_RES_BF16, 0>(p, ncu, s);
     case EPI_DGELU: return (int)launch_pk<EPI_DGELU, 0>(p, ncu, s);
-    case EPI_QKV: return (int)launch_pk<EPI_QKV, 0>(p, ncu, s);
     case EPI_F32: return (int)launch_pk<EPI_F32, 0>(p, ncu, s);
     default: return (int)hipErrorInvalidValue;
   }

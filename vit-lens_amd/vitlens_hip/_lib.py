@@ -21,7 +21,6 @@ SIGNATURES = {
     "vl_version": [],
     "vl_device_info": [I, C.c_char_p, I, C.POINTER(I), C.POINTER(I), C.POINTER(L)],
     "vl_gemm_bf16": [P, P, P, P, P, I, I, I, I, I, I, F, I, I, I, P],
-    "vl_gemm_qkv_bf16": [P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, I, I, P],
     "vl_gemm_splitk_accum_f32": [P, P, P, I, I, I, I, I, L, F, I, P, P],
     "vl_attn_fwd_bf16": [P, P, P, P, P, P, I, I, I, I, I, F, I, P],
     "vl_layernorm_fwd": [P, I, L, P, L, P, P, P, I, L, P, P, I, I, F, P],
@@ -48,7 +47,6 @@ SIGNATURES = {
     "vl_bn_bwd": [P, L, P, L, P, P, P, P, F, I, I, P, I, P, P, P, L, I, I, P],
     "vl_group_max_bwd": [P, L, P, L, P, L, P, L, L, I, I, P],
     "vl_group_sum": [P, L, P, L, L, I, I, P],
-    "vl_gemm_qkv_bf16_ex": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, I, I, P],
     "vl_layernorm_bwd": [P, I, L, P, I, L, P, P, P, P, P, P, L, I, I, P],
     "vl_layernorm_bwd_g": [P, I, L, P, I, L, P, P, P, P, P, I, P, L, I, I, P],
     "vl_colreduce_ws_floats": [I, I, I],

@@ -113,20 +113,6 @@ def gemm_dw(dyt, xt, g, cfg=-1, alpha=1.0):
     return gemm(dyt, xt, None, out=g, res=g, epi=EPI_RES_F32, cfg=cfg, alpha=alpha)
 
 
-def gemm_qkv(a, w, bias, q, k, vt, B, L, H, dh, softmax_scale=None, cfg=-1, first=0, count=3, qt=None, kt=None,
-             v=None, raw_scale=None):
-    """Packed MHA in-projection with head split: fills q,k [B,H,L,dh] and vt [B,H,dh,Lp].
-    (first, count) = which of (q,k,v) the rows of w produce."""
-    _chk2d(a, "a", torch.bfloat16); _chk2d(w, "w", torch.bfloat16)
-    if a.shape[0] != B * L or w.shape[0] != count * H * dh or w.stride(0) != w.shape[1]:
-        raise ValueError("gemm_qkv: shape mismatch")
-    tt = next((t for t in (vt, qt, kt) if t is not None), None)
-    Lp = tt.shape[-1] if tt is not None else (L + 7) // 8 * 8
-    scale = (dh ** -0.5 if softmax_scale is None else softmax_scale) * LOG2E if raw_scale is None else raw_scale
-    check(_lib.vl_gemm_qkv_bf16_ex(_p(a), _p(w), _p(bias), _p(q), _p(k), _p(vt), _p(qt), _p(kt), _p(v), B, L, H, dh, Lp,
-                                   a.shape[1], a.stride(0), float(scale), first, count, cfg, _stream()))
-
-
 def _bhld_strides(*views):
     """(batch, head, row) element strides of [B,H,L,dh] views (last stride 1) as a ctypes long array."""
     import ctypes
