@@ -140,7 +140,8 @@ int vl_transpose_colsum_bf16(const void* in, int in_dtype, long ldi, int R, int 
 /* InfoNCE pieces over logits f32 [R,C] (row r's positive is column r+label_off):
  *   vl_ce_stats      row_lse[R], col_lse[C], diag[R]; col_ws = 2*ceil(R/64)*C floats of workspace
  *   vl_ce_loss_accum *loss += w_row*mean(row_lse-diag) + w_col*mean(col_lse[r+off]-diag)
- *   vl_ce_grad       G[R,ldg] / GT[C,ldgt] bf16 = dLoss/dlogits (and transpose), *dscale += <G,logits>/scale
+ *   vl_ce_grad       G[R,ldg] / GT[C,ldgt] bf16 = dLoss/dlogits (and transpose), *dscale += <G,logits>/scale (two-stage
+ *                    fixed-order sum through ws = vl_ce_grad_ws_floats(R, C, ldg, ldgt) floats: deterministic)
  * Replaces F.cross_entropy(logits_per_x)+F.cross_entropy(logits_per_y) and autograd thereof
  * (loss.py:158-163, 300-306, 377-383). */
 /* f32 [rows,D] -> bf16 [rows,3D] hi/lo split (pattern 0: hi|lo|hi, 1: hi|hi|lo) for near-fp32 logits */
@@ -151,7 +152,8 @@ int vl_ce_loss_accum(const float* row_lse, const float* col_lse, const float* di
                      float w_row, float w_col, float* loss_inout, hipStream_t stream);
 int vl_ce_grad(const float* logits, long ld, int R, int C, int label_off, const float* row_lse, const float* col_lse,
                float w_row, float w_col, void* G, long ldg, void* GT, long ldgt, float logit_scale,
-               float* dscale_inout, hipStream_t stream);
+               float* dscale_inout, float* ws, hipStream_t stream);
+long vl_ce_grad_ws_floats(int R, int C, long ldg, long ldgt);
 
 /* ---- backward / optimizer (trainable towers; autograd of the ops above) ---------------------- */
 /* dx = dLN(dy) + dres (optional); outputs f32 `dx` and/or a bf16 copy `dx_bf16` (next GEMM operand). */

@@ -179,6 +179,36 @@ def test_forward_without_no_grad_refuses_an_untrainable_tower():
     assert not f.requires_grad
 
 
+def test_skip_trans_first_n_layers_through_factory():
+    """--skip-trans-first-n-layers (factory.py:347-360, the OpenShape flavour): the factory drops the first n blocks of the
+    visual tower after the weights are loaded and renumbers the rest; the forward must equal the oracle's on the kept
+    blocks, and differ from the full tower's."""
+    oc = _oc()
+    case = load_npz("tiny_depth.npz")
+    sd, ins, outs, grads, meta = split(case)
+    args = dict(meta["args"]); args["skip_trans_first_n_layers"] = 1
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "tiny-lens.json"), "w") as f:
+            json.dump(meta["model_cfg"], f)
+        oc.add_model_config(td)
+        ck = os.path.join(td, "w.pt")
+        torch.save({"state_dict": sd}, ck)
+        model = oc.tri_create_model("tiny-lens", ck, device="cuda", output_dict=True, args=SimpleNamespace(**args))
+    msd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    blocks = {int(k.split(".")[3]) for k in msd if k.startswith("visual.transformer.resblocks.")}
+    assert blocks == {0} and {int(k.split(".")[3]) for k in msd if k.startswith("image.transformer.resblocks.")} == {0, 1}
+    for n in ("attn.in_proj_weight", "mlp.c_fc.weight", "ln_2.bias"):        # kept block 0 IS the checkpoint's block 1
+        assert torch.equal(msd[f"visual.transformer.resblocks.0.{n}"], sd[f"visual.transformer.resblocks.1.{n}"].float())
+    model.eval()
+    with torch.no_grad():
+        fv = model.encode_visual(ins["visual_x"].cuda(), normalize=True)
+    tower, text, lens = specs_from_meta(meta)
+    import dataclasses
+    ref = O.encode_visual(msd, ins["visual_x"], dataclasses.replace(tower, layers=1), lens, normalize=True)
+    assert float((fv.float().cpu() - ref).norm() / ref.norm()) < 3e-2
+    assert float((fv.float().cpu() - outs["visual_features"]).norm() / outs["visual_features"].norm()) > 0.1   # 2 blocks -> 1
+
+
 def test_vitlens_encode_api_at_full_size():
     """mm_vit_lens.ViTLens.encode (vitlens.py:170-189): {modality: inputs} -> {modality: unit-norm [B,768]} on ViT-L
     models built by the drop-in factory (seeded random init); image/text through one shared model, depth through its

@@ -85,10 +85,11 @@ __global__ void __launch_bounds__(256) ce_reduce_kernel(const float* row_lse, co
   if (threadIdx.x == 0) atomicAdd(loss_out, (sh[0] + sh[1] + sh[2] + sh[3]) / (float)R);
 }
 
-// G[r,c] = w_row/R * (softmax_row - onehot) + w_col/R * (softmax_col - onehot); also G^T; dscale += sum(G*l)/scale
+// G[r,c] = w_row/R * (softmax_row - onehot) + w_col/R * (softmax_col - onehot); also G^T;
+// part[block] = sum over the block of G*l (stage 1 of the deterministic d/dscale reduction: no fp32 atomics)
 __global__ void __launch_bounds__(256) grad_kernel(const float* lg, long ld, int R, int C, int off,
                                                    const float* row_lse, const float* col_lse, float w_row, float w_col,
-                                                   bf16_t* G, long ldg, bf16_t* GT, long ldgt, float inv_scale, float* dscale) {
+                                                   bf16_t* G, long ldg, bf16_t* GT, long ldgt, float* part) {
   __shared__ float tile[32][33];
   __shared__ float red[4];
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -117,11 +118,26 @@ __global__ void __launch_bounds__(256) grad_kernel(const float* lg, long ld, int
       if (c < C && r < ldgt) GT[(long)c * ldgt + r] = f2bf(r < R ? tile[tx][ty + k * 8] : 0.f);
     }
   }
-  if (dscale) {
+  if (part) {
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(dscale, (red[0] + red[1] + red[2] + red[3]) * inv_scale);
+    if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+// out[0] += scale * sum_i part[i]: one block, every thread a fixed strided subsequence, fixed-order tree on top
+__global__ void __launch_bounds__(1024) part_finalize_kernel(const float* part, long n, float scale, float* out) {
+  __shared__ float sh[16];
+  float a = 0.f;
+  for (long i = threadIdx.x; i < n; i += 1024) a += part[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    out[0] += t * scale;
   }
 }
 
@@ -288,13 +304,21 @@ extern "C" int vl_ce_loss_accum(const float* row_lse, const float* col_lse, cons
 
 extern "C" int vl_ce_grad(const float* logits, long ld, int R, int C, int label_off, const float* row_lse, const float* col_lse,
                           float w_row, float w_col, void* G, long ldg, void* GT, long ldgt, float logit_scale,
-                          float* dscale_inout, hipStream_t stream) {
+                          float* dscale_inout, float* ws, hipStream_t stream) {
   if (R <= 0 || C <= 0) return vl_set_error("vl_ce_grad: empty problem");
+  if (dscale_inout && !ws) return vl_set_error("vl_ce_grad: d/dscale needs a workspace of vl_ce_grad_ws_floats(R, C, ldg, ldgt) floats");
   const int gc = (int)(((G && ldg > C ? ldg : C) + 31) / 32), gr = (int)(((GT && ldgt > R ? ldgt : R) + 31) / 32);
   hipLaunchKernelGGL(grad_kernel, dim3(gc, gr), dim3(256), 0, stream, logits, ld, R, C, label_off, row_lse, col_lse, w_row, w_col,
-                     (bf16_t*)G, ldg, (bf16_t*)GT, ldgt, 1.0f / logit_scale, dscale_inout);
+                     (bf16_t*)G, ldg, (bf16_t*)GT, ldgt, dscale_inout ? ws : nullptr);
+  if (dscale_inout)
+    hipLaunchKernelGGL(part_finalize_kernel, dim3(1), dim3(1024), 0, stream, ws, (long)gc * gr, 1.0f / logit_scale, dscale_inout);
   VL_HIP_OK(hipGetLastError());
   return 0;
+}
+
+extern "C" long vl_ce_grad_ws_floats(int R, int C, long ldg, long ldgt) {
+  const long gc = ((ldg > C ? ldg : C) + 31) / 32, gr = ((ldgt > R ? ldgt : R) + 31) / 32;
+  return gc * gr;
 }
 
 extern "C" int vl_l2_normalize_bwd(const float* f, const float* df, const float* norms, float* dx, int rows, int D, float eps,

@@ -154,7 +154,11 @@ def tri_create_model(model_name: str, pretrained: Optional[str] = None, precisio
         model.output_dict = True
     skip = getattr(args, "skip_trans_first_n_layers", None) if args is not None else None
     if skip is not None:
-        raise NotImplementedError("skip_trans_first_n_layers (OpenShape flavour) is listed under SURVEY §8(f) N4")
+        # "Add skip-first-n-layers here to drop layers" (factory.py:347-360): after the weights are in place
+        n_layers = model.visual.cfg.layers
+        assert skip < n_layers
+        logging.info("Using last %d out of %d transformer layers.", n_layers - skip, n_layers)
+        model.visual.keep_last_layers(n_layers - skip)
     return model
 
 

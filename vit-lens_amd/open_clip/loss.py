@@ -85,58 +85,41 @@ def gather_packed(feats, local_loss=False, gather_with_grad=False, rank=0, world
 
 # ------------------------------------------------------------------------------------------------ pair loss
 class _ContrastivePair(torch.autograd.Function):
-    """loss = w_row * CE(scale * X Y^T, r -> r+off) + w_col * CE(scale * Y X^T) as one autograd node."""
+    """loss = w_row * CE(scale * X Y^T, r -> r+off) + w_col * CE(scale * Y X^T) as one autograd node (the same kernels
+    and the same row-blocked mode as the fused training steps: vitlens_hip.step.pair_forward / pair_backward)."""
 
     @staticmethod
-    def forward(ctx, x, y, logit_scale, label_off, w_row, w_col):
-        from vitlens_hip import ops
+    def forward(ctx, x, y, logit_scale, label_off, w_row, w_col, chunk_rows):
+        from vitlens_hip.step import pair_forward
         if not (x.is_cuda and y.is_cuda):
             raise RuntimeError("contrastive losses run on the GPU kernels only (no CPU fallback)")
         x = x.contiguous().float(); y = y.contiguous().float()
-        R, D = x.shape
-        Cn = y.shape[0]
-        scale = float(logit_scale)
-        # hi/lo bf16 split of both feature sets: logits accurate to ~2^-17 (one GEMM with K = 3D)
-        xb, yb = ops.split_bf16x3(x, 0), ops.split_bf16x3(y, 1)
-        logits = ops.logits_gemm(xb, yb, scale)                                # [R, Cn] f32 (view of a 4-column-padded buffer), written once
-        row_lse, col_lse, diag = ops.ce_stats(logits, label_off, want_cols=(w_col != 0.0))
-        loss = torch.zeros(1, device=x.device, dtype=torch.float32)
-        ops.ce_loss_accum(loss, row_lse if w_row != 0.0 else None, col_lse, diag, R, Cn, label_off, w_row, w_col)
-        ctx.save_for_backward(x, y, logits, row_lse, col_lse if col_lse is not None else row_lse)
-        ctx.cfg = (label_off, w_row, w_col, scale, col_lse is not None, logit_scale.requires_grad
-                   if isinstance(logit_scale, torch.Tensor) else False)
+        loss, ctx.pair = pair_forward(x, y, float(logit_scale), label_off, w_row, w_col, chunk_rows=chunk_rows)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, gout):
-        from vitlens_hip import ops
-        x, y, logits, row_lse, col_lse = ctx.saved_tensors
-        label_off, w_row, w_col, scale, has_col, _ = ctx.cfg
-        g = float(gout)
-        R, D = x.shape
-        Cn = y.shape[0]
-        dscale = torch.zeros(1, device=x.device, dtype=torch.float32)
-        G, GT = ops.ce_grad(logits, row_lse if w_row != 0.0 else None, col_lse if has_col else None, label_off,
-                            w_row * g, w_col * g, scale, dscale)
-        yt = ops.transpose_to_bf16(y, ldo=G.shape[1])       # [D, Cpad]
-        xt = ops.transpose_to_bf16(x, ldo=GT.shape[1])      # [D, Rpad]
-        dx = ops.gemm(G, yt, None, epi=ops.EPI_F32, alpha=scale)     # dL/dX = scale * G  Y
-        dy = ops.gemm(GT, xt, None, epi=ops.EPI_F32, alpha=scale)    # dL/dY = scale * G^T X
-        return dx, dy, dscale.reshape(()), None, None, None
+        from vitlens_hip.step import pair_backward
+        dx, dy, dscale = pair_backward(ctx.pair, float(gout), need_dx=ctx.needs_input_grad[0], need_dy=ctx.needs_input_grad[1])
+        ctx.pair = None
+        return dx, dy, dscale.reshape(()), None, None, None, None
 
 
-def contrastive_pair(x, y, logit_scale, label_off=0, w_row=0.5, w_col=0.5):
+def contrastive_pair(x, y, logit_scale, label_off=0, w_row=0.5, w_col=0.5, chunk_rows=None):
     if not isinstance(logit_scale, torch.Tensor):
         logit_scale = torch.tensor(float(logit_scale), device=x.device)
-    return _ContrastivePair.apply(x, y, logit_scale, int(label_off), float(w_row), float(w_col))
+    return _ContrastivePair.apply(x, y, logit_scale, int(label_off), float(w_row), float(w_col), chunk_rows)
 
 
 class _LossBase(nn.Module):
     def __init__(self, local_loss=False, gather_with_grad=False, cache_labels=False, rank=0, world_size=1,
-                 use_horovod=False):
+                 use_horovod=False, chunk_rows=None):
+        """chunk_rows (extension): rows per block of the logits (None = automatic: whole matrix up to 2^26 elements,
+        2048-row blocks above; 0 = never block).  Results are the same up to fp32 summation order."""
         super().__init__()
         self.local_loss, self.gather_with_grad, self.cache_labels = local_loss, gather_with_grad, cache_labels
         self.rank, self.world_size, self.use_horovod = rank, world_size, use_horovod
+        self.chunk_rows = chunk_rows
 
     def pair_loss(self, x, y, logit_scale, gathered=None):
         """(CE(logits_per_x) + CE(logits_per_y)) / 2 with the reference's gather / local_loss rules
@@ -146,10 +129,10 @@ class _LossBase(nn.Module):
                 x, y, self.local_loss, self.gather_with_grad, self.rank, self.world_size, self.use_horovod)
             if self.local_loss:
                 off = x.shape[0] * self.rank
-                return (contrastive_pair(x, all_y, logit_scale, off, 0.5, 0.0)
-                        + contrastive_pair(y, all_x, logit_scale, off, 0.5, 0.0))
-            return contrastive_pair(all_x, all_y, logit_scale, 0, 0.5, 0.5)
-        return contrastive_pair(x, y, logit_scale, 0, 0.5, 0.5)
+                return (contrastive_pair(x, all_y, logit_scale, off, 0.5, 0.0, self.chunk_rows)
+                        + contrastive_pair(y, all_x, logit_scale, off, 0.5, 0.0, self.chunk_rows))
+            return contrastive_pair(all_x, all_y, logit_scale, 0, 0.5, 0.5, self.chunk_rows)
+        return contrastive_pair(x, y, logit_scale, 0, 0.5, 0.5, self.chunk_rows)
 
 
 class ClipLoss(_LossBase):

@@ -213,6 +213,23 @@ class VisionTransformer(nn.Module):
     def set_grad_checkpointing(self, enable=True):
         self.grad_checkpointing = enable
 
+    def keep_last_layers(self, n_keep: int):
+        """`model.visual.transformer.resblocks = resblocks[-n_keep:]` of --skip-trans-first-n-layers (factory.py:347-360):
+        the first blocks are dropped AFTER the checkpoint is loaded and the kept ones are renumbered from 0, as slicing
+        an nn.Sequential / ModuleList does (so a later state_dict() has n_keep blocks)."""
+        import dataclasses
+        mods = self.transformer.resblocks._modules
+        L = len(mods)
+        if not 0 < n_keep <= L:
+            raise ValueError(f"cannot keep {n_keep} of {L} transformer layers")
+        kept = [mods[str(i)] for i in range(L - n_keep, L)]
+        mods.clear()
+        for j, m in enumerate(kept):
+            mods[str(j)] = m
+        self.cfg = dataclasses.replace(self.cfg, layers=n_keep)
+        self._engine = self._engine_key = None
+        self._trainer_obj = self._trainer_key = None
+
     # -------------------------------------------------------------------------------------- engines
     def _cfgs(self):
         from vitlens_hip import engine as E

@@ -36,7 +36,8 @@ SIGNATURES = {
     "vl_split_bf16x3": [P, P, L, I, I, P],
     "vl_ce_stats": [P, L, I, I, I, P, P, P, P, P],
     "vl_ce_loss_accum": [P, P, P, I, I, I, F, F, P, P],
-    "vl_ce_grad": [P, L, I, I, I, P, P, F, F, P, L, P, L, F, P, P],
+    "vl_ce_grad": [P, L, I, I, I, P, P, F, F, P, L, P, L, F, P, P, P],
+    "vl_ce_grad_ws_floats": [I, I, L, L],
     "vl_gemm_bf16_ex": [P, P, P, P, P, P, I, I, I, I, I, I, F, I, I, I, I, P],
     "vl_fps": [P, P, P, P, I, I, I, P],
     "vl_knn_group": [P, P, P, P, I, I, I, I, I, P],
@@ -63,7 +64,7 @@ SIGNATURES = {
 
 
 # functions that do not return a status code
-_RET = {"vl_colreduce_ws_floats": L}
+_RET = {"vl_colreduce_ws_floats": L, "vl_ce_grad_ws_floats": L}
 
 
 def load_library():

@@ -267,8 +267,12 @@ def ce_grad(logits, row_lse, col_lse, label_off, w_row, w_col, logit_scale, dsca
     ldgt = (R + 63) // 64 * 64
     G = torch.empty(R, ldg, device=dev, dtype=torch.bfloat16) if need_g else None
     GT = torch.empty(Cc, ldgt, device=dev, dtype=torch.bfloat16) if need_gt else None
+    ws = None
+    if dscale is not None:
+        ws = torch.empty(int(_lib.vl_ce_grad_ws_floats(R, Cc, ldg if need_g else 0, ldgt if need_gt else 0)), device=dev,
+                         dtype=torch.float32)
     check(_lib.vl_ce_grad(_p(logits), logits.stride(0), R, Cc, label_off, _p(row_lse), _p(col_lse), float(w_row),
-                          float(w_col), _p(G), ldg, _p(GT), ldgt, float(logit_scale), _p(dscale), _stream()))
+                          float(w_col), _p(G), ldg, _p(GT), ldgt, float(logit_scale), _p(dscale), _p(ws), _stream()))
     return G, GT
 
 

@@ -130,26 +130,82 @@ class _StepState:
 
 
 # ------------------------------------------------------------------------------------------------ loss core
-def pair_forward(x, y, scale: float, label_off: int = 0, w_row: float = 0.5, w_col: float = 0.5):
-    """loss contribution w_row*CE(scale*x y^T) + w_col*CE(columns); returns (loss[1] tensor, ctx)."""
+# logits of this many elements or more are never materialised whole: the pair loss runs in row blocks (268 MB of f32)
+LOGITS_CHUNK_ELEMS = 1 << 26
+LOGITS_CHUNK_ROWS = 2048
+
+
+def _chunk_rows(R: int, Cn: int, chunk_rows: Optional[int]) -> int:
+    """Rows per block of the pair loss: 0 = whole matrix at once."""
+    if chunk_rows is None:
+        chunk_rows = LOGITS_CHUNK_ROWS if R * Cn >= LOGITS_CHUNK_ELEMS else 0
+    return 0 if chunk_rows <= 0 or chunk_rows >= R else int(chunk_rows)
+
+
+def pair_forward(x, y, scale: float, label_off: int = 0, w_row: float = 0.5, w_col: float = 0.5,
+                 chunk_rows: Optional[int] = None):
+    """loss contribution w_row*CE(scale*x y^T) + w_col*CE(columns); returns (loss[1] tensor, ctx).
+
+    Row-blocked mode (chunk_rows, or automatically for B_glob^2 above LOGITS_CHUNK_ELEMS): the B_glob x B_glob logits
+    are never held whole.  Forward = per block of rows: logits GEMM, exact row log-sum-exp, the block's column
+    log-sum-exp; the column statistics of the blocks are merged by one logsumexp over [blocks, C].  Backward
+    recomputes each block's logits (training/train.py:154-210 reaches batch 2048 by re-running the towers per
+    accumulation step; here only one thin GEMM is re-run)."""
+    R, Cn = x.shape[0], y.shape[0]
+    rb = _chunk_rows(R, Cn, chunk_rows)
     xb, yb = ops.split_bf16x3(x, 0), ops.split_bf16x3(y, 1)
-    logits = ops.logits_gemm(xb, yb, scale)
-    row_lse, col_lse, diag = ops.ce_stats(logits, label_off, want_cols=(w_col != 0.0))
+    if rb == 0:
+        logits = ops.logits_gemm(xb, yb, scale)
+        row_lse, col_lse, diag = ops.ce_stats(logits, label_off, want_cols=(w_col != 0.0))
+        loss = torch.zeros(1, device=x.device, dtype=torch.float32)
+        ops.ce_loss_accum(loss, row_lse if w_row != 0.0 else None, col_lse, diag, R, Cn, label_off, w_row, w_col)
+        return loss, (x, y, logits, row_lse, col_lse, label_off, w_row, w_col, scale, 0, None, None)
+    row_lse = torch.empty(R, device=x.device); diag = torch.empty(R, device=x.device)
+    col_parts = []
+    for r0 in range(0, R, rb):
+        r1 = min(R, r0 + rb)
+        lg = ops.logits_gemm(xb[r0:r1], yb, scale)
+        rl, cl, dg = ops.ce_stats(lg, label_off + r0, want_cols=(w_col != 0.0))
+        row_lse[r0:r1] = rl; diag[r0:r1] = dg
+        if cl is not None:
+            col_parts.append(cl)
+        del lg
+    col_lse = torch.logsumexp(torch.stack(col_parts), dim=0) if col_parts else None
     loss = torch.zeros(1, device=x.device, dtype=torch.float32)
-    ops.ce_loss_accum(loss, row_lse if w_row != 0.0 else None, col_lse, diag, x.shape[0], y.shape[0], label_off, w_row, w_col)
-    return loss, (x, y, logits, row_lse, col_lse, label_off, w_row, w_col, scale)
+    ops.ce_loss_accum(loss, row_lse if w_row != 0.0 else None, col_lse, diag, R, Cn, label_off, w_row, w_col)
+    return loss, (x, y, None, row_lse, col_lse, label_off, w_row, w_col, scale, rb, xb, yb)
 
 
 def pair_backward(ctx, g: float = 1.0, need_dx=True, need_dy=True):
-    x, y, logits, row_lse, col_lse, label_off, w_row, w_col, scale = ctx
+    x, y, logits, row_lse, col_lse, label_off, w_row, w_col, scale, rb, xb, yb = ctx
     dscale = torch.zeros(1, device=x.device, dtype=torch.float32)
-    G, GT = ops.ce_grad(logits, row_lse if w_row != 0.0 else None, col_lse, label_off, w_row * g, w_col * g, scale,
-                        dscale, need_g=need_dx, need_gt=need_dy)
-    dx = dy = None
-    if need_dx:
-        dx = ops.gemm(G, ops.transpose_to_bf16(y, ldo=G.shape[1]), None, epi=ops.EPI_F32, alpha=scale)
-    if need_dy:
-        dy = ops.gemm(GT, ops.transpose_to_bf16(x, ldo=GT.shape[1]), None, epi=ops.EPI_F32, alpha=scale)
+    if rb == 0:
+        G, GT = ops.ce_grad(logits, row_lse if w_row != 0.0 else None, col_lse, label_off, w_row * g, w_col * g, scale,
+                            dscale, need_g=need_dx, need_gt=need_dy)
+        dx = dy = None
+        if need_dx:
+            dx = ops.gemm(G, ops.transpose_to_bf16(y, ldo=G.shape[1]), None, epi=ops.EPI_F32, alpha=scale)
+        if need_dy:
+            dy = ops.gemm(GT, ops.transpose_to_bf16(x, ldo=GT.shape[1]), None, epi=ops.EPI_F32, alpha=scale)
+        return dx, dy, dscale
+    R, Cn = x.shape[0], y.shape[0]
+    dx = torch.empty(R, x.shape[1], device=x.device) if need_dx else None
+    dy = torch.zeros(Cn, y.shape[1], device=x.device) if need_dy else None
+    yt = None
+    for r0 in range(0, R, rb):
+        r1 = min(R, r0 + rb)
+        f = (r1 - r0) / R                      # the kernels average over the rows they are given: re-weight to the global mean
+        lg = ops.logits_gemm(xb[r0:r1], yb, scale)
+        G, GT = ops.ce_grad(lg, row_lse[r0:r1] if w_row != 0.0 else None, col_lse, label_off + r0, w_row * g * f, w_col * g * f,
+                            scale, dscale, need_g=need_dx, need_gt=need_dy)
+        if need_dx:
+            if yt is None:
+                yt = ops.transpose_to_bf16(y, ldo=G.shape[1])
+            ops.gemm(G, yt, None, out=dx[r0:r1], epi=ops.EPI_F32, alpha=scale)
+        if need_dy:
+            xt = ops.transpose_to_bf16(x[r0:r1].contiguous(), ldo=GT.shape[1])
+            ops.gemm(GT, xt, None, out=dy, res=dy, epi=ops.EPI_RES_F32, alpha=scale)       # dy += scale * G_b^T x_b
+        del lg, G, GT
     return dx, dy, dscale
 
 
