@@ -159,6 +159,44 @@ def test_reference_training_sequence_through_api(modality):
     assert torch.isfinite(loss2) and abs(float(loss2) - float(loss)) > 1e-6
 
 
+@pytest.mark.parametrize("groups,from_head", [(2, False), (1, False), (2, True)])
+def test_grouped_unlock_gradients(groups, from_head):
+    """LiT-style grouped unlock (VisionTransformer.lock, transformer.py:564-597: [stem] + blocks + [last block, ln_post] +
+    [proj], k groups from the tail - or from the head with unlock_from_head) + unlock_pos_emb: exactly the reference's
+    trainable set gets a .grad, equal to the reference autograd's gradient of the same step; everything locked stays
+    None (its dW GEMMs are not run)."""
+    oc = _oc()
+    sd, ins, outs, grads, meta = split(load_npz("tiny_depth.npz"))
+    a = dict(meta["args"]); a["unlock_from_head"] = from_head
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "tiny-lens.json"), "w") as f:
+            json.dump(meta["model_cfg"], f)
+        oc.add_model_config(td)
+        model = oc.tri_create_model("tiny-lens", None, precision="fp32", device="cuda", output_dict=True, args=SimpleNamespace(**a))
+    model.load_state_dict(sd, strict=False)
+    model.eval()
+    model.lock_image_tower(); model.lock_text_tower()
+    model.lock_visual_tower(unlocked_groups=groups, unlock_pos_emb=True)
+    L = meta["model_cfg"]["vision_cfg"]["layers"]
+    order = [("conv1.", "class_embedding", "positional_embedding", "ln_pre.")] + [(f"transformer.resblocks.{i}.",) for i in range(L - 1)]
+    order += [(f"transformer.resblocks.{L - 1}.", "ln_post."), ("proj",)]
+    picked = order[:groups] if from_head else order[-groups:]
+    want = {n for n, _ in model.visual.named_parameters()
+            if n.startswith(tuple(x for g in picked for x in g) + ("perceiver.", "visual_adapter.")) or n == "positional_embedding"}
+    assert {n for n, p in model.visual.named_parameters() if p.requires_grad} == want
+    largs = SimpleNamespace(local_loss=False, gather_with_grad=False, rank=0, world_size=1, horovod=False, n_tower=3,
+                            use_dual_loss=False, cache_dir=None)
+    loss = oc.create_loss(largs)(**model(image=ins["image"].cuda(), text=ins["text"].cuda(), visual_x=ins["visual_x"].cuda()))
+    loss.backward()
+    for n, p in model.visual.named_parameters():
+        if n in want:
+            ref = grads["visual." + n]
+            assert p.grad is not None, n
+            assert float((p.grad.float().cpu() - ref).norm() / (ref.norm() + 1e-30)) < 6e-2, n
+        else:
+            assert p.grad is None, n
+
+
 def test_forward_without_no_grad_refuses_an_untrainable_tower():
     """A tower whose parameters require grad but whose backward is not implemented must not silently produce graph-less
     features (round-1 finding): the text tower raises; under no_grad / after lock_text_tower it runs."""
