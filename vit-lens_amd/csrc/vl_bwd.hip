@@ -115,15 +115,29 @@ __global__ void __launch_bounds__(256) ln_bwd_params_kernel(const TDY* dy, long 
   ws[((long)blockIdx.y * 2) * D + j] = a; ws[((long)blockIdx.y * 2 + 1) * D + j] = b;
 }
 
-// out_k[j] += scale * sum_s ws[s][k][j]   (k < K planes), fixed summation order
-__global__ void __launch_bounds__(256) slab_finalize_kernel(const float* ws, int nslab, int K, int D, float scale, float* out0, float* out1) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= D) return;
-  for (int k = 0; k < K; ++k) {
-    float s = 0.f;
-    for (int t = 0; t < nslab; ++t) s += ws[((long)t * K + k) * D + j];
+// out_k[j] += scale * sum_s ws[s][k][j]   (k < K planes), fixed summation order.
+// One block = 64 columns of one plane x 16 slab groups: thread (j, g) adds the slabs s = g, g+16, ... in order, the 16
+// group sums are combined by a fixed tree through LDS.  (The first version gave every column ONE thread and the whole
+// grid 4 blocks: 514 dependent loads per thread, 120 us per call = 4 ms of the C3 step.)
+__global__ void __launch_bounds__(1024) slab_finalize_kernel(const float* ws, int nslab, int K, int D, float scale, float* out0, float* out1) {
+  __shared__ float sh[16][64];
+  const int jl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + jl, k = blockIdx.y;
+  float s = 0.f;
+  if (j < D)
+    for (int t = g; t < nslab; t += 16) s += ws[((long)t * K + k) * D + j];
+  sh[g][jl] = s;
+  __syncthreads();
+  if (g == 0 && j < D) {
+    float a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = sh[i][jl];
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+      for (int i = 0; i < w; ++i) a[i] += a[i + w];
     float* o = k == 0 ? out0 : out1;
-    o[j] += s * scale;
+    o[j] += a[0] * scale;
   }
 }
 
@@ -257,7 +271,7 @@ extern "C" int vl_layernorm_bwd_params(const void* dy, int dy_dtype, long dy_str
     hipLaunchKernelGGL((ln_bwd_params_kernel<float, float>), g, b, 0, stream, (const float*)dy, dy_stride, (const float*)x, x_stride, mean, rstd, ws, rows, D, slab);
   else
     hipLaunchKernelGGL((ln_bwd_params_kernel<float, bf16_t>), g, b, 0, stream, (const float*)dy, dy_stride, (const bf16_t*)x, x_stride, mean, rstd, ws, rows, D, slab);
-  hipLaunchKernelGGL(slab_finalize_kernel, dim3((D + 255) / 256), b, 0, stream, ws, nslab, 2, D, 1.0f, dw, db);
+  hipLaunchKernelGGL(slab_finalize_kernel, dim3((D + 63) / 64, 2), dim3(1024), 0, stream, ws, nslab, 2, D, 1.0f, dw, db);
   VL_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -269,7 +283,7 @@ extern "C" int vl_colsum(const void* a, int a_dtype, long lda, float* out, int r
   const dim3 g((cols + 255) / 256, nslab), b(256);
   if (a_dtype == VL_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, g, b, 0, stream, (const bf16_t*)a, lda, ws, rows, cols, slab);
   else hipLaunchKernelGGL(colsum_kernel<float>, g, b, 0, stream, (const float*)a, lda, ws, rows, cols, slab);
-  hipLaunchKernelGGL(slab_finalize_kernel, dim3((cols + 255) / 256), b, 0, stream, ws, nslab, 1, cols, scale, out, out);
+  hipLaunchKernelGGL(slab_finalize_kernel, dim3((cols + 63) / 64, 1), dim3(1024), 0, stream, ws, nslab, 1, cols, scale, out, out);
   VL_HIP_OK(hipGetLastError());
   return 0;
 }

@@ -22,7 +22,7 @@ BF = torch.bfloat16
 class _Saved:
     """Per-(B, L) activation store: residual-stream snapshots and attention operands of every block."""
 
-    def __init__(self, B, L, D, H, hidden, layers, device, res_dtype=torch.float32):
+    def __init__(self, B, L, D, H, hidden, layers, device, res_dtype=torch.float32, keep_blocks=()):
         dh = D // H
         T = B * L
         Lp = (L + 7) // 8 * 8
@@ -42,6 +42,10 @@ class _Saved:
         self.u = [bf(T, hidden) for _ in range(layers)]
         # temporaries shared by all blocks
         self.h = bf(T, D); self.hid = bf(T, hidden)
+        # trainable blocks keep their GEMM inputs (LN outputs, GELU output) for the weight gradients: 1.3 GB per block and
+        # micro-batch at b = 256 instead of two LayerNorm passes and one GELU pass in the backward (HBM is 288 GB)
+        self.h1 = {l: bf(T, D) for l in keep_blocks}; self.h2 = {l: bf(T, D) for l in keep_blocks}
+        self.hidk = {l: bf(T, hidden) for l in keep_blocks}
         self.xpre = f32(T, D); self.pre_stats = [f32(T), f32(T)]
         self.post_stats = [f32(B), f32(B)]
         self.pooled = bf(B, D)
@@ -76,7 +80,8 @@ class TowerTrainer:
     def saved(self, B, L):
         key = (B, L)
         if key not in self._saved:
-            self._saved[key] = _Saved(B, L, self.D, self.H, self.hidden, self.layers, self.eng.device, self.eng.res_dtype)
+            self._saved[key] = _Saved(B, L, self.D, self.H, self.hidden, self.layers, self.eng.device, self.eng.res_dtype,
+                                      keep_blocks=tuple(self.train_blocks))
         return self._saved[key]
 
     def grad_buffer(self, name, like):
@@ -104,13 +109,14 @@ class TowerTrainer:
                             xpre=S.xpre, mean=S.pre_stats[0], rstd=S.pre_stats[1])
         for l, w in enumerate(e.blocks):
             m1, r1, m2, r2 = S.stats[l]
-            ops.layernorm(S.X[2 * l], w["ln1_w"], w["ln1_b"], S.h, B * L, D, mean=m1, rstd=r1)
-            ops.gemm(S.h, w["in_w"], w["in_b"], out=S.qkv[l], epi=ops.EPI_BF16, cfg=cfg)
+            h1, h2, hid = S.h1.get(l, S.h), S.h2.get(l, S.h), S.hidk.get(l, S.hid)
+            ops.layernorm(S.X[2 * l], w["ln1_w"], w["ln1_b"], h1, B * L, D, mean=m1, rstd=r1)
+            ops.gemm(h1, w["in_w"], w["in_b"], out=S.qkv[l], epi=ops.EPI_BF16, cfg=cfg)
             ops.attn_fwd(S.q[l], S.k[l], S.v[l], S.a[l], lse=S.lse[l], qscale=dh ** -0.5 * ops.LOG2E)
             ops.gemm(S.a[l], w["out_w"], w["out_b"], out=S.X[2 * l + 1], res=S.X[2 * l], epi=res_epi, cfg=cfg)
-            ops.layernorm(S.X[2 * l + 1], w["ln2_w"], w["ln2_b"], S.h, B * L, D, mean=m2, rstd=r2)
-            ops.gemm(S.h, w["fc_w"], w["fc_b"], out=S.hid, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg, out2=S.u[l])
-            ops.gemm(S.hid, w["proj_w"], w["proj_b"], out=S.X[2 * l + 2], res=S.X[2 * l + 1], epi=res_epi, cfg=cfg)
+            ops.layernorm(S.X[2 * l + 1], w["ln2_w"], w["ln2_b"], h2, B * L, D, mean=m2, rstd=r2)
+            ops.gemm(h2, w["fc_w"], w["fc_b"], out=hid, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg, out2=S.u[l])
+            ops.gemm(hid, w["proj_w"], w["proj_b"], out=S.X[2 * l + 2], res=S.X[2 * l + 1], epi=res_epi, cfg=cfg)
         xl = S.X[2 * self.layers]
         ops.layernorm(xl, e.ln_post[0], e.ln_post[1], S.pooled, B, D, x_row_stride=L * D,
                       mean=S.post_stats[0], rstd=S.post_stats[1])
@@ -168,10 +174,8 @@ class TowerTrainer:
             # ---- MLP branch: x2 = x1 + proj(gelu(fc(ln2(x1)))) ----
             ops.gemm(S.dxb, wT["proj_w"], None, out=S.du, res=S.u[l], epi=ops.EPI_DGELU, cfg=cfg)       # du = (dx W_proj) * gelu'(u)
             if trainable:
-                ops.gelu_bf16(S.u[l], S.hid)
-                self._dw(bp + "mlp.c_proj.weight", S.dx, S.hid, rows, bp + "mlp.c_proj.bias")
-                ops.layernorm(S.X[2 * l + 1], w["ln2_w"], w["ln2_b"], S.h, rows, D)
-                self._dw(bp + "mlp.c_fc.weight", S.du, S.h, rows, bp + "mlp.c_fc.bias")
+                self._dw(bp + "mlp.c_proj.weight", S.dx, S.hidk[l], rows, bp + "mlp.c_proj.bias")
+                self._dw(bp + "mlp.c_fc.weight", S.du, S.h2[l], rows, bp + "mlp.c_fc.bias")
             ops.gemm(S.du, wT["fc_w"], None, out=S.dh, epi=ops.EPI_BF16, cfg=cfg)                           # dh2
             if trainable:
                 ops.layernorm_bwd_params(S.dh, S.X[2 * l + 1], m2, r2, self.grad_buffer(bp + "ln_2.weight", w["ln2_w"]),
@@ -184,8 +188,7 @@ class TowerTrainer:
             ops.attn_bwd(S.q[l], S.k[l], S.v[l], S.dO, S.av[l], S.lse[l], S.delta,
                          S.dqkv, S.dqkv[:, D:], S.dqkv[:, 2 * D:], 3 * D, 3 * D)
             if trainable:
-                ops.layernorm(S.X[2 * l], w["ln1_w"], w["ln1_b"], S.h, rows, D)
-                self._dw(bp + "attn.in_proj_weight", S.dqkv, S.h, rows, bp + "attn.in_proj_bias")
+                self._dw(bp + "attn.in_proj_weight", S.dqkv, S.h1[l], rows, bp + "attn.in_proj_bias")
             ops.gemm(S.dqkv, wT["in_w"], None, out=S.dh, epi=ops.EPI_BF16, cfg=cfg)                         # dh1
             if trainable:
                 ops.layernorm_bwd_params(S.dh, S.X[2 * l], m1, r1, self.grad_buffer(bp + "ln_1.weight", w["ln1_w"]),
