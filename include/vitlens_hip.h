@@ -87,7 +87,8 @@ int vl_device_info(int device, char* arch, int arch_len, int* cus, int* clock_kh
  * the packed in-projection output [tokens, 3*width], read in place.  q is multiplied by qscale (softmax_scale*log2e;
  * pass 1 for a pre-scaled q) as it is loaded; V is transposed while it is staged into LDS.
  * out [B,Lq,H*dh] bf16 (token-major, ready for the out-projection); lse [B,H,Lq] optional (natural-log LSE of the
- * scaled scores, kept for the backward pass).  dh in {32, 64}.
+ * scaled scores, kept for the backward pass).  dh = 32, 64, or a multiple of 8 in (64, 128] (ViT-H/14: 80, ViT-bigG/14:
+ * 104): those run zero-padded to 128 inside the kernel, only the real columns are read and written.
  * Replaces F.multi_head_attention_forward (transformer.py:241-252, causal mask :870-876) and
  * the Perceiver einsum attention (perceiver.py:128-145). */
 int vl_attn_fwd_bf16(const void* q, const void* k, const void* v, const long* strides, void* out, float* lse,

@@ -128,13 +128,15 @@ def _attn_reference(qf, kf, vf, causal):
 
 
 @pytest.mark.parametrize("B,L,H,dh", [(2, 257, 16, 64), (3, 77, 12, 64), (2, 17, 2, 32), (1, 600, 1, 64), (65, 257, 16, 64),
-                                      (2, 256, 8, 64), (2, 289, 4, 64), (3, 33, 2, 64), (2, 257, 4, 32), (1, 1, 2, 64)])
+                                      (2, 256, 8, 64), (2, 289, 4, 64), (3, 33, 2, 64), (2, 257, 4, 32), (1, 1, 2, 64),
+                                      (2, 257, 4, 104), (1, 257, 2, 80), (1, 600, 1, 128), (2, 50, 3, 72)])
 @pytest.mark.parametrize("causal", [False, True])
 def test_inproj_and_attention(B, L, H, dh, causal):
     """in_proj GEMM (packed [tokens, 3*width] output) + fused attention reading q / k / v out of it IN PLACE vs explicit
     softmax(QK^T/sqrt(d)+mask)V in fp32 on the same bf16-rounded operands.  P is rounded to bf16 before P.V
     (flash-attention practice) => abs err <= 2e-2*max|v|.  L = 257 / 33 take the shared-last-row path (8 waves + one
-    row), 289 the two-workgroup path, 600 the multi-chunk path."""
+    row), 289 the two-workgroup path, 600 the multi-chunk path; head dims 72..128 (ViT-H/14: 80, ViT-bigG/14: 104 -
+    model_configs/ViT-bigG-14.json) run zero-padded to 128 inside the kernels, reading and writing only the real columns."""
     ops = _ops()
     D = H * dh
     x = rnd(B * L, D, seed=9).bfloat16().cuda()

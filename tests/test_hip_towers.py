@@ -85,6 +85,22 @@ def test_vitl14_image_tower_vs_oracle(gemm_cfg, res_dtype):
     assert float((1 - torch.nn.functional.cosine_similarity(got.float().cpu(), ref, dim=-1)).max()) < 1e-3
 
 
+def test_head_dim_104_tower_vs_oracle():
+    """ViT-bigG/14 geometry per head (width = heads x 104, model_configs/ViT-bigG-14.json: width 1664, head_width 104) on a
+    narrower tower: 8 heads x 104 = width 832 (a multiple of the GEMMs' 64-wide k-step, like 1664), 2 blocks, 257 tokens -
+    the attention kernels' padded path inside a whole forward, against the oracle."""
+    E = _engine()
+    spec = O.TowerSpec(width=832, layers=2, heads=8, mlp_ratio=4.0, patch=14, image_size=224, embed_dim=64)
+    g = torch.Generator().manual_seed(31)
+    sd = O.init_tower(spec, g, "image.")
+    image = torch.randn(3, 3, 224, 224, generator=g)
+    ref = O.encode_image(sd, image, spec)
+    eng = E.VitEngine(sd, "image.", E.TowerCfg(width=832, layers=2, heads=8, patch=14, image_size=224, embed_dim=64), "cuda")
+    got = eng.encode_image(image.cuda())
+    assert relerr(got, ref) < 2e-2, relerr(got, ref)
+    assert float((1 - torch.nn.functional.cosine_similarity(got.float().cpu(), ref, dim=-1)).max()) < 1e-3
+
+
 def test_vitl_text_tower_vs_oracle():
     E = _engine()
     spec = O.TextSpec()

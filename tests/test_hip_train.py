@@ -88,7 +88,8 @@ def test_vitl_block_backward_vs_oracle_autograd():
 
 @pytest.mark.parametrize("B,L,H,dh,causal", [(2, 257, 4, 64, False), (2, 77, 3, 64, True), (1, 40, 2, 32, False),
                                              (2, 257, 2, 64, True), (1, 256, 2, 64, False), (1, 289, 2, 64, False),
-                                             (2, 33, 2, 32, False), (1, 600, 1, 64, False)])
+                                             (2, 33, 2, 32, False), (1, 600, 1, 64, False),
+                                             (2, 257, 2, 104, False), (1, 129, 2, 80, True), (1, 300, 1, 128, False)])
 def test_attention_backward(B, L, H, dh, causal):
     """dq / dk / dv (and the in-kernel delta) against autograd through explicit softmax attention on the same bf16 q, k, v,
     all operands read in place from token-major matrices.  257 / 33 = shared last query AND key row, 289 = two

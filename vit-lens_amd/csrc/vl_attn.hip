@@ -46,6 +46,7 @@ struct AttnP {
   bf16_t* out;   // [B, Lq, H*DH]
   float* lse;    // [B, H, Lq] (natural-log domain of the scaled scores) or null
   int B, H, Lq, Lk, causal;
+  int dh;        // real head dim (= DH, or 72..128 in the DH = 128 instantiation)
   VL_PROF_FIELD
   int lq_main;   // queries handled by the per-wave tiles (Lq, or Lq-1 when the last row is shared)
 };
@@ -53,10 +54,11 @@ struct AttnP {
 // MULTI: more keys than one LDS chunk (the chunk loop restages inside the accumulation; kept out of the common
 // single-chunk instantiations, where its 12 loads in flight would push the tile loop's registers to scratch)
 template <int DH, bool TAILQ, bool MULTI>
-__global__ void __launch_bounds__(NWMAX * 64, 4) attn_fwd_kernel(const AttnP p) {
+__global__ void __launch_bounds__(NWMAX * 64, DH == 128 ? 2 : 4) attn_fwd_kernel(const AttnP p) {
   constexpr int RB = DH * 2;          // K row bytes in LDS
   constexpr int CH = RB / 16;         // 16-byte chunks per row
-  constexpr int RSH = (DH == 64) ? 1 : 2;  // rows per 256-B bank row = 2^RSH
+  constexpr int RSH = Rsh<DH>::v;     // rows per 256-B bank row = 2^RSH
+  constexpr bool PAD = DH == 128;     // head dims 72..128 run zero-padded to 128
   constexpr int KS = DH / 16;         // MFMA k-steps for S
   constexpr int DT = DH / 32;         // 32-row tiles of O^T
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -81,6 +83,8 @@ __global__ void __launch_bounds__(NWMAX * 64, 4) attn_fwd_kernel(const AttnP p) 
   const bool wave_active = q0 < p.lq_main;
   int qrow = q0 + fr; if (qrow >= p.lq_main) qrow = p.lq_main - 1;
   const int qidx = q0 + fr;
+  const int dhr = PAD ? p.dh : DH;          // real head dim: output row stride and column count
+  const int nch = dhr >> 3;                 // valid 16-byte chunks of an operand row
 
   VL_PROF_STAMP(p, 0);
   // raw q fragments: loaded first, scaled only after the chunk is staged (the loads share one memory round trip)
@@ -88,14 +92,17 @@ __global__ void __launch_bounds__(NWMAX * 64, 4) attn_fwd_kernel(const AttnP p) 
   {
     const bf16_t* Qg = Qb + (long)qrow * p.q.sr;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qraw[ks] = *(const u32x4*)(Qg + ks * 16 + fg * 8);
+    for (int ks = 0; ks < KS; ++ks) {
+      qraw[ks] = u32x4{0u, 0u, 0u, 0u};
+      if (!PAD || ks * 2 + fg < nch) qraw[ks] = *(const u32x4*)(Qg + ks * 16 + fg * 8);
+    }
   }
   [[maybe_unused]] u32x4 tailraw = {0u, 0u, 0u, 0u};
   if constexpr (TAILQ) {
-    if (tid < CH) tailraw = *(const u32x4*)(Qb + (long)(p.Lq - 1) * p.q.sr + tid * 8);
+    if (tid < nch) tailraw = *(const u32x4*)(Qb + (long)(p.Lq - 1) * p.q.sr + tid * 8);
   }
   // first chunk: staged before the accumulators exist (12 x 16-byte loads in flight per thread need the registers)
-  stage2<DH, KC, true, false, false, true>(StageSrc{sK, nullptr, Kg, p.k.sr, 1.f}, StageSrc{nullptr, sV, Vg, p.v.sr, 1.f},
+  stage2<DH, KC, true, false, false, true>(StageSrc{sK, nullptr, Kg, p.k.sr, 1.f, nch}, StageSrc{nullptr, sV, Vg, p.v.sr, 1.f, nch},
                                            0, p.Lk, tid, nthr);
   if constexpr (TAILQ) {
     if (tid < CH) *(u32x4*)(sTailQ + tid * 8) = tailraw;
@@ -127,8 +134,8 @@ __global__ void __launch_bounds__(NWMAX * 64, 4) attn_fwd_kernel(const AttnP p) 
       if (kc0 > 0) {
         __syncthreads();
         // (one item per round here: the accumulators are live and 12 loads in flight would spill them)
-        stage2<DH, KC, true, false, false, true, 1>(StageSrc{sK, nullptr, Kg, p.k.sr, 1.f},
-                                                    StageSrc{nullptr, sV, Vg, p.v.sr, 1.f}, kc0, p.Lk, tid, nthr);
+        stage2<DH, KC, true, false, false, true, 1>(StageSrc{sK, nullptr, Kg, p.k.sr, 1.f, nch},
+                                                    StageSrc{nullptr, sV, Vg, p.v.sr, 1.f, nch}, kc0, p.Lk, tid, nthr);
       }
     }
     __syncthreads();
@@ -211,7 +218,7 @@ __global__ void __launch_bounds__(NWMAX * 64, 4) attn_fwd_kernel(const AttnP p) 
   if (wave_active) {
     const float l_tot = xhalf_sum(l2[0] + l2[1]);
     const float inv = 1.0f / l_tot;
-    store_rows_t<DT>(o, inv, p.out + ((size_t)b * p.Lq + qrow) * (p.H * DH) + h * DH, fg, qidx < p.lq_main);
+    store_rows_t<DT>(o, inv, p.out + ((size_t)b * p.Lq + qrow) * (p.H * dhr) + h * dhr, fg, qidx < p.lq_main, nch);
     if (p.lse && fg == 0 && qidx < p.lq_main)
       p.lse[bh * p.Lq + qidx] = (m_run + __log2f(l_tot)) * 0.6931471805599453f;
   }
@@ -282,18 +289,20 @@ __global__ void __launch_bounds__(NWMAX * 64, 4) attn_fwd_kernel(const AttnP p) 
       }
     }
     __syncthreads();
-    if (wid == 0 && lane < DH) {
+    if (wid == 0) {
       float M = -INFINITY;
       for (int kt = 0; kt < ntile; ++kt) M = fmaxf(M, sPart[kt * (2 + DH)]);
-      float L = 0.f, acc = 0.f;
-      for (int kt = 0; kt < ntile; ++kt) {
-        const float* part = sPart + kt * (2 + DH);
-        const float w = __builtin_amdgcn_exp2f(part[0] - M);
-        L = fmaf(part[1], w, L);
-        acc = fmaf(part[2 + lane], w, acc);
+      for (int d = lane; d < dhr; d += 64) {           // (one pass for head dims up to 64)
+        float L = 0.f, acc = 0.f;
+        for (int kt = 0; kt < ntile; ++kt) {
+          const float* part = sPart + kt * (2 + DH);
+          const float w = __builtin_amdgcn_exp2f(part[0] - M);
+          L = fmaf(part[1], w, L);
+          acc = fmaf(part[2 + d], w, acc);
+        }
+        p.out[((size_t)b * p.Lq + qT) * (p.H * dhr) + h * dhr + d] = f2bf(acc / L);
+        if (p.lse && d == 0) p.lse[bh * p.Lq + qT] = (M + __log2f(L)) * 0.6931471805599453f;
       }
-      p.out[((size_t)b * p.Lq + qT) * (p.H * DH) + h * DH + lane] = f2bf(acc / L);
-      if (p.lse && lane == 0) p.lse[bh * p.Lq + qT] = (M + __log2f(L)) * 0.6931471805599453f;
     }
   }
   VL_PROF_STAMP(p, 5);
@@ -318,13 +327,14 @@ static int launch_fwd(const AttnP& p, int gx, int nwq, hipStream_t stream) {
 extern "C" int vl_attn_fwd_bf16(const void* q, const void* k, const void* v, const long* strides, void* out, float* lse,
                                 int B, int H, int Lq, int Lk, int dh, float qscale, int causal, hipStream_t stream) {
   if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return vl_set_error("vl_attn_fwd_bf16: empty problem");
-  if (dh != 64 && dh != 32) return vl_set_error("vl_attn_fwd_bf16: head dim must be 32 or 64");
+  if (dh != 32 && dh != 64 && !(dh > 64 && dh <= 128 && (dh & 7) == 0))
+    return vl_set_error("vl_attn_fwd_bf16: head dim must be 32, 64, or a multiple of 8 in (64, 128] (run zero-padded to 128)");
   if (!strides) return vl_set_error("vl_attn_fwd_bf16: strides required");
   for (int i = 0; i < 9; ++i)
     if (strides[i] & 7) return vl_set_error("vl_attn_fwd_bf16: operand strides must be multiples of 8 elements (16-byte rows)");
   if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) return vl_set_error("vl_attn_fwd_bf16: operands must be 16-byte aligned");
   AttnP p{TV{(const bf16_t*)q, strides[0], strides[1], strides[2]}, TV{(const bf16_t*)k, strides[3], strides[4], strides[5]},
-          TV{(const bf16_t*)v, strides[6], strides[7], strides[8]}, qscale, (bf16_t*)out, lse, B, H, Lq, Lk, causal,
+          TV{(const bf16_t*)v, strides[6], strides[7], strides[8]}, qscale, (bf16_t*)out, lse, B, H, Lq, Lk, causal, dh,
 #ifdef VL_ATTN_PROF
           vl_attn_prof_buf,
 #endif
@@ -339,6 +349,6 @@ extern "C" int vl_attn_fwd_bf16(const void* q, const void* k, const void* v, con
 #define VL_FWD(DHV)                                                                  \
   (tailq ? launch_fwd<DHV, true, false>(p, gx, nwq, stream)                          \
          : (multi ? launch_fwd<DHV, false, true>(p, gx, nwq, stream) : launch_fwd<DHV, false, false>(p, gx, nwq, stream)))
-  return dh == 64 ? VL_FWD(64) : VL_FWD(32);
+  return dh == 64 ? VL_FWD(64) : (dh == 32 ? VL_FWD(32) : VL_FWD(128));
 #undef VL_FWD
 }

@@ -42,6 +42,7 @@ struct AttnBwdP {
   bf16_t *dq, *dk, *dv;     // token-major destinations (already offset to the q / k / v column block)
   long ld_dq, ld_dkv;       // row strides (elements) of the dq and dk/dv destinations
   int B, H, Lq, Lk, causal;
+  int dh;                   // real head dim (= DH, or 72..128 in the DH = 128 instantiation)
   float qscale;             // q is multiplied by this at load (softmax scale * log2 e)
   float scale;              // softmax scale (dq = scale * dS K ; dk = ln2 * dS^T Q2)
   VL_PROF_FIELD
@@ -76,8 +77,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 // (a memory round trip that is bandwidth-bound chip-wide: every workgroup asks for its 40 KB at once) overlaps the
 // other's MFMA work; measured against the single-chunk 1-workgroup-per-CU version (load + compute strictly serial).
 template <int DH, int NCA, bool TAILQ>
-__global__ void __launch_bounds__(NWMAX * 64, 4) attn_bwd_dq_kernel(const AttnBwdP p) {
+__global__ void __launch_bounds__(NWMAX * 64, DH == 128 ? 2 : 4) attn_bwd_dq_kernel(const AttnBwdP p) {
   constexpr int RB = DH * 2, KS = DH / 16, DT = DH / 32, TS = NCA + 8, CH = DH / 8;
+  constexpr bool PAD = DH == 128;                 // head dims 72..128 run zero-padded to 128
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
   unsigned char* sV = smem + NCA * RB;
@@ -100,6 +102,7 @@ __global__ void __launch_bounds__(NWMAX * 64, 4) attn_bwd_dq_kernel(const AttnBw
   const bool active = q0 < p.l_main;
   const int qidx = q0 + fr;
   const int qrow = qidx < p.l_main ? qidx : p.l_main - 1;
+  const int dhr = PAD ? p.dh : DH, nch = dhr >> 3;        // real head dim, valid 16-byte chunks per operand row
 
   VL_PROF_STAMP(p, 0);
   // one memory round trip for everything the workgroup needs first: the per-lane q / dO / O rows and the log-sum-exp
@@ -107,21 +110,25 @@ __global__ void __launch_bounds__(NWMAX * 64, 4) attn_bwd_dq_kernel(const AttnBw
   u32x4 qraw[KS], graw[KS], oraw[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    qraw[ks] = *(const u32x4*)(Qb + (long)qrow * p.q.sr + ks * 16 + fg * 8);
-    graw[ks] = *(const u32x4*)(Gb + (long)qrow * p.dO.sr + ks * 16 + fg * 8);
-    oraw[ks] = *(const u32x4*)(Ob + (long)qrow * p.o.sr + ks * 16 + fg * 8);
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    qraw[ks] = z; graw[ks] = z; oraw[ks] = z;
+    if (!PAD || ks * 2 + fg < nch) {
+      qraw[ks] = *(const u32x4*)(Qb + (long)qrow * p.q.sr + ks * 16 + fg * 8);
+      graw[ks] = *(const u32x4*)(Gb + (long)qrow * p.dO.sr + ks * 16 + fg * 8);
+      oraw[ks] = *(const u32x4*)(Ob + (long)qrow * p.o.sr + ks * 16 + fg * 8);
+    }
   }
   const float lse_raw = p.lse[bh * p.Lq + qrow];
   [[maybe_unused]] const float lse_tail = TAILQ ? p.lse[bh * p.Lq + p.Lq - 1] : 0.f;   // (uniform: a scalar load)
   [[maybe_unused]] u32x4 tailraw = {0u, 0u, 0u, 0u};
   if constexpr (TAILQ) {
-    if (tid < 3 * CH) {
+    if (tid < 3 * CH && tid % CH < nch) {
       const int m = tid / CH, c = tid % CH;
       const bf16_t* src = m == 0 ? Qb + (long)(p.Lq - 1) * p.q.sr : (m == 1 ? Gb + (long)(p.Lq - 1) * p.dO.sr : Ob + (long)(p.Lq - 1) * p.o.sr);
       tailraw = *(const u32x4*)(src + c * 8);
     }
   }
-  stage2<DH, NCA, true, true, true, false, 2>(StageSrc{sK, sKt, Kb, p.k.sr, 1.f}, StageSrc{sV, nullptr, Vb, p.v.sr, 1.f},
+  stage2<DH, NCA, true, true, true, false, 2>(StageSrc{sK, sKt, Kb, p.k.sr, 1.f, nch}, StageSrc{sV, nullptr, Vb, p.v.sr, 1.f, nch},
                                               0, p.Lk, tid, nthr);
   if constexpr (TAILQ) {
     if (tid < 3 * CH) *(u32x4*)(sTail + tid * 8) = tailraw;
@@ -155,7 +162,7 @@ __global__ void __launch_bounds__(NWMAX * 64, 4) attn_bwd_dq_kernel(const AttnBw
     if (kc0 > 0) {
       __syncthreads();
       // (fewer loads in flight here: the accumulators are live)
-      stage2<DH, NCA, true, true, true, false, 1>(StageSrc{sK, sKt, Kb, p.k.sr, 1.f}, StageSrc{sV, nullptr, Vb, p.v.sr, 1.f},
+      stage2<DH, NCA, true, true, true, false, 1>(StageSrc{sK, sKt, Kb, p.k.sr, 1.f, nch}, StageSrc{sV, nullptr, Vb, p.v.sr, 1.f, nch},
                                                   kc0, p.Lk, tid, nthr);
     }
     __syncthreads();
@@ -203,7 +210,9 @@ __global__ void __launch_bounds__(NWMAX * 64, 4) attn_bwd_dq_kernel(const AttnBw
       //      every key: host guarantees no causal cut) ----
       if (wid < ctile) {
         // delta of the row: lane d multiplies dO[d] * O[d], summed over the wave
-        const float dT = wave_sum_dpp(lane < DH ? bf2f(sTail[DH + lane]) * bf2f(sTail[2 * DH + lane]) : 0.f);
+        float dloc = 0.f;
+        for (int d = lane; d < DH; d += 64) dloc = fmaf(bf2f(sTail[DH + d]), bf2f(sTail[2 * DH + d]), dloc);
+        const float dT = wave_sum_dpp(dloc);
         if (kc0 == 0 && wid == 0 && lane == 0) p.delta[bh * p.Lq + p.Lq - 1] = dT;
         const float lT = lse_tail * LOG2E;
         float* myP = sP + wid * 32;
@@ -241,31 +250,38 @@ __global__ void __launch_bounds__(NWMAX * 64, 4) attn_bwd_dq_kernel(const AttnBw
   }
   VL_PROF_STAMP(p, 3);
   if (active)
-    store_rows_t<DT>(dq, p.scale, p.dq + ((size_t)b * p.Lq + qrow) * p.ld_dq + h * DH, fg, qidx < p.l_main);
+    store_rows_t<DT>(dq, p.scale, p.dq + ((size_t)b * p.Lq + qrow) * p.ld_dq + h * dhr, fg, qidx < p.l_main, nch);
   VL_PROF_STAMP(p, 4);
   if constexpr (TAILQ) {
     __syncthreads();
-    if (wid == 0 && lane < DH) {
-      float acc = 0.f;
-      for (int w = 0; w < nwq; ++w) acc += sPart[w * DH + lane];
-      p.dq[((size_t)b * p.Lq + p.Lq - 1) * p.ld_dq + h * DH + lane] = f2bf(acc * p.scale);
+    if (wid == 0) {
+      for (int d = lane; d < dhr; d += 64) {
+        float acc = 0.f;
+        for (int w = 0; w < nwq; ++w) acc += sPart[w * DH + d];
+        p.dq[((size_t)b * p.Lq + p.Lq - 1) * p.ld_dq + h * dhr + d] = f2bf(acc * p.scale);
+      }
     }
   }
   VL_PROF_STAMP(p, 5);
 }
 
 // ------------------------------------------------------------------------------------- kernel B: dK, dV
-template <int DH, bool TAILK>
+// NCB queries per LDS chunk (288 = the whole 257-token sequence; 96 for the padded 128-wide head dims, whose images are
+// twice as large).  The padded instantiation also walks its 4 output d-tiles in two passes of TPP = 2 (dK, dV, K, V for 128
+// columns would need 256 accumulator / operand registers): S and dP are recomputed per pass.
+template <int DH, int NCB, bool TAILK>
 __global__ void __launch_bounds__(NWMAX * 64, 2) attn_bwd_dkv_kernel(const AttnBwdP p) {
-  constexpr int RB = DH * 2, KS = DH / 16, DT = DH / 32, TS = NC + 8;
+  constexpr int RB = DH * 2, KS = DH / 16, DT = DH / 32, TS = NCB + 8;
+  constexpr bool PAD = DH == 128;
+  constexpr int TPP = PAD ? 2 : DT;              // output d-tiles per pass
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sQ = smem;
-  unsigned char* sdO = smem + NC * RB;
-  bf16_t* sQt = (bf16_t*)(smem + 2 * NC * RB);
+  unsigned char* sdO = smem + NCB * RB;
+  bf16_t* sQt = (bf16_t*)(smem + 2 * NCB * RB);
   bf16_t* sdOt = sQt + DH * TS;
   float* sNegL = (float*)(sdOt + DH * TS);        // -lse2 per query of the chunk (-inf on padded rows)
-  float* sNegD = sNegL + NC;                      // -delta                       (0 on padded rows)
-  float* sP = sNegD + NC;                         // [NWMAX][2][32]   (TAILK)
+  float* sNegD = sNegL + NCB;                      // -delta                       (0 on padded rows)
+  float* sP = sNegD + NCB;                         // [NWMAX][2][32]   (TAILK)
   float* sPart = sP + NWMAX * 64;                 // [NWMAX][2*DH]    (TAILK)
   bf16_t* sTail = (bf16_t*)(sPart + NWMAX * 2 * DH);   // [2][DH] the shared key's K and V rows, fetched up front (TAILK)
   constexpr int CH = DH / 8;
@@ -283,52 +299,59 @@ __global__ void __launch_bounds__(NWMAX * 64, 2) attn_bwd_dkv_kernel(const AttnB
   const bool active = k0 < p.l_main;
   const int kidx = k0 + fr;
   const int krow = kidx < p.l_main ? kidx : p.l_main - 1;
+  const int dhr = PAD ? p.dh : DH, nch = dhr >> 3;        // real head dim, valid 16-byte chunks per operand row
 
   VL_PROF_STAMP(p, 0);
   [[maybe_unused]] u32x4 tailraw = {0u, 0u, 0u, 0u};
   if constexpr (TAILK) {
-    if (tid < 2 * CH)
+    if (tid < 2 * CH && tid % CH < nch)
       tailraw = *(const u32x4*)((tid < CH ? Kb + (long)(p.Lk - 1) * p.k.sr : Vb + (long)(p.Lk - 1) * p.v.sr) + (tid % CH) * 8);
   }
   bf16x8 kf[KS], vf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    kf[ks] = load_frag(Kb + (long)krow * p.k.sr, ks, fg, 1.f);
-    vf[ks] = load_frag(Vb + (long)krow * p.v.sr, ks, fg, 1.f);
+    kf[ks] = zero_bf8(); vf[ks] = zero_bf8();
+    if (!PAD || ks * 2 + fg < nch) {
+      kf[ks] = load_frag(Kb + (long)krow * p.k.sr, ks, fg, 1.f);
+      vf[ks] = load_frag(Vb + (long)krow * p.v.sr, ks, fg, 1.f);
+    }
   }
-  f32x16 dk[DT], dv[DT];
+  const float ln2 = 0.6931471805599453f;
+#pragma unroll 1
+  for (int tp = 0; tp < DT; tp += TPP) {         // one pass for head dims up to 64
+  f32x16 dk[TPP], dv[TPP];
 #pragma unroll
-  for (int t = 0; t < DT; ++t) { dk[t] = zero16(); dv[t] = zero16(); }
-  [[maybe_unused]] float dkT[DT], dvT[DT];        // the shared last key's partial rows: slot 0 of per-tile MFMAs (TAILK)
+  for (int t = 0; t < TPP; ++t) { dk[t] = zero16(); dv[t] = zero16(); }
+  [[maybe_unused]] float dkT[TPP], dvT[TPP];      // the shared last key's partial rows: slot 0 of per-tile MFMAs (TAILK)
 #pragma unroll
-  for (int t = 0; t < DT; ++t) { dkT[t] = 0.f; dvT[t] = 0.f; }
+  for (int t = 0; t < TPP; ++t) { dkT[t] = 0.f; dvT[t] = 0.f; }
 
-  for (int qc0 = 0; qc0 < p.Lq; qc0 += NC) {
+  for (int qc0 = 0; qc0 < p.Lq; qc0 += NCB) {
     __syncthreads();
     // (log-sum-exp / delta of the chunk requested before the staging loads: one round trip)
-    float lraw[(NC + NWMAX * 64 - 1) / (NWMAX * 64)], draw[(NC + NWMAX * 64 - 1) / (NWMAX * 64)];
+    float lraw[(NCB + NWMAX * 64 - 1) / (NWMAX * 64)], draw[(NCB + NWMAX * 64 - 1) / (NWMAX * 64)];
     if (nthr == NWMAX * 64) {
 #pragma unroll
-      for (int j = 0; j < (NC + NWMAX * 64 - 1) / (NWMAX * 64); ++j) {
+      for (int j = 0; j < (NCB + NWMAX * 64 - 1) / (NWMAX * 64); ++j) {
         const int i = tid + j * NWMAX * 64;
-        const bool ok = i < NC && qc0 + i < p.Lq;
+        const bool ok = i < NCB && qc0 + i < p.Lq;
         lraw[j] = ok ? p.lse[bh * p.Lq + qc0 + i] : INFINITY;
         draw[j] = ok ? p.delta[bh * p.Lq + qc0 + i] : 0.f;
       }
     }
-    stage2<DH, NC, true, true, true, true>(StageSrc{sQ, sQt, Qb, p.q.sr, p.qscale}, StageSrc{sdO, sdOt, Gb, p.dO.sr, 1.f},
+    stage2<DH, NCB, true, true, true, true>(StageSrc{sQ, sQt, Qb, p.q.sr, p.qscale, nch}, StageSrc{sdO, sdOt, Gb, p.dO.sr, 1.f, nch},
                                            qc0, p.Lq, tid, nthr);
     if constexpr (TAILK) {
       if (qc0 == 0 && tid < 2 * CH) *(u32x4*)(sTail + tid * 8) = tailraw;
     }
     if (nthr == NWMAX * 64) {
 #pragma unroll
-      for (int j = 0; j < (NC + NWMAX * 64 - 1) / (NWMAX * 64); ++j) {
+      for (int j = 0; j < (NCB + NWMAX * 64 - 1) / (NWMAX * 64); ++j) {
         const int i = tid + j * NWMAX * 64;
-        if (i < NC) { sNegL[i] = -lraw[j] * LOG2E; sNegD[i] = -draw[j]; }
+        if (i < NCB) { sNegL[i] = -lraw[j] * LOG2E; sNegD[i] = -draw[j]; }
       }
     } else {
-      for (int i = tid; i < NC; i += nthr) {
+      for (int i = tid; i < NCB; i += nthr) {
         const bool ok = qc0 + i < p.Lq;
         sNegL[i] = ok ? -p.lse[bh * p.Lq + qc0 + i] * LOG2E : -INFINITY;
         sNegD[i] = ok ? -p.delta[bh * p.Lq + qc0 + i] : 0.f;
@@ -337,7 +360,7 @@ __global__ void __launch_bounds__(NWMAX * 64, 2) attn_bwd_dkv_kernel(const AttnB
     VL_PROF_STAMP(p, 1);
     __syncthreads();
     VL_PROF_STAMP(p, 2);
-    const int ntile = (min(p.Lq - qc0, NC) + 31) >> 5;
+    const int ntile = (min(p.Lq - qc0, NCB) + 31) >> 5;
     if (active) {
       int t0 = 0;
       if (p.causal) t0 = max(0, (k0 - qc0) >> 5);      // queries before this key tile never see it
@@ -356,14 +379,18 @@ __global__ void __launch_bounds__(NWMAX * 64, 2) attn_bwd_dkv_kernel(const AttnB
           s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(sQ, qt * 32 + fr, ks, fg), kf[ks], s, 0, 0, 0);
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(sdO, qt * 32 + fr, ks, fg), vf[ks], dp, 0, 0, 0);
         }
-        bf16x8 gtf[2][DT], qtf[2][DT];
+        // (fragments of the transposed images requested ahead of the exponentials - except in the padded instantiation,
+        //  which has no registers to hold them)
+        [[maybe_unused]] bf16x8 gtf[2][TPP], qtf[2][TPP];
+        if constexpr (!PAD) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+          for (int c = 0; c < 2; ++c)
 #pragma unroll
-          for (int t = 0; t < DT; ++t) {
-            gtf[c][t] = frag_t<NC>(sdOt, t * 32 + fr, qt, c, fg);
-            qtf[c][t] = frag_t<NC>(sQt, t * 32 + fr, qt, c, fg);
-          }
+            for (int t = 0; t < TPP; ++t) {
+              gtf[c][t] = frag_t<NCB>(sdOt, (tp + t) * 32 + fr, qt, c, fg);
+              qtf[c][t] = frag_t<NCB>(sQt, (tp + t) * 32 + fr, qt, c, fg);
+            }
+        }
         if (p.causal && qc0 + qt * 32 < k0 + 31) {      // diagonal tile: key > query is masked
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -378,9 +405,9 @@ __global__ void __launch_bounds__(NWMAX * 64, 2) attn_bwd_dkv_kernel(const AttnB
         for (int c = 0; c < 2; ++c) {
           const bf16x8 pf = pack8(pv + c * 8), df = pack8(ds + c * 8);
 #pragma unroll
-          for (int t = 0; t < DT; ++t) {
-            dv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gtf[c][t], pf, dv[t], 0, 0, 0);
-            dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[c][t], df, dk[t], 0, 0, 0);
+          for (int t = 0; t < TPP; ++t) {
+            dv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PAD ? frag_t<NCB>(sdOt, (tp + t) * 32 + fr, qt, c, fg) : gtf[c][t], pf, dv[t], 0, 0, 0);
+            dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PAD ? frag_t<NCB>(sQt, (tp + t) * 32 + fr, qt, c, fg) : qtf[c][t], df, dk[t], 0, 0, 0);
           }
         }
       }
@@ -390,64 +417,70 @@ __global__ void __launch_bounds__(NWMAX * 64, 2) attn_bwd_dkv_kernel(const AttnB
       // ---- the shared last key against query tile(s) wid, wid + 8, ... (lane = query) ----
       const int kT = p.Lk - 1;
       float* myP = sP + wid * 64;
-      bf16x8 ka[KS], va[KS];                        // A operands: row 0 = the key / value row, rows 1..31 zero
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        ka[ks] = zero_bf8(); va[ks] = zero_bf8();
-        if (fr == 0) {
-          ka[ks] = load_frag(sTail, ks, fg, 1.f);
-          va[ks] = load_frag(sTail + DH, ks, fg, 1.f);
-        }
-      }
       for (int qt = wid; qt < ntile; qt += nwk) {
         if (p.causal && qc0 + qt * 32 + 31 < kT) continue;
-        f32x16 st = zero16(), dpt = zero16();
+        // A operands: row 0 = the key / value row (lanes fr == 0), rows 1..31 zero; S then dP through one accumulator
+        f32x16 acc = zero16();
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], frag_rows<DH>(sQ, qt * 32 + fr, ks, fg), st, 0, 0, 0);
-          dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[ks], frag_rows<DH>(sdO, qt * 32 + fr, ks, fg), dpt, 0, 0, 0);
-        }
+        for (int ks = 0; ks < KS; ++ks)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr == 0 ? load_frag(sTail, ks, fg, 1.f) : zero_bf8(),
+                                                        frag_rows<DH>(sQ, qt * 32 + fr, ks, fg), acc, 0, 0, 0);
+        const float s0 = acc[0];
+        acc = zero16();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr == 0 ? load_frag(sTail + DH, ks, fg, 1.f) : zero_bf8(),
+                                                        frag_rows<DH>(sdO, qt * 32 + fr, ks, fg), acc, 0, 0, 0);
+        const float dp0 = acc[0];
         float pT = 0.f, dsT = 0.f;
         if (fg == 0 && !(p.causal && qc0 + qt * 32 + fr < kT)) {
-          pT = __builtin_amdgcn_exp2f(st[0] + sNegL[qt * 32 + fr]);      // padded rows: -inf -> 0
-          dsT = pT * (dpt[0] + sNegD[qt * 32 + fr]);
+          pT = __builtin_amdgcn_exp2f(s0 + sNegL[qt * 32 + fr]);         // padded rows: -inf -> 0
+          dsT = pT * (dp0 + sNegD[qt * 32 + fr]);
         }
         wave_lds_sync();
         if (fg == 0) { myP[fr] = pT; myP[32 + fr] = dsT; }
         wave_lds_sync();
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const bf16x8 pa = gather_row0(myP, c, fr, fg), da = gather_row0(myP + 32, c, fr, fg);
+        for (int t = 0; t < TPP; ++t) {
+          acc = zero16();
 #pragma unroll
-          for (int t = 0; t < DT; ++t) {
-            dvT[t] += __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_t<NC>(sdOt, t * 32 + fr, qt, c, fg), zero16(), 0, 0, 0)[0];
-            dkT[t] += __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, frag_t<NC>(sQt, t * 32 + fr, qt, c, fg), zero16(), 0, 0, 0)[0];
-          }
+          for (int c = 0; c < 2; ++c)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gather_row0(myP, c, fr, fg), frag_t<NCB>(sdOt, (tp + t) * 32 + fr, qt, c, fg), acc, 0, 0, 0);
+          dvT[t] += acc[0];
+          acc = zero16();
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gather_row0(myP + 32, c, fr, fg), frag_t<NCB>(sQt, (tp + t) * 32 + fr, qt, c, fg), acc, 0, 0, 0);
+          dkT[t] += acc[0];
         }
       }
     }
   }
   VL_PROF_STAMP(p, 4);
-  const float ln2 = 0.6931471805599453f;
   if (active) {
-    store_rows_t<DT>(dk, ln2, p.dk + ((size_t)b * p.Lk + krow) * p.ld_dkv + h * DH, fg, kidx < p.l_main);
-    store_rows_t<DT>(dv, 1.f, p.dv + ((size_t)b * p.Lk + krow) * p.ld_dkv + h * DH, fg, kidx < p.l_main);
+    store_rows_t<TPP>(dk, ln2, p.dk + ((size_t)b * p.Lk + krow) * p.ld_dkv + h * dhr + tp * 32, fg, kidx < p.l_main, nch - tp * 4);
+    store_rows_t<TPP>(dv, 1.f, p.dv + ((size_t)b * p.Lk + krow) * p.ld_dkv + h * dhr + tp * 32, fg, kidx < p.l_main, nch - tp * 4);
   }
   if constexpr (TAILK) {
     if (fg == 0) {
 #pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        sPart[wid * 2 * DH + t * 32 + fr] = dvT[t];
-        sPart[wid * 2 * DH + DH + t * 32 + fr] = dkT[t];
+      for (int t = 0; t < TPP; ++t) {
+        sPart[wid * 2 * DH + (tp + t) * 32 + fr] = dvT[t];
+        sPart[wid * 2 * DH + DH + (tp + t) * 32 + fr] = dkT[t];
       }
     }
+  }
+  }   // passes over the output d-tiles
+  if constexpr (TAILK) {
     __syncthreads();
-    if (wid == 0 && lane < DH) {
-      float av = 0.f, ak = 0.f;
-      for (int w = 0; w < nwk; ++w) { av += sPart[w * 2 * DH + lane]; ak += sPart[w * 2 * DH + DH + lane]; }
-      const size_t row = ((size_t)b * p.Lk + p.Lk - 1) * p.ld_dkv + h * DH + lane;
-      p.dv[row] = f2bf(av);
-      p.dk[row] = f2bf(ak * ln2);
+    if (wid == 0) {
+      for (int d = lane; d < dhr; d += 64) {
+        float av = 0.f, ak = 0.f;
+        for (int w = 0; w < nwk; ++w) { av += sPart[w * 2 * DH + d]; ak += sPart[w * 2 * DH + DH + d]; }
+        const size_t row = ((size_t)b * p.Lk + p.Lk - 1) * p.ld_dkv + h * dhr + d;
+        p.dv[row] = f2bf(av);
+        p.dk[row] = f2bf(ak * ln2);
+      }
     }
   }
   VL_PROF_STAMP(p, 5);
@@ -459,13 +492,14 @@ extern "C" int vl_set_error(const char* msg);
 
 template <int DH, bool TQ, bool TK>
 static int launch_bwd(const AttnBwdP& pin, int lq_main, int lk_main, hipStream_t stream) {
+  constexpr int NCB = DH == 128 ? 96 : NC;
   const size_t smA = (size_t)2 * NCA * DH * 2 + (size_t)DH * (NCA + 8) * 2 + (size_t)NWMAX * 32 * 4 + (size_t)NWMAX * DH * 4 +
                      (size_t)3 * DH * 2;
-  const size_t smB = (size_t)2 * NC * DH * 2 + (size_t)2 * DH * (NC + 8) * 2 + (size_t)2 * NC * 4 + (size_t)NWMAX * 64 * 4 +
+  const size_t smB = (size_t)2 * NCB * DH * 2 + (size_t)2 * DH * (NCB + 8) * 2 + (size_t)2 * NCB * 4 + (size_t)NWMAX * 64 * 4 +
                      (size_t)NWMAX * 2 * DH * 4 + (size_t)2 * DH * 2;
   static const hipError_t attrA = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DH, NCA, TQ>,
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smA);
-  static const hipError_t attrB = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DH, TK>,
+  static const hipError_t attrB = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DH, NCB, TK>,
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smB);
   if (attrA != hipSuccess) return vl_set_error(hipGetErrorString(attrA));
   if (attrB != hipSuccess) return vl_set_error(hipGetErrorString(attrB));
@@ -478,7 +512,7 @@ static int launch_bwd(const AttnBwdP& pin, int lq_main, int lk_main, hipStream_t
 #ifdef VL_ATTN_PROF
   if (p.prof) p.prof += (size_t)p.B * p.H * ((qtiles + nwq - 1) / nwq) * 8;     // kernel B's stamps follow kernel A's
 #endif
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, TK>), dim3((ktiles + nwk - 1) / nwk, p.H, p.B), dim3(nwk * 64), smB, stream, p);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, NCB, TK>), dim3((ktiles + nwk - 1) / nwk, p.H, p.B), dim3(nwk * 64), smB, stream, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : vl_set_error(hipGetErrorString(e));
 }
@@ -488,7 +522,8 @@ extern "C" int vl_attn_bwd_bf16(const void* q, const void* k, const void* v, con
                                 long ld_dq, long ld_dkv, int B, int H, int Lq, int Lk, int dh, float qscale, int causal,
                                 float scale, hipStream_t stream) {
   if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return vl_set_error("vl_attn_bwd_bf16: empty problem");
-  if (dh != 64 && dh != 32) return vl_set_error("vl_attn_bwd_bf16: head dim must be 32 or 64");
+  if (dh != 32 && dh != 64 && !(dh > 64 && dh <= 128 && (dh & 7) == 0))
+    return vl_set_error("vl_attn_bwd_bf16: head dim must be 32, 64, or a multiple of 8 in (64, 128] (run zero-padded to 128)");
   if (!strides || !delta || !lse) return vl_set_error("vl_attn_bwd_bf16: strides, lse and the delta workspace are required");
   for (int i = 0; i < 15; ++i)
     if (strides[i] & 7) return vl_set_error("vl_attn_bwd_bf16: operand strides must be multiples of 8 elements (16-byte rows)");
@@ -500,18 +535,18 @@ extern "C" int vl_attn_bwd_bf16(const void* q, const void* k, const void* v, con
   AttnBwdP p{TV{(const bf16_t*)q, s[0], s[1], s[2]},   TV{(const bf16_t*)k, s[3], s[4], s[5]},
              TV{(const bf16_t*)v, s[6], s[7], s[8]},   TV{(const bf16_t*)dO, s[9], s[10], s[11]},
              TV{(const bf16_t*)o, s[12], s[13], s[14]}, lse, delta, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv,
-             ld_dq, ld_dkv, B, H, Lq, Lk, causal, qscale, scale,
+             ld_dq, ld_dkv, B, H, Lq, Lk, causal, dh, qscale, scale,
 #ifdef VL_ATTN_PROF
              vl_attn_prof_buf,
 #endif
              0};
   // one row beyond whole tiles (257 tokens): shared by the 8 waves of the single workgroup instead of a ninth wave
   const bool tq = (Lq % 32 == 1) && Lq > 32 && Lq - 1 <= NWMAX * 32 && (!causal || Lk <= Lq);
-  const bool tk = (Lk % 32 == 1) && Lk > 32 && Lk - 1 <= NWMAX * 32 && Lq <= NC;
+  const bool tk = (Lk % 32 == 1) && Lk > 32 && Lk - 1 <= NWMAX * 32;      // (the query chunks are walked inside the kernel)
   const int lqm = tq ? Lq - 1 : Lq, lkm = tk ? Lk - 1 : Lk;
 #define VL_BWD(DHV)                                                                       \
   (tq ? (tk ? launch_bwd<DHV, true, true>(p, lqm, lkm, stream) : launch_bwd<DHV, true, false>(p, lqm, lkm, stream)) \
       : (tk ? launch_bwd<DHV, false, true>(p, lqm, lkm, stream) : launch_bwd<DHV, false, false>(p, lqm, lkm, stream)))
-  return dh == 64 ? VL_BWD(64) : VL_BWD(32);
+  return dh == 64 ? VL_BWD(64) : (dh == 32 ? VL_BWD(32) : VL_BWD(128));
 #undef VL_BWD
 }

@@ -58,11 +58,15 @@ struct StageSrc {
   const bf16_t* src;
   long sr;
   float scale;           // applied while copying when != 1 (q is scaled by softmax_scale*log2e)
+  int nch = 0;           // padded head dims (DH = 128 instantiation, real dim 72..128): valid 16-byte chunks per row
 };
+
+// rows per 256-byte LDS bank row = 2^RSH (the XOR swizzle of the row image is keyed by row >> RSH)
+template <int DH> struct Rsh { static constexpr int v = DH == 32 ? 2 : (DH == 64 ? 1 : 0); };
 
 template <int DH, int NR, bool ROWS, bool TRANS>
 __device__ __forceinline__ void stage_write(const StageSrc& m, int i, u32x4 a, u32x4 bq) {
-  constexpr int RB = DH * 2, CH = RB / 16, RSH = (DH == 64) ? 1 : 2, TS = NR + 8;
+  constexpr int RB = DH * 2, CH = RB / 16, RSH = Rsh<DH>::v, TS = NR + 8;
   const int rp = i / CH, c = i % CH;
   const int rl = 2 * rp;
   if (m.scale != 1.0f) { a = scale_bf16x8(a, m.scale); bq = scale_bf16x8(bq, m.scale); }
@@ -94,11 +98,12 @@ __device__ __forceinline__ void stage2(const StageSrc& m0, const StageSrc& m1, i
       a0[u] = z; b0[u] = z; a1[u] = z; b1[u] = z;
       // 32-bit byte offsets from the uniform base pointers: global_load ... saddr + voffset, one VGPR per address
       const unsigned o0 = ((unsigned)row * (unsigned)m0.sr + c * 8) * 2u, o1 = ((unsigned)row * (unsigned)m1.sr + c * 8) * 2u;
-      if (i < NP && row < L) {
+      const bool cok = DH != 128 || c < m0.nch;        // padded head dim: chunks beyond the real row stay zero
+      if (i < NP && row < L && cok) {
         a0[u] = *(const u32x4*)((const unsigned char*)m0.src + o0);
         a1[u] = *(const u32x4*)((const unsigned char*)m1.src + o1);
       }
-      if (i < NP && row + 1 < L) {
+      if (i < NP && row + 1 < L && cok) {
         b0[u] = *(const u32x4*)((const unsigned char*)m0.src + (o0 + (unsigned)m0.sr * 2u));
         b1[u] = *(const u32x4*)((const unsigned char*)m1.src + (o1 + (unsigned)m1.sr * 2u));
       }
@@ -150,8 +155,9 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 // token-major matrix.  A lane owns 4-element d groups alternating with its partner (fg ^ 1); one v_permlane32_swap per
 // dword gives every lane whole 8-element (16-byte) pieces: 4 stores of 16 bytes instead of 16 of 8 (the forward spent
 // 50 of 222 us in its 8-byte epilogue stores).  dst = the row of lane fr (d = 0); `valid` masks padded rows.
+// npiece: number of valid 16-byte pieces per row (padded head dims store only the real columns)
 template <int DT>
-__device__ __forceinline__ void store_rows_t(const f32x16* acc, float mul, bf16_t* dst, int fg, bool valid) {
+__device__ __forceinline__ void store_rows_t(const f32x16* acc, float mul, bf16_t* dst, int fg, bool valid, int npiece = 4 * DT) {
 #pragma unroll
   for (int t = 0; t < DT; ++t)
 #pragma unroll
@@ -166,14 +172,14 @@ __device__ __forceinline__ void store_rows_t(const f32x16* acc, float mul, bf16_
       auto r1 = __builtin_amdgcn_permlane32_swap(ev[1], od[1], false, false);
       const unsigned w0 = r0[0], w1 = r1[0], w2 = r0[1], w3 = r1[1];
       const u32x4 w = {w0, w1, w2, w3};
-      if (valid) *(u32x4*)(dst + t * 32 + (2 * pp + fg) * 8) = w;
+      if (valid && t * 4 + 2 * pp + fg < npiece) *(u32x4*)(dst + t * 32 + (2 * pp + fg) * 8) = w;
     }
 }
 
 // fragment of the row image: row `row`, d-slice (ks, fg) -> 8 consecutive d
 template <int DH>
 __device__ __forceinline__ bf16x8 frag_rows(const unsigned char* base, int row, int ks, int fg) {
-  constexpr int RB = DH * 2, CH = RB / 16, RSH = (DH == 64) ? 1 : 2;
+  constexpr int RB = DH * 2, CH = RB / 16, RSH = Rsh<DH>::v;
   return *(const bf16x8*)(base + row * RB + (((ks * 2 + fg) ^ ((row >> RSH) & (CH - 1))) * 16));
 }
 // fragment of the T image: d = `d`, rows of tile `tile`, slice c, half fg (already in accumulator order)
