@@ -16,12 +16,17 @@
 //   outputs: dq -> dQKV[(b*Lq+q), 0*D + h*dh + d], dk -> [.., 1*D ..], dv -> [.., 2*D ..]  (token-major, bf16);
 //            delta [B,H,Lq] fp32 is produced by kernel A and consumed by kernel B (same stream).
 //
-// VALU trimming (the kernels were VALU/latency bound, MFMA 18-25 % busy): -lse2 and -delta enter as the C operands of the
-// S and dP MFMAs (register blocks in A; four ds_read_b128 per tile from LDS in B, where padded query rows carry -inf /
-// 0 and need no masking), so the elementwise work per 32x32 tile is 16 exp2, 16 multiplies and the bf16 packing.
+// VALU trimming (the round-1 kernels were VALU/latency bound, MFMA 18-25 % busy): in B, -lse2 and -delta enter as the C
+// operands of the S and dP MFMAs (four ds_read_b128 per tile from LDS; padded query rows carry -inf / 0 and need no
+// masking), so the elementwise work per 32x32 tile is 16 exp2, 16 multiplies and the bf16 packing.  A sits at the
+// 128-register cap of its two-workgroups-per-CU layout and has no room for the two constant C blocks: it subtracts
+// lse2 / delta with packed fp32 operations (v_pk_add_f32 / v_pk_mul_f32, two elements per instruction).
+//
+// Head dims 72..128 (ViT-H/14: 80, ViT-bigG/14: 104) run in DH = 128 instantiations, zero-padded inside LDS / registers;
+// only the real columns are read and written.  B then walks its four output d-tiles in two passes (S, dP recomputed).
 //
 // L = 257 (8 whole tiles + one row): the lone last query (A) / key (B) is not given a ninth wave; the 8 waves share it
-// after their own tiles - wave w takes tile w with the MFMA operand roles swapped (the lone row is row 0 of the A
+// alongside their own tiles - wave w takes tile w with the MFMA operand roles swapped (the lone row is row 0 of the A
 // operand), pushes p / dS through a 128-byte LDS scratch to make them an A operand, and the per-wave partial dQ (or
 // dK, dV) rows are summed in a fixed order through LDS.
 #include "vl_attn_common.h"
