@@ -42,6 +42,11 @@ def tiny_args(modality):
                                     pc_trans_dim=64, pc_npoints=256, perceiver_input_chan=64,
                                     perceiver_depth=2, perceiver_self_per_cross_attn=1,
                                     pc_tokenizer="pointbert", pc_in_channel=3, pc_radius=0.2, **common)
+    if modality == "tactile":       # no Lens: the visual tower is a second trainable ViT with its own patch embedding
+        return ref_loader.lens_args("tactile")
+    if modality == "eeg":
+        return ref_loader.lens_args("eeg", eeg_chans=8, eeg_time_len=40, eeg_window_size=3, eeg_stride=2,
+                                    perceiver_input_chan=64, perceiver_depth=1, perceiver_self_per_cross_attn=1, **common)
     raise ValueError(modality)
 
 
@@ -75,8 +80,12 @@ def tiny_case(oc, modality, seed):
     extra = {}
     if modality == "depth":
         vx = torch.randn(B, 1, 32, 32, generator=g)
+    elif modality == "tactile":
+        vx = torch.randn(B, 3, 32, 32, generator=g)
     elif modality == "audio":
         vx = torch.randn(B, 48, 32, generator=g)
+    elif modality == "eeg":
+        vx = torch.randn(B, 8, 40, generator=g)
     else:
         vx = torch.rand(B, 256, 3, generator=g) * 2 - 1
         # reproduce the reference's internal torch.randint start (misc.py:60)
@@ -297,6 +306,13 @@ def pc_bn_train_case(oc, seed):
 def main():
     os.makedirs(OUT, exist_ok=True)
     oc = ref_loader.load()
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":      # e.g. `--only eeg 23`: add one case without touching the others
+        with tempfile.TemporaryDirectory() as td:
+            with open(os.path.join(td, "tiny-lens.json"), "w") as f:
+                json.dump(TINY, f)
+            oc.add_model_config(td)
+            tiny_case(oc, sys.argv[2], seed=int(sys.argv[3]))
+        return
     with tempfile.TemporaryDirectory() as td:
         with open(os.path.join(td, "tiny-lens.json"), "w") as f:
             json.dump(TINY, f)

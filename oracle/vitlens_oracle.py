@@ -53,7 +53,7 @@ class TextSpec:
 class LensSpec:
     """What sits in front of the frozen ViT for a non-image modality
     (mm_vit_lens/model_cfg.py:80-178, module_cfg.py:37-92)."""
-    modality: str = "depth"            # depth | audio | pc | image
+    modality: str = "depth"            # depth | audio | pc | eeg | image
     perceiver_identity: bool = True    # perceiver.py:370-371
     depth: int = 2                     # perceiver_depth
     self_per_cross: int = 3
@@ -69,6 +69,11 @@ class LensSpec:
     audio_tstride: int = 10
     audio_mel_bins: int = 128
     audio_target_length: int = 512
+    # EEG (modal_eeg/models/EEG_tokenizer.py: PatchEmbed1D)
+    eeg_chans: int = 128
+    eeg_time_len: int = 512
+    eeg_window_size: int = 1
+    eeg_stride: int = 1
     # point cloud (pointbert)
     pc_num_group: int = 512
     pc_group_size: int = 32
@@ -321,6 +326,14 @@ def encode_image(sd: SD, image: Tensor, spec: TowerSpec, normalize: bool = False
     return l2_normalize(f) if normalize else f
 
 
+def eeg_tokens(sd: SD, prefix: str, x: Tensor, lens: LensSpec):
+    """PatchEmbed1D.forward (modal_eeg/models/EEG_tokenizer.py:35-42): Conv1d(chans -> width, kernel = window, stride,
+    WITH bias) over the time axis of x [N, chans, time], transposed to tokens [N, T', width]; pos_emb [T', width]."""
+    a = prefix + "visual_adapter."
+    t = torch.nn.functional.conv1d(x, sd[a + "proj.weight"], sd[a + "proj.bias"], stride=lens.eeg_stride)
+    return t.transpose(1, 2).contiguous(), sd[a + "pos_emb"]
+
+
 def encode_visual(sd: SD, x: Tensor, spec: TowerSpec, lens: LensSpec, normalize: bool = False,
                   prefix: str = "visual.", fps_start: Optional[Tensor] = None,
                   training: bool = False, running_out: Optional[Dict[str, Tensor]] = None) -> Tensor:
@@ -334,6 +347,8 @@ def encode_visual(sd: SD, x: Tensor, spec: TowerSpec, lens: LensSpec, normalize:
             t, pos = audio_tokens(sd, prefix, x, lens)
         elif lens.modality == "pc":
             t, pos, _, _ = point_tokens(sd, prefix, x, lens, fps_start, training, running_out)
+        elif lens.modality == "eeg":
+            t, pos = eeg_tokens(sd, prefix, x, lens)
         else:
             raise NotImplementedError(lens.modality)
         tok = t + (0 * pos if lens.disable_adapter_pos else pos)
@@ -492,6 +507,11 @@ def init_lens(spec: TowerSpec, lens: LensSpec, gen: torch.Generator, prefix: str
         td = (lens.audio_target_length - spec.patch) // lens.audio_tstride + 1
         sd[a + "conv1.weight"] = uni(D, 1, spec.patch, spec.patch, bound=1.0 / spec.patch)
         sd[a + "pos_emb"] = rn(fd * td, D, std=D ** -0.5)
+    elif lens.modality == "eeg":
+        fan = lens.eeg_chans * lens.eeg_window_size
+        sd[a + "proj.weight"] = uni(D, lens.eeg_chans, lens.eeg_window_size, bound=fan ** -0.5)
+        sd[a + "proj.bias"] = uni(D, bound=fan ** -0.5)
+        sd[a + "pos_emb"] = rn((lens.eeg_time_len - lens.eeg_window_size) // lens.eeg_stride + 1, D, std=D ** -0.5)
     elif lens.modality == "pc":
         E, Tr = lens.pc_encoder_dims, lens.pc_trans_dim
         def lin(name, o, i, conv=False):

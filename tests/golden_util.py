@@ -31,7 +31,7 @@ def specs_from_meta(meta):
                         patch=v["patch_size"], image_size=v["image_size"], embed_dim=cfg["embed_dim"])
     text = O.TextSpec(context_length=t["context_length"], vocab_size=t["vocab_size"], width=t["width"],
                       heads=t["heads"], layers=t["layers"], embed_dim=cfg["embed_dim"])
-    mod = {"3dpc": "pc"}.get(a["visual_modality_type"], a["visual_modality_type"])
+    mod = {"3dpc": "pc", "tactile": "image"}.get(a["visual_modality_type"], a["visual_modality_type"])
     lens = O.LensSpec(
         modality=mod, perceiver_identity=bool(a.get("perceiver_as_identity", False)),
         depth=a["perceiver_depth"], self_per_cross=a["perceiver_self_per_cross_attn"],
@@ -41,6 +41,8 @@ def specs_from_meta(meta):
         latent_dim_head=a["perceiver_latent_dim_head"],
         audio_fstride=a.get("audio_fstride", 10), audio_tstride=a.get("audio_tstride", 10),
         audio_mel_bins=a.get("audio_mel_bins", 128), audio_target_length=a.get("audio_target_length", 512),
+        eeg_chans=a.get("eeg_chans", 128), eeg_time_len=a.get("eeg_time_len", 512),
+        eeg_window_size=a.get("eeg_window_size", 1), eeg_stride=a.get("eeg_stride", 1),
         pc_num_group=a.get("pc_num_group", 512), pc_group_size=a.get("pc_group_size", 32),
         pc_encoder_dims=a.get("pc_encoder_dims", 256), pc_trans_dim=a.get("pc_trans_dim", 384),
         use_orig_pos=not a.get("disable_orig_pos", False),

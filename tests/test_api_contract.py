@@ -22,7 +22,7 @@ out = {}
 with tempfile.TemporaryDirectory() as td:
     json.dump(G.TINY, open(os.path.join(td, "tiny-lens.json"), "w"))
     oc.add_model_config(td)
-    for m in ("depth", "audio", "pc"):
+    for m in ("depth", "audio", "pc", "eeg"):
         model = oc.tri_create_model("tiny-lens", None, precision="fp32", device="cpu", output_dict=True, args=G.tiny_args(m))
         model.lock_image_tower(); model.lock_text_tower()
         model.lock_visual_tower(unlock_trans_first_n_layers=1, unlock_cls=(m == "audio"))
@@ -54,7 +54,7 @@ def test_state_dict_and_lock_recipes_match_reference():
     with tempfile.TemporaryDirectory() as td:
         json.dump(G.TINY, open(os.path.join(td, "tiny-lens.json"), "w"))
         oc.add_model_config(td)
-        for m in ("depth", "audio", "pc"):
+        for m in ("depth", "audio", "pc", "eeg"):
             args = SimpleNamespace(**ref[m]["args"])
             model = oc.tri_create_model("tiny-lens", None, device="cpu", output_dict=True, args=args)
             mine = {k: list(v.shape) for k, v in model.state_dict().items()}

@@ -15,7 +15,7 @@ def close(a, b, **kw):
     torch.testing.assert_close(a, b, **t)
 
 
-@pytest.mark.parametrize("modality", ["depth", "audio", "pc"])
+@pytest.mark.parametrize("modality", ["depth", "audio", "pc", "eeg", "tactile"])
 def test_tiny_towers(modality):
     sd, ins, outs, grads, meta = split(load_npz(f"tiny_{modality}.npz"))
     tower, text, lens = specs_from_meta(meta)
@@ -31,7 +31,7 @@ def test_tiny_towers(modality):
     close(sd["logit_scale"].exp(), outs["logit_scale"])
 
 
-@pytest.mark.parametrize("modality", ["depth", "audio", "pc"])
+@pytest.mark.parametrize("modality", ["depth", "audio", "pc", "eeg", "tactile"])
 def test_losses_and_feature_grads(modality):
     sd, ins, outs, grads, meta = split(load_npz(f"tiny_{modality}.npz"))
     f = {k: outs[k + "_features"].clone().requires_grad_(True) for k in ("image", "text", "visual")}
@@ -53,7 +53,7 @@ def test_losses_and_feature_grads(modality):
     close(ls.grad, outs["dual_grad_logit_scale"], atol=1e-6)
 
 
-@pytest.mark.parametrize("modality", ["depth", "audio"])
+@pytest.mark.parametrize("modality", ["depth", "audio", "eeg", "tactile"])
 def test_step_param_grads(modality):
     """Autograd through the oracle = the reference's backward for the trainable tower."""
     sd, ins, outs, grads, meta = split(load_npz(f"tiny_{modality}.npz"))

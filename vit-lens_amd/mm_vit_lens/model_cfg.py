@@ -19,6 +19,9 @@ _MODALITY = {
                   audio_fstride=10, audio_tstride=10, audio_mel_bins=128, audio_target_length=512, perceiver_depth=2,
                   perceiver_input_chan=1024, perceiver_self_per_cross_attn=3),
     "depth": dict(visual_modality_type="depth", v_key="depth", perceiver_as_identity=True),
+    "tactile": dict(visual_modality_type="tactile", v_key="tactile", use_perceiver=False, use_visual_adapter=False),
+    "eeg": dict(visual_modality_type="eeg", v_key="eeg", eeg_chans=128, eeg_stride=1, eeg_time_len=512, eeg_window_size=1,
+                perceiver_depth=1, perceiver_input_chan=1024, perceiver_self_per_cross_attn=1),
     "image": dict(visual_modality_type="image", v_key="image", use_perceiver=False, use_visual_adapter=False),
 }
 

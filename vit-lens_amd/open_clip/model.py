@@ -130,6 +130,11 @@ class VisionTransformer(nn.Module):
             td = (a.audio_target_length - P) // a.audio_tstride + 1
             prm["visual_adapter.conv1.weight"] = _uni((D, 1, P, P), (P * P) ** -0.5)
             prm["visual_adapter.pos_emb"] = scale * torch.randn(fd * td, D)
+        elif self.modality == "eeg":
+            fan = a.eeg_chans * a.eeg_window_size
+            prm["visual_adapter.proj.weight"] = _uni((D, a.eeg_chans, a.eeg_window_size), fan ** -0.5)
+            prm["visual_adapter.proj.bias"] = _uni((D,), fan ** -0.5)
+            prm["visual_adapter.pos_emb"] = scale * torch.randn((a.eeg_time_len - a.eeg_window_size) // a.eeg_stride + 1, D)
         elif self.modality == "pc":
             E, Tr = a.pc_encoder_dims, a.pc_trans_dim
             def lin(name, o, i, conv=False):
@@ -246,7 +251,9 @@ class VisionTransformer(nn.Module):
                 cross_dim_head=_g(a, "perceiver_cross_dim_head", 64), latent_heads=_g(a, "perceiver_latent_heads", 16),
                 latent_dim_head=_g(a, "perceiver_latent_dim_head", 64), audio_fstride=_g(a, "audio_fstride", 10),
                 audio_tstride=_g(a, "audio_tstride", 10), audio_mel_bins=_g(a, "audio_mel_bins", 128),
-                audio_target_length=_g(a, "audio_target_length", 512), pc_num_group=_g(a, "pc_num_group", 512),
+                audio_target_length=_g(a, "audio_target_length", 512), eeg_chans=_g(a, "eeg_chans", 128),
+                eeg_time_len=_g(a, "eeg_time_len", 512), eeg_window_size=_g(a, "eeg_window_size", 1),
+                eeg_stride=_g(a, "eeg_stride", 1), pc_num_group=_g(a, "pc_num_group", 512),
                 pc_group_size=_g(a, "pc_group_size", 32), pc_encoder_dims=_g(a, "pc_encoder_dims", 256),
                 pc_trans_dim=_g(a, "pc_trans_dim", 384), use_orig_pos=not _g(a, "disable_orig_pos", False),
                 disable_adapter_pos=bool(_g(a, "disable_visual_adapter_pos", False)),
@@ -293,6 +300,8 @@ class VisionTransformer(nn.Module):
                 tr = T.DepthLensTrainer(eng, tower_kw=kw)
             elif self.modality == "audio" and not self.perceiver_identity:
                 tr = T.AudioLensTrainer(eng, tower_kw=kw)
+            elif self.modality == "eeg" and not self.perceiver_identity:
+                tr = T.EEGLensTrainer(eng, tower_kw=kw)
             elif self.modality == "pc" and not self.perceiver_identity:
                 from vitlens_hip.points import PointTokenizerTrainer
                 sd = {("t." + k): v for k, v in self.state_dict().items() if k.startswith("visual_adapter.")}

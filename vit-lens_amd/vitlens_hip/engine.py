@@ -209,6 +209,10 @@ class LensCfg:
     pc_trans_dim: int = 384
     use_orig_pos: bool = True
     disable_adapter_pos: bool = False
+    eeg_chans: int = 128               # modal_eeg/models/EEG_tokenizer.py (PatchEmbed1D)
+    eeg_time_len: int = 512
+    eeg_window_size: int = 1
+    eeg_stride: int = 1
     weight_tie_layers: bool = False    # perceiver.py:249-254: layers >= 1 share one set of modules (forward works from the
                                        # duplicated state_dict keys; TRAINING a tied Lens is refused, see step.py)
 
@@ -326,6 +330,11 @@ class LensEngine:
             self.conv_w = conv_weight_as_gemm(sd[a + "conv1.weight"], device)
             pos = sd[a + "pos_emb"].detach().float()
             self.adapter_pos = _dev(pos * (0.0 if lens.disable_adapter_pos else 1.0), device)      # (the product is a new tensor)
+        elif lens.modality == "eeg":
+            # PatchEmbed1D: Conv1d(chans -> width, kernel = window, stride, bias) over time = a conv over [N, C, 1, T]
+            self.conv_w = conv_weight_as_gemm(sd[a + "proj.weight"].unsqueeze(2), device)
+            self.conv_b = _dev(sd[a + "proj.bias"], device)
+            self.adapter_pos = _dev(sd[a + "pos_emb"].detach().float() * (0.0 if lens.disable_adapter_pos else 1.0), device)
         elif lens.modality == "pc":
             from .points import PointTokenizerEngine
             self.points = PointTokenizerEngine(sd, a, lens, device, gemm_cfg=gemm_cfg)
@@ -344,7 +353,16 @@ class LensEngine:
             cols, gh, gw = ops.im2col(x.contiguous().float().unsqueeze(1), p, p, L.audio_fstride, L.audio_tstride,
                                       self.conv_w.shape[1], transpose_hw=True)
             return ops.gemm(cols, self.conv_w, None, epi=ops.EPI_BF16, cfg=self.gemm_cfg), self.adapter_pos
+        if L.modality == "eeg":         # EEG_tokenizer.py:35-42: [N, chans, time] -> tokens [N*T', width]
+            cols = self.eeg_cols(x)
+            return ops.gemm(cols, self.conv_w, self.conv_b, epi=ops.EPI_BF16, cfg=self.gemm_cfg), self.adapter_pos
         raise NotImplementedError(L.modality)
+
+    def eeg_cols(self, x: torch.Tensor) -> torch.Tensor:
+        """windows of the time axis as GEMM rows: [N*T', pad64(chans*window)], column order (chan, tap) = Conv1d's weight"""
+        L = self.lens
+        cols, gh, gw = ops.im2col(x.contiguous().float().unsqueeze(2), 1, L.eeg_window_size, 1, L.eeg_stride, self.conv_w.shape[1])
+        return cols
 
     def encode(self, x: torch.Tensor, normalize: bool = False, **kw) -> torch.Tensor:
         B = x.shape[0]

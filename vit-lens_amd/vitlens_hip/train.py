@@ -564,6 +564,34 @@ class AudioLensTrainer:
         ops.batch_rowsum(ddata, self.tower.grad_buffer("visual.visual_adapter.pos_emb", self.le.adapter_pos), B, T, D, T, 0)
 
 
+class EEGLensTrainer(AudioLensTrainer):
+    """`visual.` tower of the EEG recipe (mm_vit_lens/model_cfg.py:153-178): PatchEmbed1D (Conv1d with bias over the
+    time axis) + pos_emb + Perceiver trainable in front of the locked ViT - the audio recipe with a 1-D tokenizer."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        le = self.le
+        B = x.shape[0]
+        cols = le.eeg_cols(x)
+        tok = ops.gemm(cols, le.conv_w, le.conv_b, epi=ops.EPI_BF16, cfg=le.gemm_cfg)
+        T = tok.shape[0] // B
+        xin = torch.empty_like(tok)
+        ops.add_rows(tok, le.adapter_pos, xin, tok.shape[0], T, tok.shape[1])
+        lat = self.perc.forward(xin, B)
+        self.ctx = (cols, B, T)
+        return self.tower.forward(lat, B)
+
+    def backward(self, dfeat: torch.Tensor):
+        cols, B, T = self.ctx
+        dlat = self.tower.backward(dfeat)
+        ddata = self.perc.backward(dlat)                          # f32 [B*T, D]: gradient of tokens + pos
+        D = ddata.shape[1]
+        g = self.tower.grad_buffer("visual.visual_adapter.proj.weight_gemm", torch.empty(D, cols.shape[1]))
+        rp = (ddata.shape[0] + 63) // 64 * 64
+        ops.gemm_dw(ops.transpose_to_bf16(ddata, ldo=rp), ops.transpose_to_bf16(cols, ldo=rp), g, cfg=self.le.gemm_cfg)
+        ops.colsum(ddata, self.tower.grad_buffer("visual.visual_adapter.proj.bias", self.le.conv_b))
+        ops.batch_rowsum(ddata, self.tower.grad_buffer("visual.visual_adapter.pos_emb", self.le.adapter_pos), B, T, D, T, 0)
+
+
 class PCLensTrainer:
     """`visual.` tower of the point-cloud recipe: PointBERT tokenizer + Perceiver trainable, ViT blocks locked.
     `tok` is the shared PointTokenizerTrainer (masters, bf16 operands, running statistics); each micro-batch gets
