@@ -33,6 +33,10 @@ def tiny_args(modality):
                   perceiver_latent_dim_head=32, perceiver_cross_dim_head=64, perceiver_cross_heads=1)
     if modality == "depth":
         return ref_loader.lens_args("depth", **common)
+    if modality == "audio_tied":    # perceiver_weight_tie_layers: layers 1, 2 of a depth-3 Perceiver are the same modules
+        return ref_loader.lens_args("audio", audio_mel_bins=32, audio_target_length=48, audio_fstride=6, audio_tstride=6,
+                                    perceiver_input_chan=64, perceiver_depth=3, perceiver_self_per_cross_attn=1,
+                                    perceiver_weight_tie_layers=True, **common)
     if modality == "audio":
         return ref_loader.lens_args("audio", audio_mel_bins=32, audio_target_length=48,
                                     audio_fstride=6, audio_tstride=6, perceiver_input_chan=64,
@@ -82,7 +86,7 @@ def tiny_case(oc, modality, seed):
         vx = torch.randn(B, 1, 32, 32, generator=g)
     elif modality == "tactile":
         vx = torch.randn(B, 3, 32, 32, generator=g)
-    elif modality == "audio":
+    elif modality in ("audio", "audio_tied"):
         vx = torch.randn(B, 48, 32, generator=g)
     elif modality == "eeg":
         vx = torch.randn(B, 8, 40, generator=g)

@@ -81,6 +81,7 @@ class LensSpec:
     pc_trans_dim: int = 384
     use_orig_pos: bool = True          # transformer.py:545-551
     disable_adapter_pos: bool = False  # transformer.py:738-745
+    weight_tie_layers: bool = False    # perceiver.py:249-254 (see tie_perceiver_layers; the forward needs nothing special)
 
 
 # ----------------------------------------------------------------------------- primitives
@@ -332,6 +333,16 @@ def eeg_tokens(sd: SD, prefix: str, x: Tensor, lens: LensSpec):
     a = prefix + "visual_adapter."
     t = torch.nn.functional.conv1d(x, sd[a + "proj.weight"], sd[a + "proj.bias"], stride=lens.eeg_stride)
     return t.transpose(1, 2).contiguous(), sd[a + "pos_emb"]
+
+
+def tie_perceiver_layers(sd: SD, depth: int, prefix: str = "visual.perceiver.") -> SD:
+    """perceiver_weight_tie_layers (perceiver.py:249-254): layers 1 .. depth-1 are the same modules.  Makes the entries of
+    layers >= 2 the SAME tensor objects as layer 1's, so autograd on this dict sums their gradients as the reference does."""
+    p1 = f"{prefix}layers.1."
+    for k in [k for k in sd if k.startswith(p1)]:
+        for li in range(2, depth):
+            sd[f"{prefix}layers.{li}." + k[len(p1):]] = sd[k]
+    return sd
 
 
 def encode_visual(sd: SD, x: Tensor, spec: TowerSpec, lens: LensSpec, normalize: bool = False,

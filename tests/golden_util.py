@@ -46,5 +46,6 @@ def specs_from_meta(meta):
         pc_num_group=a.get("pc_num_group", 512), pc_group_size=a.get("pc_group_size", 32),
         pc_encoder_dims=a.get("pc_encoder_dims", 256), pc_trans_dim=a.get("pc_trans_dim", 384),
         use_orig_pos=not a.get("disable_orig_pos", False),
-        disable_adapter_pos=bool(a.get("disable_visual_adapter_pos", False)))
+        disable_adapter_pos=bool(a.get("disable_visual_adapter_pos", False)),
+        weight_tie_layers=bool(a.get("perceiver_weight_tie_layers", False)))
     return tower, text, lens

@@ -64,7 +64,7 @@ def test_c1_vitb32_image_text_pairs_through_api():
     assert abs(float(out["logit_scale"]) - 1 / 0.07) < 1e-3
 
 
-@pytest.mark.parametrize("modality", ["depth", "audio", "pc", "eeg", "tactile"])
+@pytest.mark.parametrize("modality", ["depth", "audio", "pc", "eeg", "tactile", "audio_tied"])
 def test_tiny_golden_forward_and_loss_through_api(modality):
     """tri_create_model + load_state_dict(reference weights) + TriCLIP.forward + create_loss on the reference's tiny
     golden case: the three feature sets and the TriClipLoss value the reference produced."""
@@ -102,7 +102,7 @@ def _pc_tol(name):
     return 0.30 if "visual_adapter.encoder" in name else 8e-2
 
 
-@pytest.mark.parametrize("modality", ["depth", "audio", "pc", "eeg", "tactile"])
+@pytest.mark.parametrize("modality", ["depth", "audio", "pc", "eeg", "tactile", "audio_tied"])
 def test_reference_training_sequence_through_api(modality):
     """The reference's loop body (training/train.py:131-152, 212-235) verbatim on the drop-in modules:
         out = model(image, text, visual_x); loss = loss_fn(**out); loss.backward(); optimizer.step()

@@ -356,11 +356,14 @@ def test_step_checkpoint_export_reload_and_resume(recipe):
         assert relerr(v.float(), before[k].float()) < 1e-6 or v.dtype == torch.long, k
 
 
-def test_audio_lens_backward_vs_reference_grads():
+@pytest.mark.parametrize("case", ["audio", "audio_tied"])
+def test_audio_lens_backward_vs_reference_grads(case):
     """Audio recipe: AST tokenizer + Perceiver (cross + self attention, GEGLU FF) trainable, ViT locked, cls unlocked.
-    Every gradient the HIP backward produces vs the reference's own autograd on the tiny golden model."""
+    Every gradient the HIP backward produces vs the reference's own autograd on the tiny golden model.  `audio_tied`:
+    perceiver_weight_tie_layers with depth 3 - layers 1 and 2 are the same modules, their gradients arrive summed under
+    layer 1's names (as named_parameters() of the reference lists them)."""
     from vitlens_hip import engine as E, train as TR
-    sd, ins, outs, grads, meta = split(load_npz("tiny_audio.npz"))
+    sd, ins, outs, grads, meta = split(load_npz(f"tiny_{case}.npz"))
     tower, text, lens = specs_from_meta(meta)
     tc = E.TowerCfg(width=tower.width, layers=tower.layers, heads=tower.heads, patch=tower.patch,
                     image_size=tower.image_size, embed_dim=tower.embed_dim)
@@ -388,13 +391,17 @@ def test_audio_lens_backward_vs_reference_grads():
     # latents, adapter (2), cls, per layer: cross attn 3 w + 1 b + 2 LN x2, ff 2w+2b+LN2, selfs ...
     assert n >= 40, n
     assert "visual.class_embedding" in got and "visual.perceiver.latents" in got
+    if case == "audio_tied":
+        assert not any(".layers.2." in k for k in got) and le.perceiver.layers[2] is le.perceiver.layers[1]
 
 
-def test_dual_audio_step_runs_and_matches_reference_loss():
+@pytest.mark.parametrize("case", ["audio", "audio_tied"])
+def test_dual_audio_step_runs_and_matches_reference_loss(case):
     """Audio <-> text dual step (ClipLossGeneral): loss vs the reference's value on the tiny golden model, then two
-    optimizer steps (masters move, bf16 operands + transposes refreshed, loss does not increase)."""
+    optimizer steps (masters move, bf16 operands + transposes refreshed, loss does not increase).  Tied Perceiver layers:
+    one master per shared tensor, the exported state_dict repeats it under every tied layer index."""
     from vitlens_hip import engine as E, step as ST
-    sd, ins, outs, grads, meta = split(load_npz("tiny_audio.npz"))
+    sd, ins, outs, grads, meta = split(load_npz(f"tiny_{case}.npz"))
     tower, text, lens = specs_from_meta(meta)
     tc = E.TowerCfg(width=tower.width, layers=tower.layers, heads=tower.heads, patch=tower.patch,
                     image_size=tower.image_size, embed_dim=tower.embed_dim)
@@ -409,6 +416,12 @@ def test_dual_audio_step_runs_and_matches_reference_loss():
     l2 = st.step(ins["visual_x"].cuda(), ins["text"].cuda())
     l3 = st.step(ins["visual_x"].cuda(), ins["text"].cuda())
     assert torch.isfinite(l3) and float(l3) < float(loss) + 1e-3, (float(loss), float(l2), float(l3))
+    if case == "audio_tied":
+        assert not any(".layers.2." in k for k in st.masters)
+        out = st.state_dict()
+        assert set(out) == set(sd)
+        k1 = "visual.perceiver.layers.1.0.fn.to_q.weight"
+        assert torch.equal(out[k1], out[k1.replace(".layers.1.", ".layers.2.")]) and not torch.equal(out[k1].float().cpu(), sd[k1].float())
 
 
 # ------------------------------------------------------------------------------------------------ point-cloud Lens

@@ -15,7 +15,7 @@ def close(a, b, **kw):
     torch.testing.assert_close(a, b, **t)
 
 
-@pytest.mark.parametrize("modality", ["depth", "audio", "pc", "eeg", "tactile"])
+@pytest.mark.parametrize("modality", ["depth", "audio", "pc", "eeg", "tactile", "audio_tied"])
 def test_tiny_towers(modality):
     sd, ins, outs, grads, meta = split(load_npz(f"tiny_{modality}.npz"))
     tower, text, lens = specs_from_meta(meta)
@@ -53,13 +53,15 @@ def test_losses_and_feature_grads(modality):
     close(ls.grad, outs["dual_grad_logit_scale"], atol=1e-6)
 
 
-@pytest.mark.parametrize("modality", ["depth", "audio", "eeg", "tactile"])
+@pytest.mark.parametrize("modality", ["depth", "audio", "eeg", "tactile", "audio_tied"])
 def test_step_param_grads(modality):
     """Autograd through the oracle = the reference's backward for the trainable tower."""
     sd, ins, outs, grads, meta = split(load_npz(f"tiny_{modality}.npz"))
     tower, text, lens = specs_from_meta(meta)
     sd = {k: (v.clone().requires_grad_(True) if (k.startswith("visual.") or k == "logit_scale") else v)
           for k, v in sd.items()}
+    if meta["args"].get("perceiver_weight_tie_layers"):        # shared modules: one tensor object under every tied layer index
+        O.tie_perceiver_layers(sd, lens.depth)
     i = O.encode_image(sd, ins["image"], tower, normalize=True)
     t = O.encode_text(sd, ins["text"], text, normalize=True)
     v = O.encode_visual(sd, ins["visual_x"], tower, lens, normalize=True)

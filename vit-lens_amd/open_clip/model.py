@@ -176,6 +176,12 @@ class VisionTransformer(nn.Module):
             _attach(self, k, v)
         for k, v in bufs.items():
             _attach(self, k, v, buffer=True)
+        if self.use_perceiver and not self.perceiver_identity and _g(a, "perceiver_weight_tie_layers", False):
+            # perceiver.py:249-254 (`cache_fn`): layers 1 .. depth-1 are ONE set of modules - the state_dict lists them under
+            # every index, named_parameters() (and so the optimizer and lock()) only once, under layer 1
+            mods = self.perceiver.layers._modules
+            for i in range(2, len(mods)):
+                mods[str(i)] = mods["1"]
         self.image_mean = self.image_std = None
         self._engine = None
         self._engine_key = None

@@ -213,8 +213,7 @@ class LensCfg:
     eeg_time_len: int = 512
     eeg_window_size: int = 1
     eeg_stride: int = 1
-    weight_tie_layers: bool = False    # perceiver.py:249-254: layers >= 1 share one set of modules (forward works from the
-                                       # duplicated state_dict keys; TRAINING a tied Lens is refused, see step.py)
+    weight_tie_layers: bool = False    # perceiver.py:249-254: layers >= 1 share one set of modules
 
 
 def _interleave_geglu(w: torch.Tensor, b: torch.Tensor):
@@ -252,6 +251,11 @@ class PerceiverEngine:
         ln = lambda q: (_dev(sd[q + ".weight"], device), _dev(sd[q + ".bias"], device))
         self.layers = []
         for i in range(cfg.depth):
+            if cfg.weight_tie_layers and i >= 2:
+                # perceiver.py:249-254 (`cache_fn`): layers 1 .. depth-1 ARE one set of modules; the state_dict repeats their
+                # tensors under every layer index.  Sharing the objects here makes an update of layer 1 an update of all.
+                self.layers.append(self.layers[1])
+                continue
             q = f"{prefix}layers.{i}."
             lay = {"x_norm": ln(q + "0.norm"), "x_norm_ctx": ln(q + "0.norm_context"),
                    "x_attn": prep_lens_attn(sd, q + "0.fn.", device, False),

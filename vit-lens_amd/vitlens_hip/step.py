@@ -98,6 +98,12 @@ class _StepState:
         for name, m in self.masters.items():
             for k, v in _master_to_sd(name, m.detach(), self._base_sd, cfg).items():
                 out[k] = v.to(device=self._base_sd[k].device, dtype=self._base_sd[k].dtype).clone()
+        if cfg is not None and getattr(cfg, "weight_tie_layers", False):
+            # the reference's state_dict repeats the shared modules under every tied layer index (perceiver.py:249-254)
+            P1 = "visual.perceiver.layers.1."
+            for k in [k for k in out if k.startswith(P1)]:
+                for li in range(2, cfg.depth):
+                    out[f"visual.perceiver.layers.{li}." + k[len(P1):]] = out[k].clone()
         tok = getattr(self, "tok", None)
         if tok is not None:                                      # BatchNorm running statistics of the PointTokenizer
             for k, (rm, rv) in tok.running.items():
@@ -430,12 +436,11 @@ class _PerceiverLensStep(_StepState):
 
     def _collect_perceiver(self, sd):
         pe, P = self.lens.perceiver, "visual.perceiver."
-        if getattr(self.lens.lens, "weight_tie_layers", False) and len(pe.layers) > 1:
-            # tied layers share parameters (perceiver.py:249-254): their gradients would have to be summed into one master
-            raise NotImplementedError("training a Perceiver with perceiver_weight_tie_layers=True is not implemented")
         f32 = lambda k: sd[k].detach().float().to(self.dev).contiguous().clone()
         self.masters[P + "latents"] = pe.latents
         for li, lay in enumerate(pe.layers):
+            if li >= 2 and lay is pe.layers[1]:
+                continue      # tied to layer 1 (perceiver_weight_tie_layers): same tensors, same masters, summed gradients
             q = f"{P}layers.{li}."
             self._attn(q + "0.", lay["x_attn"], lay["x_norm"], (li, "x"), sd, f32, ctx_norm=lay["x_norm_ctx"])
             self._ff(q + "1.", lay["x_ff"], lay["x_ff_norm"], (li, "xff"), sd, f32)

@@ -336,7 +336,10 @@ class PerceiverTrainer:
         self.grads: Dict[str, torch.Tensor] = {}
         t = lambda w: w.t().contiguous()
         self.wT = []
-        for lay in pe.layers:
+        for li, lay in enumerate(pe.layers):
+            if li >= 2 and lay is pe.layers[1]:           # tied layers (perceiver_weight_tie_layers): one set of transposes too
+                self.wT.append(self.wT[1])
+                continue
             d = {"x": {"q": t(lay["x_attn"]["q_w"]), "kv": t(lay["x_attn"]["kv_w"]), "out": t(lay["x_attn"]["to_out_w"])},
                  "xff": {"w0": t(lay["x_ff"]["w0"]), "w2": t(lay["x_ff"]["w2"])}, "selfs": []}
             for sl in lay["selfs"]:
@@ -351,6 +354,11 @@ class PerceiverTrainer:
             g = torch.zeros(tuple(shape), device=self.pe.device, dtype=torch.float32)
             self.grads[name] = g
         return g
+
+    def layer_name(self, li: int) -> int:
+        """Index under which layer li's parameters are named: tied layers (>= 2) are layer 1's modules, so their
+        gradients accumulate in layer 1's buffers (what autograd does for the reference's shared modules)."""
+        return 1 if li >= 2 and self.pe.layers[li] is self.pe.layers[1] else li
 
     def _state(self, B, Tc):
         key = (B, Tc)
@@ -457,7 +465,7 @@ class PerceiverTrainer:
             lay, S, wT = pe.layers[li], st["layers"][li], self.wT[li]
             for sj in reversed(range(c.self_per_cross)):
                 sl, T, w = lay["selfs"][sj], S["selfs"][sj], wT["selfs"][sj]
-                pn = f"{P}layers.{li}.2.{sj}."
+                pn = f"{P}layers.{self.layer_name(li)}.2.{sj}."
                 xi -= 1
                 self._ff_bwd(st, xi, sl["ff_norm"], sl["ff"], w, T["ff_stats"], T["ff_h"], rows, D, pn)
                 xi -= 1
@@ -476,7 +484,7 @@ class PerceiverTrainer:
                 self._ln_params(pn + "0.norm", st["dhn"], X[xi], T["stats"], rows, D)
                 ops.layernorm_bwd(st["dhn"], X[xi], T["stats"][0], T["stats"][1], sl["norm"][0], rows, D, dres=st["dx"],
                                   dx=st["dx"], dx_bf16=st["dxb"])
-            pn = f"{P}layers.{li}."
+            pn = f"{P}layers.{self.layer_name(li)}."
             xi -= 1
             self._ff_bwd(st, xi, lay["x_ff_norm"], lay["x_ff"], wT["xff"], S["xff_stats"], S["xff_h"], rows, D, pn)
             xi -= 1
