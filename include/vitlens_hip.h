@@ -192,6 +192,9 @@ int vl_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dO
 /* farthest point sampling: xyz [B,N,3] f32, start [B] (the reference draws it with torch.randint, misc.py:60);
  * idx [B,G] int64 (bit-exact vs misc.fps), centers [B,G,3] optional. */
 int vl_fps(const float* xyz, const int64_t* start, int64_t* idx, float* centers, int B, int N, int G, hipStream_t stream);
+/* pc_norm after a gather (modal_3d/processors/pc_processor.py:32-38, PCProcessorEval :60-88): out [B,G,C] f32 =
+ * (pts[b, idx[b,g], :] - centroid) / max distance from the centroid over the G selected points; idx NULL = all N points. */
+int vl_pc_gather_normalize(const float* pts, const int64_t* idx, float* out, int B, int N, int G, int C, hipStream_t stream);
 /* k nearest neighbours of each centre (set semantics = topk(sorted=False), dvae.py:107-118) + gather +
  * centre subtraction: nidx [B,G,k] int32 optional, patches bf16 [B*G*k, Kp] optional (xyz in cols 0..2). */
 int vl_knn_group(const float* xyz, const int64_t* center_idx, int* nidx, void* patches, int B, int N, int G,

@@ -581,3 +581,31 @@ def synth_text(n: int, gen: torch.Generator, ctx: int = 77, vocab: int = 49408) 
         t[i, 1:1 + k] = torch.randint(1, vocab - 2, (k,), generator=gen)
         t[i, 1 + k] = vocab - 1
     return t
+
+
+# ------------------------------------------------------------------------------------------------
+# data-loader side of the 3D recipe: numpy, as the reference runs it
+# ------------------------------------------------------------------------------------------------
+def pc_farthest_point_sample(point, npoint: int, start: int):
+    """farthest_point_sample, modal_3d/processors/pc_processor.py:8-29, with the random start made an argument.
+    point [N, C] numpy (xyz first) -> (sampled points [npoint, C], indices [npoint])."""
+    import numpy as np
+    xyz = point[:, :3]
+    N = xyz.shape[0]
+    centroids = np.zeros((npoint,), dtype=np.int64)
+    distance = np.ones((N,)) * 1e10
+    farthest = int(start)
+    for i in range(npoint):
+        centroids[i] = farthest
+        dist = np.sum((xyz - xyz[farthest, :]) ** 2, -1)
+        mask = dist < distance
+        distance[mask] = dist[mask]
+        farthest = int(np.argmax(distance, -1))
+    return point[centroids], centroids
+
+
+def pc_norm(pc):
+    """pc_norm, modal_3d/processors/pc_processor.py:32-38: centre on the centroid, scale the farthest point to radius 1."""
+    import numpy as np
+    pc = pc - np.mean(pc, axis=0)
+    return pc / np.max(np.sqrt(np.sum(pc ** 2, axis=1)))

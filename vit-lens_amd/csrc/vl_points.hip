@@ -6,12 +6,16 @@
 //                 iterations (the reference launches ~6 tiny kernels per iteration); the argmax is a
 //                 wave shuffle + one LDS hop; ties resolve to the lowest index like torch.max.
 //                 Distances are computed as ((dx*dx + dy*dy) + dz*dz) with every operation rounded
-//                 separately (no FMA contraction) to reproduce the CPU reference's fp32 values.
+//                 separately (`#pragma clang fp contract(off)` on plain operators: the __f*_rn intrinsics do NOT stop
+//                 hipcc's contraction) to reproduce the CPU reference's fp32 values.
 //   vl_knn_group  k nearest points of every centre with the reference's expanded distance
 //                 -2ab + |a|^2 + |b|^2 (dvae.py:107-140) via an exact radix select of the k-th smallest
 //                 key (no sort, no N x G distance matrix in HBM), then gather + centre-subtract
 //                 (Group.forward, dvae.py:150-176) straight into the bf16 GEMM operand of the first conv.
 //   vl_group_max  max over the points of a group (torch.max(feature, dim=2), dvae.py:206,211)
+//   vl_pc_gather_normalize  the data-loader side of the 3D path on the GPU: gather the sampled points and
+//                 scale them into the unit sphere (pc_norm, modal_3d/processors/pc_processor.py:32-38); with vl_fps in
+//                 front of it this is PCProcessorEval (`uniform` sampling to 8192 points)
 #include "vl_common.h"
 #include "vitlens_hip.h"
 
@@ -46,8 +50,12 @@ __global__ void __launch_bounds__(FPS_THREADS) fps_kernel(const float* xyz, cons
     for (int k = 0; k < PPT; ++k) {
       const int i = tid + k * FPS_THREADS;
       if (i < N) {
-        const float dx = __fsub_rn(px[k], cx), dy = __fsub_rn(py[k], cy), dz = __fsub_rn(pz[k], cz);
-        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        // no FMA: hipcc contracts a*a + b*b into v_fma_f32 even through the __f*_rn intrinsics (they are plain operators
+        // in HIP), which moved one distance by an ulp and swapped two consecutive picks against the reference
+        // (found with tools at N = 3000 / G = 2900; the 8192 -> 512 goldens never hit it)
+#pragma clang fp contract(off)
+        const float dx = px[k] - cx, dy = py[k] - cy, dz = pz[k] - cz;
+        const float d = (dx * dx + dy * dy) + dz * dz;          // every operation rounded separately
         const float m = fminf(dist[k], d);
         dist[k] = m;
         if (m > best) { best = m; besti = i; }      // increasing i within a thread: strict > keeps the lowest index
@@ -161,6 +169,51 @@ __global__ void __launch_bounds__(256) pad3_kernel(const float* c, bf16_t* out, 
   }
 }
 
+// out[b, g, :] = (pts[b, idx[b,g], :] - mean_g) / max_g ||pts - mean||   (pc_norm after the gather), C <= 8 channels.
+// One workgroup per cloud; fixed-order block reductions (deterministic): per-thread strided partials, then a tree in LDS.
+__global__ void __launch_bounds__(1024) pc_gather_norm_kernel(const float* pts, const int64_t* idx, float* out, int N, int G, int C) {
+  __shared__ float sh[1024];
+  __shared__ float s_mean[8];
+  __shared__ float s_max;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* P = pts + (size_t)b * N * C;
+  const int64_t* I = idx ? idx + (size_t)b * G : nullptr;
+  auto row = [&](int g) { return P + (size_t)(I ? I[g] : g) * C; };
+  for (int c = 0; c < C; ++c) {
+    float a = 0.f;
+    for (int g = tid; g < G; g += 1024) a += row(g)[c];
+    sh[tid] = a;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+      if (tid < w) sh[tid] += sh[tid + w];
+      __syncthreads();
+    }
+    if (tid == 0) s_mean[c] = sh[0] / (float)G;
+    __syncthreads();
+  }
+  float m = 0.f;
+  for (int g = tid; g < G; g += 1024) {
+    const float* r = row(g);
+    float q = 0.f;
+    for (int c = 0; c < C; ++c) { const float d = r[c] - s_mean[c]; q = fmaf(d, d, q); }
+    m = fmaxf(m, sqrtf(q));
+  }
+  sh[tid] = m;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if (tid < w) sh[tid] = fmaxf(sh[tid], sh[tid + w]);
+    __syncthreads();
+  }
+  if (tid == 0) s_max = sh[0];
+  __syncthreads();
+  const float inv = 1.0f / s_max;
+  for (int g = tid; g < G; g += 1024) {
+    const float* r = row(g);
+    float* o = out + ((size_t)b * G + g) * C;
+    for (int c = 0; c < C; ++c) o[c] = (r[c] - s_mean[c]) * inv;
+  }
+}
+
 }  // namespace
 
 extern "C" int vl_set_error(const char* msg);
@@ -210,4 +263,13 @@ extern "C" int vl_pad3_bf16(const float* c, void* out, long R, int Kp, hipStream
   hipLaunchKernelGGL(pad3_kernel, dim3(grid_for(R * Kp)), dim3(256), 0, stream, c, (bf16_t*)out, R, Kp);
   VL_HIP_OK(hipGetLastError());
   return 0;
+}
+
+extern "C" int vl_pc_gather_normalize(const float* pts, const int64_t* idx, float* out, int B, int N, int G, int C,
+                                      hipStream_t stream) {
+  if (B <= 0 || N <= 0 || G <= 0 || C < 3 || C > 8) return vl_set_error("vl_pc_gather_normalize: bad shape (3 <= C <= 8)");
+  if (!idx && G != N) return vl_set_error("vl_pc_gather_normalize: without an index list G must equal N");
+  hipLaunchKernelGGL(pc_gather_norm_kernel, dim3(B), dim3(1024), 0, stream, pts, idx, out, N, G, C);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : vl_set_error(hipGetErrorString(e));
 }

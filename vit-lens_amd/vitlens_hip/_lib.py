@@ -40,6 +40,7 @@ SIGNATURES = {
     "vl_ce_grad_ws_floats": [I, I, L, L],
     "vl_gemm_bf16_ex": [P, P, P, P, P, P, I, I, I, I, I, I, F, I, I, I, I, P],
     "vl_fps": [P, P, P, P, I, I, I, P],
+    "vl_pc_gather_normalize": [P, P, P, I, I, I, I, P],
     "vl_knn_group": [P, P, P, P, I, I, I, I, I, P],
     "vl_group_max": [P, L, P, I, L, L, I, I, P],
     "vl_pad3_bf16": [P, P, L, I, P],

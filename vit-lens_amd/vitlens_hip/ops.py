@@ -374,6 +374,16 @@ def fps(xyz, start, G, want_centers=True):
     return idx, centers
 
 
+def pc_gather_normalize(pts, idx=None):
+    """pts [B,N,C] f32, idx [B,G] int64 or None -> [B,G,C] f32: the selected points centred and scaled into the unit sphere."""
+    B, N, Cc = pts.shape
+    G = N if idx is None else idx.shape[1]
+    out = torch.empty(B, G, Cc, device=pts.device, dtype=torch.float32)
+    check(_lib.vl_pc_gather_normalize(_p(pts.contiguous()), _p(idx.contiguous() if idx is not None else None), _p(out), B, N, G, Cc,
+                                      _stream()))
+    return out
+
+
 def knn_group(xyz, center_idx, k, Kp=64, want_idx=False):
     B, N, _ = xyz.shape
     G = center_idx.shape[1]
