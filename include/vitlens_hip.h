@@ -195,6 +195,25 @@ int vl_fps(const float* xyz, const int64_t* start, int64_t* idx, float* centers,
 /* pc_norm after a gather (modal_3d/processors/pc_processor.py:32-38, PCProcessorEval :60-88): out [B,G,C] f32 =
  * (pts[b, idx[b,g], :] - centroid) / max distance from the centroid over the G selected points; idx NULL = all N points. */
 int vl_pc_gather_normalize(const float* pts, const int64_t* idx, float* out, int B, int N, int G, int C, hipStream_t stream);
+/* ---- evaluation-time image / depth preprocessing (csrc/vl_preproc.hip) ----
+ * Separable bicubic resampling restricted to a crop window, tables built by the host (vitlens_hip/preproc.py):
+ * bounds [n_out,2] int32 = (first tap, tap count) and coefficients [n_out,ksize] per OUTPUT index of the full resized
+ * axis; xout0/nxout (yout0/nyout) select the crop.  8-bit path = Pillow's Image.resize(BICUBIC) (22-bit fixed-point
+ * int32 taps, 8-bit intermediate; byte-exact), replacing torchvision Resize+CenterCrop+ToTensor+Normalize of
+ * open_clip/transform.py:138-155: the vertical pass writes out [C,nyout,W] f32 = (u8/255 - mean[c]) / std[c] (mean/std:
+ * HOST arrays of C floats) and/or the resized bytes out_u8 [nyout,W,C].  Float path = ATen bicubic (antialiased or the
+ * 4-tap border-clamped form) with DepthNorm's clamp(lo,hi)/divide_by fused into the read, replacing
+ * modal_depth/processors/vt_processor.py:292-337; taps are clamped to the image, so bounds may start at -1. */
+int vl_resample_h_u8(const uint8_t* src, long row_stride, int C, int row0, int nrows, const int* bounds, const int* kk,
+                     int ksize, int xout0, int nxout, uint8_t* dst, hipStream_t stream);
+int vl_resample_v_u8_norm(const uint8_t* src, int W, int C, int row0, const int* bounds, const int* kk, int ksize,
+                          int yout0, int nyout, const float* mean, const float* stdv, float* out, uint8_t* out_u8,
+                          hipStream_t stream);
+int vl_resample_h_f32(const float* src, long row_stride, int W, int row0, int nrows, const int* bounds,
+                      const float* weights, int ksize, int xout0, int nxout, int clamp_on, float clamp_lo,
+                      float clamp_hi, float divide_by, float* dst, hipStream_t stream);
+int vl_resample_v_f32_norm(const float* src, int W, int H, int row0, const int* bounds, const float* weights, int ksize,
+                           int yout0, int nyout, float mean, float stdv, float* out, hipStream_t stream);
 /* k nearest neighbours of each centre (set semantics = topk(sorted=False), dvae.py:107-118) + gather +
  * centre subtraction: nidx [B,G,k] int32 optional, patches bf16 [B*G*k, Kp] optional (xyz in cols 0..2). */
 int vl_knn_group(const float* xyz, const int64_t* center_idx, int* nidx, void* patches, int B, int N, int G,
@@ -209,6 +228,21 @@ int vl_pad3_bf16(const float* c, void* out, long R, int Kp, hipStream_t stream);
  * is the input gradient; train=0 treats mean/var as constants (eval-mode BN). */
 int vl_bn_stats(const void* x, long ldx, int R, int C, float* ws, int nchunk, float* mean, float* var,
                 float* running_mean, float* running_var, float momentum, hipStream_t stream);
+/* SyncBatchNorm (torch.nn.SyncBatchNorm under --use-bn-sync, training/point_cloud/pc_tri_main.py:372-373): the two
+ * passes above split where the ranks exchange data.  Forward: vl_bn_stats_local -> local [2C+1] floats = per-column
+ * mean, M2 = sum (x-mean)^2, and the row count as int bits; all-gather to [W, 2C+1]; vl_bn_stats_merge -> global
+ * mean / biased var (+ running statistics with the global unbiased variance) and *total = global row count.
+ * Backward: vl_bn_bwd_reduce accumulates dgamma/dbeta (local, as SyncBatchNorm does) and writes sums [2C] =
+ * (sum dy', sum dy'*xhat); all-reduce(sum) them; vl_bn_bwd_apply -> dx with the global sums and count. */
+int vl_bn_stats_local(const void* x, long ldx, int R, int C, float* ws, int nchunk, float* local, hipStream_t stream);
+int vl_bn_stats_merge(const float* gathered, int W, int C, float* mean, float* var, float* running_mean,
+                      float* running_var, float momentum, int* total, hipStream_t stream);
+int vl_bn_bwd_reduce(const void* dy, long lddy, const void* x, long ldx, const float* mean, const float* var,
+                     const float* gamma, const float* beta, float eps, int relu, float* ws, int nchunk, float* dgamma,
+                     float* dbeta, float* sums, int R, int C, hipStream_t stream);
+int vl_bn_bwd_apply(const void* dy, long lddy, const void* x, long ldx, const float* mean, const float* var,
+                    const float* gamma, const float* beta, float eps, int relu, const float* sums, const int* total,
+                    void* dx, long lddx, int R, int C, hipStream_t stream);
 int vl_bn_apply(const void* x, long ldx, const float* mean, const float* var, const float* gamma, const float* beta,
                 float eps, int relu, void* out, long ldo, long R, int C, hipStream_t stream);
 int vl_bn_bwd(const void* dy, long lddy, const void* x, long ldx, const float* mean, const float* var,

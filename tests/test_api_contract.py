@@ -77,7 +77,7 @@ def test_public_surface():
     oc = importlib.import_module("open_clip")
     for name in ("ModalityType", "tokenize", "get_tokenizer", "tri_create_model", "tri_create_model_and_transforms",
                  "create_loss", "ClipLoss", "ClipLossGeneral", "TriClipLoss", "gather_features", "list_models",
-                 "add_model_config", "get_model_config", "TriCLIP"):
+                 "add_model_config", "get_model_config", "TriCLIP", "image_transform", "AugmentationCfg"):
         assert hasattr(oc, name), name
     assert oc.ModalityType.PC == "pc" and oc.ModalityType.DEPTH == "depth"
     assert "ViT-L-14" in oc.list_models()
@@ -198,3 +198,16 @@ def test_list_models_natural_order_and_pos_embed_resize():
     sd = {"visual.positional_embedding": pe.clone()}
     F.resize_pos_embed(sd, model_with(49))
     assert torch.equal(sd["visual.positional_embedding"], pe)
+
+
+def test_set_bn_sync_is_a_noop_without_ranks():
+    import open_clip
+    from types import SimpleNamespace
+    m = open_clip.model.VisionTransformer.__new__(open_clip.model.VisionTransformer)
+    m.modality, m._bn_sync = "pc", None
+    assert m.set_bn_sync(True)._bn_sync is None                                   # torch.distributed not initialised
+    comm = SimpleNamespace(all_gather=None, all_reduce_sum=None)
+    assert m.set_bn_sync(True, comm=comm, world_size=2)._bn_sync == (comm, 2)
+    assert m.set_bn_sync(False)._bn_sync is None
+    m.modality = "depth"
+    assert m.set_bn_sync(True, comm=comm, world_size=2)._bn_sync is None

@@ -16,7 +16,7 @@ EXTRA_FLAGS = {"vl_attn.hip": ["-fno-honor-nans"], "vl_attn_bwd.hip": ["-fno-hon
 
 
 @pytest.mark.parametrize("src", ["vl_gemm.hip", "vl_gemm_park.hip", "vl_attn.hip", "vl_attn_bwd.hip", "vl_rows.hip", "vl_loss.hip",
-                                 "vl_bwd.hip", "vl_points.hip", "vl_bn.hip"])
+                                 "vl_bwd.hip", "vl_points.hip", "vl_bn.hip", "vl_preproc.hip"])
 def test_no_spills(src, tmp_path):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):

@@ -1,0 +1,86 @@
+"""CPU: pins oracle/preproc_oracle.py (N3 preprocessing restatement) against the libraries the reference's transforms
+call - Pillow's 8-bit bicubic resampler (byte equality), torch's ToTensor / Normalize arithmetic (bit equality) and
+torch.nn.functional.interpolate(bicubic, antialias on/off) for the depth path."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import preproc_oracle as po  # noqa: E402
+
+Image = pytest.importorskip("PIL.Image")
+
+SIZES = [(37, 53, 24, 31), (240, 320, 224, 298), (500, 375, 298, 224), (224, 224, 224, 224), (64, 48, 224, 168),
+         (231, 517, 100, 224), (1000, 30, 400, 12), (300, 300, 299, 301)]
+
+
+@pytest.mark.parametrize("h,w,oh,ow", SIZES)
+def test_pil_bicubic_resize_is_byte_exact(h, w, oh, ow):
+    rng = np.random.default_rng(h * 1000 + w)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    if h == 37:
+        img[:, ::2] = 255; img[:, 1::2] = 0                           # ringing: exercises the clip to [0, 255]
+    want = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BICUBIC))
+    got = po.pil_resize_bicubic_u8(img, ow, oh)
+    assert got.dtype == np.uint8 and np.array_equal(got, want)
+
+
+def test_pil_resize_with_box_is_byte_exact():
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (180, 260, 3), dtype=np.uint8)
+    box = (17, 9, 201, 150)                                            # RandomResizedCrop = crop, then resize
+    want = np.asarray(Image.fromarray(img).crop(box).resize((224, 224), Image.BICUBIC))
+    got = po.pil_resize_bicubic_u8(img[9:150, 17:201], 224, 224)
+    assert np.array_equal(got, want)
+
+
+def test_to_tensor_normalize_matches_torch_bitwise():
+    from open_clip.constants import OPENAI_DATASET_MEAN, OPENAI_DATASET_STD
+    u8 = np.arange(256, dtype=np.uint8).reshape(16, 16, 1).repeat(3, 2)
+    t = torch.from_numpy(u8).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+    mean = torch.as_tensor(OPENAI_DATASET_MEAN, dtype=torch.float32)[:, None, None]
+    std = torch.as_tensor(OPENAI_DATASET_STD, dtype=torch.float32)[:, None, None]
+    want = t.sub_(mean).div_(std).numpy()
+    got = po.to_tensor_normalize(u8, OPENAI_DATASET_MEAN, OPENAI_DATASET_STD)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("h,w", [(240, 320), (530, 730), (224, 300), (100, 80)])
+def test_image_eval_transform_matches_pil_pipeline(h, w):
+    from open_clip.constants import OPENAI_DATASET_MEAN, OPENAI_DATASET_STD
+    rng = np.random.default_rng(h + w)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    nh, nw = po.resized_output_size(h, w, 224)
+    pil = Image.fromarray(img).resize((nw, nh), Image.BICUBIC)
+    top, left = po.center_crop_origin(nh, nw, 224)
+    pil = pil.crop((left, top, left + 224, top + 224)).convert("RGB")
+    t = torch.from_numpy(np.asarray(pil)).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+    want = t.sub_(torch.as_tensor(OPENAI_DATASET_MEAN)[:, None, None]).div_(torch.as_tensor(OPENAI_DATASET_STD)[:, None, None])
+    got = po.image_eval_transform(img, 224, OPENAI_DATASET_MEAN, OPENAI_DATASET_STD)
+    assert got.shape == (3, 224, 224) and np.array_equal(got, want.numpy())
+
+
+@pytest.mark.parametrize("antialias", [True, False])
+@pytest.mark.parametrize("h,w,oh,ow", [(530, 730, 224, 308), (120, 90, 298, 224), (224, 224, 224, 224), (61, 47, 20, 33)])
+def test_float_bicubic_matches_torch_interpolate(h, w, oh, ow, antialias):
+    g = torch.Generator().manual_seed(h)
+    x = torch.rand(h, w, generator=g)
+    want = torch.nn.functional.interpolate(x[None, None], (oh, ow), mode="bicubic", align_corners=False, antialias=antialias)[0, 0]
+    got = po.resize_bicubic_f32(x.numpy(), oh, ow, antialias)
+    assert np.abs(got - want.numpy()).max() < 2e-6
+
+
+def test_depth_eval_transform_matches_the_torch_pipeline():
+    g = torch.Generator().manual_seed(3)
+    d = torch.rand(427, 561, generator=g) * 90 - 2                     # values below min_depth and above max_depth
+    x = d.clamp(min=0.01).clamp(max=75.0) / 75.0
+    nh, nw = po.resized_output_size(427, 561, 224)
+    r = torch.nn.functional.interpolate(x[None, None], (nh, nw), mode="bicubic", align_corners=False, antialias=True)[0, 0]
+    top, left = po.center_crop_origin(nh, nw, 224)
+    want = (r[top:top + 224, left:left + 224] - 0.0418) / 0.0295
+    got = po.depth_eval_transform(d.numpy())
+    assert got.shape == (1, 224, 224) and np.abs(got[0] - want.numpy()).max() < 1e-4

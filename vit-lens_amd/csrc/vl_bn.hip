@@ -8,6 +8,11 @@
 //   vl_bn_apply        y = gamma*(x-mean)*rstd + beta, optional ReLU, bf16 out
 //   vl_bn_bwd          dgamma += sum dy'*xhat, dbeta += sum dy'; dx = gamma*rstd*(dy' - [train](mean(dy') + xhat*mean(dy'*xhat)))
 //                      with dy' = dy * (y > 0) when the ReLU is fused
+//   vl_bn_stats_local / vl_bn_stats_merge / vl_bn_bwd_reduce / vl_bn_bwd_apply
+//                      the same two passes split at the point where SyncBatchNorm exchanges data between ranks
+//                      (torch.nn.SyncBatchNorm, enabled by --use-bn-sync: training/point_cloud/pc_tri_main.py:372-373):
+//                      forward = all-gather of per-rank (mean, M2, count) then a Chan merge in rank order; backward =
+//                      all-reduce of (sum dy', sum dy'*xhat) then the elementwise pass with the global count
 //   vl_group_max_bwd   df = base + one_hot(argmax over the M rows of a group) * dg      (torch.max(dim) backward)
 //   vl_group_sum       out[g,:] = sum over the M rows of group g                          (backward of the expand)
 #include "vl_common.h"
@@ -65,6 +70,42 @@ __global__ void __launch_bounds__(256) bn_stats_finalize_kernel(const bf16_t* __
   if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(R > 1 ? v * R / (R - 1) : v);   // unbiased, as nn.BatchNorm1d
 }
 
+// per-rank statistics for SyncBN: local[c] = mean, local[C+c] = M2 = sum (x - mean)^2, local[2C] = row count (int bits)
+__global__ void __launch_bounds__(256) bn_local_finalize_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ws, int nchunk,
+                                                                int R, int C, float* __restrict__ local) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c == 0) local[2 * C] = __builtin_bit_cast(float, R);
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nchunk; ++k) { s1 += ws[((long)k * 2) * C + c]; s2 += ws[((long)k * 2 + 1) * C + c]; }
+  const double m = s1 / R;
+  local[c] = (float)(m + (double)bf2f(x[c]));
+  local[C + c] = (float)fmax(s2 - s1 * m, 0.0);
+}
+
+// Chan et al. pairwise merge of the ranks' (count, mean, M2) in rank order: every rank computes the same bits
+__global__ void __launch_bounds__(256) bn_merge_kernel(const float* __restrict__ gathered, int W, int C, float* mean, float* var,
+                                                       float* rmean, float* rvar, float momentum, int* total) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const long ld = 2L * C + 1;
+  double n = 0.0, mu = 0.0, m2 = 0.0;
+  for (int r = 0; r < W; ++r) {
+    const float* g = gathered + r * ld;
+    const double nk = (double)__builtin_bit_cast(int, g[2 * C]);
+    if (nk <= 0.0) continue;
+    const double d = (double)g[c] - mu, nn = n + nk;
+    mu += d * (nk / nn);
+    m2 += (double)g[C + c] + d * d * (n * nk / nn);
+    n = nn;
+  }
+  const double v = n > 0.0 ? m2 / n : 0.0;
+  mean[c] = (float)mu; var[c] = (float)v;
+  if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mu;
+  if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(n > 1.0 ? m2 / (n - 1.0) : v);
+  if (c == 0 && total) *total = (int)n;
+}
+
 // ------------------------------------------------------------------------------------------------ apply
 __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ mean,
                                                        const float* __restrict__ var, const float* __restrict__ gamma,
@@ -101,6 +142,9 @@ struct BnBwdP {
   float* ws; int nchunk, rows_per_chunk;
   float* dgamma; float* dbeta;
   bf16_t* dx; long lddx; int R, C;
+  const float* fin;        // [2C]: what the elementwise pass subtracts - the two means, or (SyncBN) the two global sums
+  const int* total;        // SyncBN: device pointer to the global row count (fin holds sums), else NULL
+  float* sums;             // SyncBN reduce pass: raw local sums out [2C], else NULL
 };
 
 __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const BnBwdP p) {
@@ -146,6 +190,7 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const BnBwdP p) {
   for (int k = 0; k < p.nchunk; ++k) { s1 += p.ws[((long)k * 2) * p.C + c]; s2 += p.ws[((long)k * 2 + 1) * p.C + c]; }
   if (p.dbeta) p.dbeta[c] += (float)s1;
   if (p.dgamma) p.dgamma[c] += (float)s2;
+  if (p.sums) { p.sums[c] = (float)s1; p.sums[p.C + c] = (float)s2; return; }
   float* fin = p.ws + (long)p.nchunk * 2 * p.C;
   fin[c] = p.train ? (float)(s1 / p.R) : 0.f;
   fin[p.C + c] = p.train ? (float)(s2 / p.R) : 0.f;
@@ -156,7 +201,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnBwdP p) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)p.R * c8) return;
   const long r = i / c8; const int c = (int)(i - r * c8) * 8;
-  const float* fin = p.ws + (long)p.nchunk * 2 * p.C;
+  const float* fin = p.fin;
+  const float inv_n = p.total ? 1.0f / (float)*p.total : 1.0f;
   const u32x4 xv = *(const u32x4*)(p.x + r * p.ldx + c);
   const u32x4 dv = *(const u32x4*)(p.dy + r * p.lddy + c);
   u32x4 o;
@@ -170,7 +216,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnBwdP p) {
       const float xh = (bf2f((bf16_t)(h ? (xv[k] >> 16) : (xv[k] & 0xffff))) - p.mean[cc]) * rs;
       float d = bf2f((bf16_t)(h ? (dv[k] >> 16) : (dv[k] & 0xffff)));
       if (p.relu && fmaf(xh, g, p.beta[cc]) <= 0.f) d = 0.f;
-      y[h] = g * rs * (d - fin[cc] - xh * fin[p.C + cc]);
+      y[h] = g * rs * (d - fin[cc] * inv_n - xh * (fin[p.C + cc] * inv_n));
     }
     o[k] = pack2bf(y[0], y[1]);
   }
@@ -254,10 +300,53 @@ extern "C" int vl_bn_bwd(const void* dy, long lddy, const void* x, long ldx, con
   if (!ws_shape_ok(R, nchunk) || C <= 0 || (C & 7) || (ldx & 7) || (lddy & 7) || (lddx & 7))
     return vl_set_error("vl_bn_bwd: C and strides must be multiples of 8, 1<=nchunk<=65535");
   BnBwdP p{(const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean, var, gamma, beta, eps, relu, train, ws, nchunk,
-           (R + nchunk - 1) / nchunk, dgamma, dbeta, (bf16_t*)dx, lddx, R, C};
+           (R + nchunk - 1) / nchunk, dgamma, dbeta, (bf16_t*)dx, lddx, R, C, ws + (long)nchunk * 2 * C, nullptr, nullptr};
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((C + 127) / 128, nchunk), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, p);
   if (dx) hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid1((long)R * (C >> 3))), dim3(256), 0, stream, p);
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vl_bn_stats_local(const void* x, long ldx, int R, int C, float* ws, int nchunk, float* local, hipStream_t stream) {
+  if (!ws_shape_ok(R, nchunk) || C <= 0 || (C & 1) || (ldx & 1)) return vl_set_error("vl_bn_stats_local: need R>=1, even C and ldx, 1<=nchunk<=65535");
+  const int rpc = (R + nchunk - 1) / nchunk;
+  hipLaunchKernelGGL(bn_partial_kernel, dim3((C + 127) / 128, nchunk), dim3(256), 0, stream, (const bf16_t*)x, ldx, R, C, rpc, ws);
+  hipLaunchKernelGGL(bn_local_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const bf16_t*)x, ws, nchunk, R, C, local);
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vl_bn_stats_merge(const float* gathered, int W, int C, float* mean, float* var, float* running_mean,
+                                 float* running_var, float momentum, int* total, hipStream_t stream) {
+  if (W <= 0 || C <= 0) return vl_set_error("vl_bn_stats_merge: need W >= 1 and C >= 1");
+  hipLaunchKernelGGL(bn_merge_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, gathered, W, C, mean, var, running_mean, running_var,
+                     momentum, total);
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vl_bn_bwd_reduce(const void* dy, long lddy, const void* x, long ldx, const float* mean, const float* var,
+                                const float* gamma, const float* beta, float eps, int relu, float* ws, int nchunk, float* dgamma,
+                                float* dbeta, float* sums, int R, int C, hipStream_t stream) {
+  if (!ws_shape_ok(R, nchunk) || C <= 0 || (C & 7) || (ldx & 7) || (lddy & 7) || !sums)
+    return vl_set_error("vl_bn_bwd_reduce: C and strides must be multiples of 8, 1<=nchunk<=65535, sums required");
+  BnBwdP p{(const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean, var, gamma, beta, eps, relu, 1, ws, nchunk,
+           (R + nchunk - 1) / nchunk, dgamma, dbeta, nullptr, 0, R, C, nullptr, nullptr, sums};
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((C + 127) / 128, nchunk), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, p);
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vl_bn_bwd_apply(const void* dy, long lddy, const void* x, long ldx, const float* mean, const float* var,
+                               const float* gamma, const float* beta, float eps, int relu, const float* sums, const int* total,
+                               void* dx, long lddx, int R, int C, hipStream_t stream) {
+  if (R <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (lddy & 7) || (lddx & 7) || !sums || !total || !dx)
+    return vl_set_error("vl_bn_bwd_apply: C and strides must be multiples of 8; sums, total and dx required");
+  BnBwdP p{(const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean, var, gamma, beta, eps, relu, 1, nullptr, 0, 0, nullptr, nullptr,
+           (bf16_t*)dx, lddx, R, C, sums, total, nullptr};
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid1((long)R * (C >> 3))), dim3(256), 0, stream, p);
   VL_HIP_OK(hipGetLastError());
   return 0;
 }

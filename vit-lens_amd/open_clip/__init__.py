@@ -6,5 +6,6 @@ from .factory import (add_model_config, create_loss, get_model_config, get_token
 from .loss import ClipLoss, ClipLossGeneral, TriClipLoss, gather_features
 from .model import CLIPTextCfg, CLIPVisionCfg, TriCLIP
 from .tokenizer import SimpleTokenizer, decode, tokenize
+from .transform import AugmentationCfg, image_transform
 from .utils import all_gather, concat_all_gather, scaled_all_reduce
 from .zero_shot_classifier import accuracy, build_zero_shot_classifier, zero_shot_logits

@@ -167,14 +167,21 @@ def tri_create_model_and_transforms(model_name: str, pretrained: Optional[str] =
                                     force_patch_dropout=None, force_image_size=None, pretrained_image=False,
                                     pretrained_hf=True, load_ckpt_strict=False, image_mean=None, image_std=None,
                                     aug_cfg=None, cache_dir=None, output_dict=None, args=None):
-    """Returns (model, preprocess_train, preprocess_val); the torchvision transforms are host-side data
-    plumbing outside the hot path, so the preprocess slots are None (synthetic / pre-normalised tensors)."""
+    """Returns (model, preprocess_train, preprocess_val) (factory.py:372-424); the two transforms are the on-GPU
+    `image_transform`s of open_clip/transform.py (Pillow-exact bicubic resize + crop + normalise on the model's device)."""
     model = tri_create_model(model_name, pretrained, precision=precision, device=device, jit=jit,
                              force_quick_gelu=force_quick_gelu, force_custom_text=force_custom_text,
                              force_patch_dropout=force_patch_dropout, force_image_size=force_image_size,
                              pretrained_image=pretrained_image, pretrained_hf=pretrained_hf, cache_dir=cache_dir,
                              output_dict=output_dict, strict=load_ckpt_strict, args=args)
-    return model, None, None
+    from .transform import image_transform
+    image_mean = image_mean or getattr(model.image, "image_mean", None)
+    image_std = image_std or getattr(model.image, "image_std", None)
+    size = model.image.cfg.image_size
+    tdev = device if torch.device(device).type == "cuda" else "cuda"
+    preprocess_train = image_transform(size, is_train=True, mean=image_mean, std=image_std, aug_cfg=aug_cfg, device=tdev)
+    preprocess_val = image_transform(size, is_train=False, mean=image_mean, std=image_std, device=tdev)
+    return model, preprocess_train, preprocess_val
 
 
 def create_loss(args):

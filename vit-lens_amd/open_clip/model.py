@@ -187,6 +187,25 @@ class VisionTransformer(nn.Module):
         self._engine_key = None
         self._trainer_obj, self._trainer_key, self._gen = None, None, 0
         self._freeze_bn = False
+        self._bn_sync = None          # (communicator, world size) once set_bn_sync(True) was called in a multi-rank job
+
+    def set_bn_sync(self, enabled=True, comm=None, world_size=None):
+        """Counterpart of `torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)` (--use-bn-sync, e.g.
+        training/point_cloud/pc_tri_main.py:372-373) for this tower: its BatchNorm layers (the PointBERT mini-PointNet
+        only) take their batch statistics and backward sums over all ranks of `torch.distributed` (or of `comm`, any
+        object with all_gather / all_reduce_sum).  A no-op for towers without BatchNorm and in single-process runs."""
+        if not enabled or self.modality != "pc":
+            self._bn_sync = None
+            return self
+        if comm is None:
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+                self._bn_sync = None
+                return self
+            from vitlens_hip.step import TorchComm
+            comm, world_size = TorchComm(), dist.get_world_size()
+        self._bn_sync = (comm, int(world_size))
+        return self
 
     # -------------------------------------------------------------------------------------- lock recipes
     def lock(self, unlocked_groups=0, freeze_bn_stats=False, unlock_cls=False, unlock_pos_emb=False,
@@ -288,7 +307,7 @@ class VisionTransformer(nn.Module):
         blocks = tuple(sorted({int(n.split(".")[2]) for n in req if n.startswith("transformer.resblocks.")}))
         return (blocks, "class_embedding" in req, "positional_embedding" in req, any(n.startswith("ln_pre.") for n in req),
                 any(n.startswith("ln_post.") for n in req), "proj" in req, "conv1.weight" in req,
-                self.training and not self._freeze_bn)
+                self.training and not self._freeze_bn, self._bn_sync is not None)
 
     def _trainer(self):
         """Forward-with-saved-activations / backward executor for the current lock recipe (vitlens_hip.train), bound to
@@ -298,7 +317,7 @@ class VisionTransformer(nn.Module):
         flags = self._train_flags()
         key = (id(eng), flags)
         if self._trainer_obj is None or key != self._trainer_key:
-            blocks, cls, pos, lpre, lpost, proj, conv, bn_train = flags
+            blocks, cls, pos, lpre, lpost, proj, conv, bn_train, _ = flags
             kw = dict(train_blocks=blocks, train_cls=cls, train_pos=pos, train_ln_pre=lpre, train_ln_post=lpost, train_proj=proj)
             if self.modality in ("image", "tactile"):
                 tr = T.ImageTowerTrainer(eng, kw, train_conv=conv)
@@ -311,7 +330,9 @@ class VisionTransformer(nn.Module):
             elif self.modality == "pc" and not self.perceiver_identity:
                 from vitlens_hip.points import PointTokenizerTrainer
                 sd = {("t." + k): v for k, v in self.state_dict().items() if k.startswith("visual_adapter.")}
-                tok = PointTokenizerTrainer(sd, "t.visual_adapter.", eng.lens, eng.device, bn_training=bn_train)
+                sync = self._bn_sync or (None, 1)
+                tok = PointTokenizerTrainer(sd, "t.visual_adapter.", eng.lens, eng.device, bn_training=bn_train, bn_sync=sync[0],
+                                            world_size=sync[1])
                 tr = T.PCLensTrainer(eng, tok, tower_kw=kw)
             else:
                 raise NotImplementedError(f"training recipe for modality {self.modality!r} "

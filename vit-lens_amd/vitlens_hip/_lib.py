@@ -41,10 +41,18 @@ SIGNATURES = {
     "vl_gemm_bf16_ex": [P, P, P, P, P, P, I, I, I, I, I, I, F, I, I, I, I, P],
     "vl_fps": [P, P, P, P, I, I, I, P],
     "vl_pc_gather_normalize": [P, P, P, I, I, I, I, P],
+    "vl_resample_h_u8": [P, L, I, I, I, P, P, I, I, I, P, P],
+    "vl_resample_v_u8_norm": [P, I, I, I, P, P, I, I, I, P, P, P, P, P],
+    "vl_resample_h_f32": [P, L, I, I, I, P, P, I, I, I, I, F, F, F, P, P],
+    "vl_resample_v_f32_norm": [P, I, I, I, P, P, I, I, I, F, F, P, P],
     "vl_knn_group": [P, P, P, P, I, I, I, I, I, P],
     "vl_group_max": [P, L, P, I, L, L, I, I, P],
     "vl_pad3_bf16": [P, P, L, I, P],
     "vl_bn_stats": [P, L, I, I, P, I, P, P, P, P, F, P],
+    "vl_bn_stats_local": [P, L, I, I, P, I, P, P],
+    "vl_bn_stats_merge": [P, I, I, P, P, P, P, F, P, P],
+    "vl_bn_bwd_reduce": [P, L, P, L, P, P, P, P, F, I, P, I, P, P, P, I, I, P],
+    "vl_bn_bwd_apply": [P, L, P, L, P, P, P, P, F, I, P, P, P, L, I, I, P],
     "vl_bn_apply": [P, L, P, P, P, P, F, I, P, L, L, I, P],
     "vl_bn_bwd": [P, L, P, L, P, P, P, P, F, I, I, P, I, P, P, P, L, I, I, P],
     "vl_group_max_bwd": [P, L, P, L, P, L, P, L, L, I, I, P],

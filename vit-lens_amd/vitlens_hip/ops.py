@@ -444,6 +444,52 @@ def bn_bwd(dy, x, mean, var, gamma, beta, dgamma, dbeta, eps=1e-5, relu=False, t
     return dx
 
 
+# ---- SyncBatchNorm: the statistics / backward passes split where the ranks exchange data (csrc/vl_bn.hip) ----
+def bn_stats_local(x):
+    """This rank's share of the batch statistics of x [R,C] bf16 -> f32 [2C+1]: mean, M2, row count (int bits)."""
+    _chk2d(x, "x", torch.bfloat16)
+    R, C = x.shape
+    n = _bn_chunks(R)
+    ws = torch.empty((n + 1) * 2 * C, device=x.device, dtype=torch.float32)
+    local = torch.empty(2 * C + 1, device=x.device, dtype=torch.float32)
+    check(_lib.vl_bn_stats_local(_p(x), x.stride(0), R, C, _p(ws), n, _p(local), _stream()))
+    return local
+
+
+def bn_stats_merge(gathered, running_mean=None, running_var=None, momentum=0.1):
+    """gathered f32 [W, 2C+1] (all ranks' bn_stats_local) -> (mean, biased var, total) with total an int32 [1] tensor
+    holding the global row count; running statistics updated with the global unbiased variance."""
+    W, n = gathered.shape
+    Cc = (n - 1) // 2
+    mean = torch.empty(Cc, device=gathered.device, dtype=torch.float32); var = torch.empty_like(mean)
+    total = torch.empty(1, device=gathered.device, dtype=torch.int32)
+    check(_lib.vl_bn_stats_merge(_p(gathered.contiguous()), W, Cc, _p(mean), _p(var), _p(running_mean), _p(running_var), momentum,
+                                 _p(total), _stream()))
+    return mean, var, total
+
+
+def bn_bwd_reduce(dy, x, mean, var, gamma, beta, dgamma, dbeta, eps=1e-5, relu=False):
+    """dgamma/dbeta accumulated (local sums, as SyncBatchNorm); returns sums f32 [2C] = (sum dy', sum dy'*xhat) to all-reduce."""
+    _chk2d(dy, "dy", torch.bfloat16); _chk2d(x, "x", torch.bfloat16)
+    R, C = x.shape
+    n = _bn_chunks(R)
+    ws = torch.empty((n + 1) * 2 * C, device=x.device, dtype=torch.float32)
+    sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+    check(_lib.vl_bn_bwd_reduce(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(mean), _p(var), _p(gamma), _p(beta), eps, int(relu),
+                                _p(ws), n, _p(dgamma), _p(dbeta), _p(sums), R, C, _stream()))
+    return sums
+
+
+def bn_bwd_apply(dy, x, mean, var, gamma, beta, sums, total, eps=1e-5, relu=False):
+    """dx bf16 [R,C] from the globally summed `sums` and the global row count `total` (int32 [1] on the device)."""
+    _chk2d(dy, "dy", torch.bfloat16); _chk2d(x, "x", torch.bfloat16)
+    R, C = x.shape
+    dx = torch.empty_like(x)
+    check(_lib.vl_bn_bwd_apply(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(mean), _p(var), _p(gamma), _p(beta), eps, int(relu),
+                               _p(sums), _p(total), _p(dx), dx.stride(0), R, C, _stream()))
+    return dx
+
+
 def group_max_bwd(f, dg, M, base=None):
     _chk2d(f, "f", torch.bfloat16); _chk2d(dg, "dg", torch.bfloat16)
     out = torch.empty_like(f)

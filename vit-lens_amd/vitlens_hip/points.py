@@ -80,8 +80,11 @@ class PointTokenizerTrainer:
     KP = 64
     BN_EPS, BN_MOMENTUM = 1e-5, 0.1           # nn.BatchNorm1d defaults (dvae.py:186,191)
 
-    def __init__(self, sd, a: str, lens, device, grads=None, gemm_cfg=-1, bn_training=True):
+    def __init__(self, sd, a: str, lens, device, grads=None, gemm_cfg=-1, bn_training=True, bn_sync=None, world_size=1):
+        """bn_sync: a communicator (all_gather / all_reduce_sum, e.g. step.TorchComm) turns the two BatchNorm layers into
+        SyncBatchNorm over `world_size` ranks (--use-bn-sync); None = per-rank statistics, the reference's default."""
         self.a, self.lens, self.device, self.cfg, self.bn_training = a, lens, torch.device(device), gemm_cfg, bn_training
+        self.bn_sync, self.world = bn_sync, world_size
         self.grads = {} if grads is None else grads
         f32 = lambda k: sd[a + k].detach().float().to(device).contiguous().clone()      # masters never alias the caller's tensors
         m = self.masters = {}
@@ -124,13 +127,31 @@ class PointTokenizerTrainer:
 
     def _bn(self, z, k):
         a, m = self.a, self.masters
-        if self.bn_training:
+        total = None
+        if self.bn_training and self.bn_sync is not None:
+            rm, rv = self.running[k]
+            local = ops.bn_stats_local(z)
+            gathered = torch.empty(self.world, local.numel(), device=self.device, dtype=torch.float32)
+            self.bn_sync.all_gather(gathered.view(-1), local)
+            mean, var, total = ops.bn_stats_merge(gathered, rm, rv, self.BN_MOMENTUM)
+        elif self.bn_training:
             rm, rv = self.running[k]
             mean, var = ops.bn_stats(z, rm, rv, self.BN_MOMENTUM)
         else:
             mean, var = self.running[k]
         h = ops.bn_apply(z, mean, var, m[a + k + ".weight"], m[a + k + ".bias"], self.BN_EPS, relu=True)
-        return h, mean, var
+        return h, (mean, var, total)
+
+    def _bn_bwd(self, dh, z, stats, k):
+        a, m = self.a, self.masters
+        mean, var, total = stats
+        args = (dh, z, mean, var, m[a + k + ".weight"], m[a + k + ".bias"])
+        if total is None:
+            return ops.bn_bwd(*args, self.grad_buffer(a + k + ".weight"), self.grad_buffer(a + k + ".bias"), self.BN_EPS, relu=True,
+                              train=self.bn_training)
+        sums = ops.bn_bwd_reduce(*args, self.grad_buffer(a + k + ".weight"), self.grad_buffer(a + k + ".bias"), self.BN_EPS, relu=True)
+        self.bn_sync.all_reduce_sum(sums)
+        return ops.bn_bwd_apply(*args, sums, total, self.BN_EPS, relu=True)
 
     def forward(self, pts: torch.Tensor, fps_start=None) -> torch.Tensor:
         """pts [B,N,3] -> tokens + pos, bf16 [B*G, trans_dim]."""
@@ -142,13 +163,13 @@ class PointTokenizerTrainer:
         cidx, centers = ops.fps(pts, fps_start.to(self.device), L.pc_num_group)
         patches, _ = ops.knn_group(pts, cidx, L.pc_group_size, Kp=self.KP)
         z1 = ops.gemm(patches, o["w1"], m[a + "encoder.first_conv.0.bias"], cfg=c)
-        h1, m1, v1 = self._bn(z1, "encoder.first_conv.1")
+        h1, s1 = self._bn(z1, "encoder.first_conv.1")
         f = ops.gemm(h1, o["w2"], m[a + "encoder.first_conv.3.bias"], cfg=c)
         g = ops.group_max(f, M)
         t = ops.gemm(g, o["w3g"], m[a + "encoder.second_conv.0.bias"], cfg=c)
         z3 = torch.empty(f.shape[0], o["w3l"].shape[0], device=self.device, dtype=BF)
         ops.gemm(f, o["w3l"], None, out=z3, res=t, res_div=M, epi=ops.EPI_RES_BF16, cfg=c)
-        h2, m3, v3 = self._bn(z3, "encoder.second_conv.1")
+        h2, s3 = self._bn(z3, "encoder.second_conv.1")
         f2 = ops.gemm(h2, o["w4"], m[a + "encoder.second_conv.3.bias"], cfg=c)
         g2 = ops.group_max(f2, M)
         tok = ops.gemm(g2, o["wr"], m[a + "reduce_dim.bias"], cfg=c)
@@ -157,7 +178,7 @@ class PointTokenizerTrainer:
         p1 = ops.gemm(c3, o["wp0"], m[a + "pos_embed.0.bias"], act=ops.ACT_GELU, cfg=c, out2=u)
         out = torch.empty_like(tok)
         ops.gemm(p1, o["wp2"], m[a + "pos_embed.2.bias"], out=out, res=tok, epi=ops.EPI_RES_BF16, cfg=c)
-        self.ctx = (patches, z1, m1, v1, h1, f, g, z3, m3, v3, h2, f2, g2, c3, u, p1)
+        self.ctx = (patches, z1, s1[0], s1[1], h1, f, g, z3, s3[0], s3[1], h2, f2, g2, c3, u, p1, s1[2], s3[2])
         return out
 
     def _dw(self, name, dy, x, cols=None):
@@ -179,9 +200,8 @@ class PointTokenizerTrainer:
         """dctx f32|bf16 [B*G, trans_dim] = gradient w.r.t. the returned tokens+pos."""
         L, a, m, o, c = self.lens, self.a, self.masters, self.op, self.cfg
         M = L.pc_group_size
-        patches, z1, m1, v1, h1, f, g, z3, m3, v3, h2, f2, g2, c3, u, p1 = self.ctx
+        patches, z1, m1, v1, h1, f, g, z3, m3, v3, h2, f2, g2, c3, u, p1, t1, t3 = self.ctx
         dout = dctx if dctx.dtype == BF else ops.cast_bf16(dctx.contiguous())
-        tr = self.bn_training
         # positional MLP: pos = W2 gelu(W0 c + b0) + b2
         self._dw(a + "pos_embed.2.weight", dout, p1); self._db(a + "pos_embed.2.bias", dout)
         du = torch.empty_like(u)
@@ -193,9 +213,7 @@ class PointTokenizerTrainer:
         df2 = ops.group_max_bwd(f2, dg2, M)
         self._dw(a + "encoder.second_conv.3.weight", df2, h2); self._db(a + "encoder.second_conv.3.bias", df2)
         dh2 = ops.gemm(df2, o["w4T"], None, cfg=c)
-        k = "encoder.second_conv.1"
-        dz3 = ops.bn_bwd(dh2, z3, m3, v3, m[a + k + ".weight"], m[a + k + ".bias"], self.grad_buffer(a + k + ".weight"),
-                         self.grad_buffer(a + k + ".bias"), self.BN_EPS, relu=True, train=tr)
+        dz3 = self._bn_bwd(dh2, z3, (m3, v3, t3), "encoder.second_conv.1")
         dt = ops.group_sum(dz3, M)
         gw = self.grad_buffer(a + "encoder.second_conv.0.weight")
         half = gw.shape[1] // 2
@@ -209,7 +227,5 @@ class PointTokenizerTrainer:
         df = ops.group_max_bwd(f, dg, M, base=dfl)
         self._dw(a + "encoder.first_conv.3.weight", df, h1); self._db(a + "encoder.first_conv.3.bias", df)
         dh1 = ops.gemm(df, o["w2T"], None, cfg=c)
-        k = "encoder.first_conv.1"
-        dz1 = ops.bn_bwd(dh1, z1, m1, v1, m[a + k + ".weight"], m[a + k + ".bias"], self.grad_buffer(a + k + ".weight"),
-                         self.grad_buffer(a + k + ".bias"), self.BN_EPS, relu=True, train=tr)
+        dz1 = self._bn_bwd(dh1, z1, (m1, v1, t1), "encoder.first_conv.1")
         self._dw(a + "encoder.first_conv.0.weight", dz1, patches, cols=3); self._db(a + "encoder.first_conv.0.bias", dz1)

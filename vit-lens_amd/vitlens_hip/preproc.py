@@ -1,0 +1,187 @@
+"""Host side of the on-GPU image / depth preprocessing (kernels in csrc/vl_preproc.hip).
+
+The resamplers are table driven: per output index of a resized axis a first tap, a tap count and the coefficients.
+The tables depend only on (input size, output size), so they are built once on the host - exactly where Pillow and
+ATen build theirs - cached, and kept on the device.
+
+  * `pil_bicubic_tables`  = Pillow `Resample.c:precompute_coeffs` + `normalize_coeffs_8bpc` (double precision, Keys
+    kernel a = -0.5, support scaled when shrinking, 22-bit fixed point rounded half away from zero);
+  * `aten_bicubic_tables` = ATen `UpSampleKernel.cpp` weights: antialiased (`_compute_indices_min_size_weights_aa`,
+    float32, a = -0.5, normalised) or plain (`get_cubic_upsample_coefficients`, a = -0.75, 4 taps from floor(src) - 1,
+    border-clamped in the kernel).
+
+`image_to_tensor` / `depth_to_tensor` run Resize(shorter edge) -> CenterCrop -> Normalize restricted to the crop
+window (torchvision `_compute_resized_output_size`, `center_crop`); see open_clip/transform.py and
+open_clip/modal_depth/processors/vt_processor.py for the reference-facing classes."""
+import ctypes
+import functools
+import math
+
+import numpy as np
+import torch
+
+PRECISION_BITS = 32 - 8 - 2
+
+
+def resized_output_size(h, w, size):
+    """Resize(int): shorter edge -> size, longer = int(size * long / short) (torchvision functional.resize)."""
+    short, long = (w, h) if w <= h else (h, w)
+    new_long = int(size * long / short)
+    return (new_long, size) if w <= h else (size, new_long)
+
+
+def center_crop_origin(h, w, size):
+    return int(round((h - size) / 2.0)), int(round((w - size) / 2.0))
+
+
+def _keys(x, a):
+    x = np.abs(x)
+    near = ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    far = (((x - 5) * x + 8) * x - 4) * a
+    return np.where(x < 1.0, near, np.where(x < 2.0, far, 0.0))
+
+
+@functools.lru_cache(maxsize=256)
+def pil_bicubic_tables(in_size, out_size, in0=0.0, in1=None):
+    """-> (bounds [out,2] int32, kk [out,ksize] int32, ksize); operation order as in Resample.c so that every double
+    is the one Pillow computes (the row sum is a left-to-right running sum)."""
+    in1 = float(in_size) if in1 is None else float(in1)
+    scale = (in1 - in0) / out_size
+    filterscale = scale if scale >= 1.0 else 1.0
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    ss = 1.0 / filterscale
+    center = in0 + (np.arange(out_size, dtype=np.float64) + 0.5) * scale
+    xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)               # C cast: truncation (values >= -1.5 -> ok)
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size) - xmin
+    j = np.arange(ksize, dtype=np.int64)[None, :]
+    w = _keys(((j + xmin[:, None]).astype(np.float64) - center[:, None] + 0.5) * ss, -0.5)
+    w = np.where(j < xmax[:, None], w, 0.0)
+    ww = np.cumsum(w, axis=1)[:, -1:]                                             # sequential, as the C loop
+    w = np.where(ww != 0.0, w / np.where(ww != 0.0, ww, 1.0), w)
+    fx = w * float(1 << PRECISION_BITS)
+    kk = np.where(w < 0, (-0.5 + fx).astype(np.int64), (0.5 + fx).astype(np.int64)).astype(np.int32)   # (int) truncates
+    kk = np.where(j < xmax[:, None], kk, 0).astype(np.int32)
+    bounds = np.stack([xmin, xmax], 1).astype(np.int32)
+    return bounds, kk, ksize
+
+
+@functools.lru_cache(maxsize=256)
+def aten_bicubic_tables(in_size, out_size, antialias=True):
+    """-> (bounds [out,2] int32, weights [out,ksize] float32, ksize) in float32 arithmetic, as ATen for a float input."""
+    f = np.float32
+    scale = f(in_size) / f(out_size)
+    i = np.arange(out_size, dtype=np.float32)
+    if antialias:
+        support = f(2.0) * scale if scale >= 1.0 else f(2.0)
+        invscale = f(1.0) / scale if scale >= 1.0 else f(1.0)
+        ksize = int(math.ceil(float(support))) * 2 + 1
+        center = scale * (i + f(0.5))
+        xmin = np.maximum((center - support + f(0.5)).astype(np.int64), 0)
+        xsize = np.minimum((center + support + f(0.5)).astype(np.int64), in_size) - xmin
+        j = np.arange(ksize, dtype=np.int64)[None, :]
+        arg = (((j + xmin[:, None]).astype(np.float32) - center[:, None] + f(0.5)) * invscale).astype(np.float32)
+        w = _keys(arg.astype(np.float64), -0.5).astype(np.float32)
+        w = np.where(j < xsize[:, None], w, f(0.0)).astype(np.float32)
+        tot = np.cumsum(w, axis=1, dtype=np.float32)[:, -1:]
+        w = np.where(tot != 0, w / np.where(tot != 0, tot, f(1.0)), w).astype(np.float32)
+        return np.stack([xmin, xsize], 1).astype(np.int32), np.ascontiguousarray(w), ksize
+    A = -0.75
+    # ATen's AVX2 build contracts scale * (i + 0.5) - 0.5 into one fused multiply-subtract: a single rounding to float32
+    src = (np.float64(scale) * (np.arange(out_size, dtype=np.float64) + 0.5) - 0.5).astype(np.float32).astype(np.float64)
+    i0 = np.floor(src)
+    t = src - i0
+    c1 = lambda v: ((A + 2) * v - (A + 3)) * v * v + 1
+    c2 = lambda v: ((A * v - 5 * A) * v + 8 * A) * v - 4 * A
+    w = np.stack([c2(t + 1.0), c1(t), c1(1.0 - t), c2(2.0 - t)], 1).astype(np.float32)
+    bounds = np.stack([i0.astype(np.int64) - 1, np.full(out_size, 4, np.int64)], 1).astype(np.int32)
+    return bounds, np.ascontiguousarray(w), 4
+
+
+_DEVICE_TABLES = {}
+
+
+def _on_device(key, builder, device):
+    k = (key, str(device))
+    if k not in _DEVICE_TABLES:
+        bounds, coef, ksize = builder()
+        _DEVICE_TABLES[k] = (torch.from_numpy(bounds).to(device), torch.from_numpy(coef).to(device), ksize, bounds)
+    return _DEVICE_TABLES[k]
+
+
+def _window(bounds_host, first, count, limit):
+    """Source rows/cols touched by outputs [first, first+count): (lo, n) clamped to [0, limit)."""
+    b = bounds_host[first:first + count]
+    lo = max(int(b[:, 0].min()), 0)
+    hi = min(int((b[:, 0] + b[:, 1]).max()), limit)
+    return lo, hi - lo
+
+
+def _floats(vals):
+    return (ctypes.c_float * len(vals))(*[float(v) for v in vals])
+
+
+def image_to_tensor(img_u8, size, mean, std, out=None, box=None, want_u8=False):
+    """img_u8: uint8 [H, W, C] CUDA tensor (C = 1..4).  Resize(size, BICUBIC) -> CenterCrop(size) -> ToTensor ->
+    Normalize(mean, std) -> float32 [C, size, size] (written into `out` if given).
+    box = (top, left, height, width) with size = (out_h, out_w): RandomResizedCrop's crop-then-resize to exactly that
+    size (the caller draws the box).  want_u8: also return the resized uint8 crop [size, size, C]."""
+    from . import ops
+    assert img_u8.dtype == torch.uint8 and img_u8.dim() == 3 and img_u8.is_cuda
+    dev = img_u8.device
+    if box is not None:
+        top, left, bh, bw = box
+        img_u8 = img_u8[top:top + bh, left:left + bw]
+        oh, ow = size if isinstance(size, (tuple, list)) else (size, size)
+        nh, nw, ctop, cleft, ch, cw = oh, ow, 0, 0, oh, ow
+    else:
+        H, W = img_u8.shape[:2]
+        nh, nw = resized_output_size(H, W, size)
+        ctop, cleft = center_crop_origin(nh, nw, size)
+        ch = cw = size
+        if ctop < 0 or cleft < 0:
+            raise ValueError("image smaller than the crop after Resize: padding is not part of the evaluation transform")
+    H, W, C = img_u8.shape
+    if img_u8.stride(2) != 1 or img_u8.stride(1) != C:
+        img_u8 = img_u8.contiguous()
+    hb, hk, hks, hb_host = _on_device(("pil", W, nw), lambda: pil_bicubic_tables(W, nw), dev)
+    vb, vk, vks, vb_host = _on_device(("pil", H, nh), lambda: pil_bicubic_tables(H, nh), dev)
+    row0, nrows = _window(vb_host, ctop, ch, H)
+    tmp = torch.empty(nrows, cw, C, device=dev, dtype=torch.uint8)
+    ops.check(ops._lib.vl_resample_h_u8(ops._p(img_u8), img_u8.stride(0), C, row0, nrows, ops._p(hb), ops._p(hk), hks, cleft, cw,
+                                        ops._p(tmp), ops._stream()))
+    if out is None:
+        out = torch.empty(C, ch, cw, device=dev, dtype=torch.float32)
+    assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (C, ch, cw)
+    u8 = torch.empty(ch, cw, C, device=dev, dtype=torch.uint8) if want_u8 else None
+    ops.check(ops._lib.vl_resample_v_u8_norm(ops._p(tmp), cw, C, row0, ops._p(vb), ops._p(vk), vks, ctop, ch, _floats(mean), _floats(std),
+                                             ops._p(out), ops._p(u8), ops._stream()))
+    return (out, u8) if want_u8 else out
+
+
+def depth_to_tensor(depth, size, mean, std, clamp=None, antialias=True, out=None):
+    """depth: float32 [H, W] CUDA tensor.  clamp = (lo, hi, divide_by) = DepthNorm; Resize(size, bicubic) ->
+    CenterCrop(size) -> (x - mean) / std -> float32 [1, size, size]."""
+    from . import ops
+    assert depth.dtype == torch.float32 and depth.dim() == 2 and depth.is_cuda
+    dev = depth.device
+    if depth.stride(1) != 1:
+        depth = depth.contiguous()
+    H, W = depth.shape
+    nh, nw = resized_output_size(H, W, size)
+    ctop, cleft = center_crop_origin(nh, nw, size)
+    if ctop < 0 or cleft < 0:
+        raise ValueError("depth map smaller than the crop after Resize")
+    hb, hw, hks, _ = _on_device(("aten", W, nw, antialias), lambda: aten_bicubic_tables(W, nw, antialias), dev)
+    vb, vw, vks, vb_host = _on_device(("aten", H, nh, antialias), lambda: aten_bicubic_tables(H, nh, antialias), dev)
+    row0, nrows = _window(vb_host, ctop, size, H)
+    tmp = torch.empty(nrows, size, device=dev, dtype=torch.float32)
+    lo, hi, div = clamp if clamp is not None else (0.0, 0.0, 1.0)
+    ops.check(ops._lib.vl_resample_h_f32(ops._p(depth), depth.stride(0), W, row0, nrows, ops._p(hb), ops._p(hw), hks, cleft, size,
+                                         int(clamp is not None), float(lo), float(hi), float(div), ops._p(tmp), ops._stream()))
+    if out is None:
+        out = torch.empty(1, size, size, device=dev, dtype=torch.float32)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == size * size
+    ops.check(ops._lib.vl_resample_v_f32_norm(ops._p(tmp), size, H, row0, ops._p(vb), ops._p(vw), vks, ctop, size, float(mean),
+                                              float(std), ops._p(out), ops._stream()))
+    return out

@@ -589,20 +589,23 @@ class TriModalPCStep(_PerceiverLensStep):
     mm_vit_lens/model_cfg.py:85-110): image and text towers frozen, visual tower = PointBERT tokenizer (FPS -> kNN ->
     mini-PointNet with BatchNorm) + Perceiver, both trainable, in front of the locked ViT.  BatchNorm uses the batch
     statistics of each forward call (per micro-batch, per rank - SyncBN off, as the reference's default) and updates the
-    running statistics; `bn_training=False` freezes it at the running statistics (--lock-visual-freeze-bn-stats)."""
+    running statistics; `bn_training=False` freezes it at the running statistics (--lock-visual-freeze-bn-stats);
+    `bn_sync=True` (--use-bn-sync, pc_tri_main.py:372-373) makes the statistics and the backward sums global over the
+    ranks: one all-gather of [2C+1] floats per BatchNorm forward, one all-reduce of [2C] per backward."""
 
     def __init__(self, sd, tower: TowerCfg, text: TextCfg, lens: LensCfg, device, micro_batch: int = 32, lr: float = 2e-4,
                  betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2, rank: int = 0, world_size: int = 1,
                  gemm_cfg: int = -1, bn_training: bool = True, unlock_cls: bool = False, comm=None,
                  frozen_res_dtype=torch.float32, local_loss: bool = False, gather_with_grad: bool = False,
-                 train_res_dtype=torch.float32):
+                 train_res_dtype=torch.float32, bn_sync: bool = False):
         from .points import PointTokenizerTrainer
         from .train import PCLensTrainer
         self._init_common(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad)
         self.image = VitEngine(sd, "image.", tower, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
         self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
         self.lens = LensEngine(sd, "visual.", tower, lens, device, gemm_cfg=gemm_cfg, res_dtype=train_res_dtype)
-        self.tok = PointTokenizerTrainer(sd, "visual.visual_adapter.", lens, device, gemm_cfg=gemm_cfg, bn_training=bn_training)
+        self.tok = PointTokenizerTrainer(sd, "visual.visual_adapter.", lens, device, gemm_cfg=gemm_cfg, bn_training=bn_training,
+                                         bn_sync=self.comm if bn_sync and world_size > 1 else None, world_size=world_size)
         self._mk = lambda: PCLensTrainer(self.lens, self.tok, train_cls=unlock_cls)
         if unlock_cls:
             self.masters["visual.class_embedding"] = self.lens.vit.cls
