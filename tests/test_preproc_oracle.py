@@ -58,7 +58,7 @@ def test_image_eval_transform_matches_pil_pipeline(h, w):
     pil = Image.fromarray(img).resize((nw, nh), Image.BICUBIC)
     top, left = po.center_crop_origin(nh, nw, 224)
     pil = pil.crop((left, top, left + 224, top + 224)).convert("RGB")
-    t = torch.from_numpy(np.asarray(pil)).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+    t = torch.from_numpy(np.array(pil)).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
     want = t.sub_(torch.as_tensor(OPENAI_DATASET_MEAN)[:, None, None]).div_(torch.as_tensor(OPENAI_DATASET_STD)[:, None, None])
     got = po.image_eval_transform(img, 224, OPENAI_DATASET_MEAN, OPENAI_DATASET_STD)
     assert got.shape == (3, 224, 224) and np.array_equal(got, want.numpy())

@@ -66,7 +66,7 @@ def _to_device_u8(img, device):
     if hasattr(img, "mode") and hasattr(img, "convert"):                          # PIL.Image without importing PIL
         if img.mode not in ("RGB", "L"):
             img = img.convert("RGB")
-        img = np.asarray(img)
+        img = np.array(img)                                                       # a writable copy of the decoded bytes
     if isinstance(img, np.ndarray):
         img = torch.from_numpy(np.ascontiguousarray(img))
     if img.dtype != torch.uint8:
