@@ -1,0 +1,66 @@
+"""CPU: the per-modality input processors of `ViTLens.encode` (mm_vit_lens/data_processors.py, reference
+mm_vit_lens/data_processors.py:15-323) - host logic only: caption cleaning, EEG resampling against scipy, argument
+plumbing, loud failures where a front end is not available.  The GPU side is in tests/test_hip_preproc.py."""
+import numpy as np
+import pytest
+import torch
+
+
+def test_pre_caption_matches_the_reference_rules():
+    from mm_vit_lens.data_processors import TextProcessor
+    tp = TextProcessor()
+    # data_processors.py:68-87: lower-case, the characters . ! " ( ) * # : ; ~ become blanks, runs of blanks collapse,
+    # trailing newline / surrounding blanks go, at most max_words words survive
+    assert tp.pre_caption('A Dog!  (running): "fast"; ~ok~ #1.\n') == "a dog running fast ok 1"
+    assert tp.pre_caption("  sea   wave ") == "sea wave"
+    assert tp.pre_caption("keep, commas & dashes - and? marks") == "keep, commas & dashes - and? marks"
+    assert TextProcessor(max_words=3).pre_caption("one two three four five") == "one two three"
+    ids = TextProcessor(prompt="a photo of ")(["A Bird.", "sea wave"])
+    from open_clip import tokenize
+    assert ids.shape == (2, 77) and torch.equal(ids, tokenize(["a photo of a bird", "a photo of sea wave"]))
+    assert TextProcessor()(None) is None
+    tp2 = TextProcessor.from_config({"prompt": "x ", "max_words": 5})
+    assert tp2.prompt == "x " and tp2.max_words == 5
+
+
+def test_eeg_processor_equals_scipy_interp1d(tmp_path):
+    interp1d = pytest.importorskip("scipy.interpolate").interp1d
+    from mm_vit_lens.data_processors import EEGProcessor
+    g = torch.Generator().manual_seed(0)
+    e = torch.randn(128, 500, generator=g)
+    eeg = e.float().t()[20:460, :]                                                 # eeg_processor.py:236-246, verbatim order
+    eeg = np.array(eeg.transpose(0, 1))
+    want = torch.from_numpy(interp1d(np.linspace(0, 1, eeg.shape[-1]), eeg)(np.linspace(0, 1, 512))).float()
+    path = tmp_path / "eeg.pth"
+    torch.save(e, path)
+    got = EEGProcessor()([str(path), e])
+    assert got.shape == (2, 128, 512) and torch.equal(got[0], want) and torch.equal(got[1], want)
+
+
+def test_audio_processor_takes_spectrograms_and_refuses_waveform_files():
+    from mm_vit_lens.data_processors import AudioProcessor
+    ap = AudioProcessor()
+    x = ap([torch.zeros(3, 512, 128), np.ones((3, 512, 128), np.float32)])
+    assert x.shape == (2, 3, 512, 128) and x.dtype == torch.float32
+    with pytest.raises(NotImplementedError):
+        ap(["clip.flac"])
+    with pytest.raises(ValueError):
+        ap([torch.zeros(3, 100, 128)])
+
+
+def test_processor_table_and_vitlens_wiring():
+    from mm_vit_lens import data_processors as DP
+    from mm_vit_lens.vitlens import ViTLens
+    from open_clip import ModalityType
+    procs = DP.get_vitlens_processors_cls()["vitlensL"]()
+    assert set(procs) == {"image", "text", "pc", "depth", "audio", "tactile", "eeg"}
+    assert procs["pc"].wrap_processor.npoint == 8192 and procs["pc"].wrap_processor.uniform
+    assert procs["depth"].wrap_processor.max_depth == 75.0 and procs["depth"].wrap_processor.mean[3] == 0.0418
+    assert procs["tactile"].wrap_processor.resize == 256 and procs["tactile"].wrap_processor.size == 224
+    assert procs["image"].transform.image_size == 224 and not procs["image"].transform.is_train
+    assert DP.get_vitlens_processors_cls()["vitlensB"]() is None
+    vl = ViTLens(modality_loaded=[ModalityType.TACTILE, ModalityType.EEG], device="cpu")
+    assert isinstance(vl.processor(ModalityType.EEG), DP.EEGProcessor) and isinstance(vl.processor("tactile"), DP.TactileProcessor)
+    assert vl.processor("eeg") is vl.processor("eeg")
+    with pytest.raises(RuntimeError):                                             # no GPU here: the towers refuse CPU tensors loudly
+        vl.encode({ModalityType.EEG: torch.zeros(1, 128, 512)})

@@ -84,3 +84,62 @@ def test_depth_processor_vs_oracle(h, w, antialias):
     ref = (r[top:top + 224, left:left + 224] - 0.0418) / 0.0295                    # the torch pipeline itself
     assert (got[0].cpu() - ref).abs().max() < 2e-4
     assert torch.equal(proc.batch([d, d.numpy()])[1], got)
+
+
+def test_tactile_processor_vs_the_torch_pipeline():
+    """TactileRGBProcessorEval (tact_processor.py:281-300): ToTensor -> Resize(256, bicubic) on the float tensor ->
+    CenterCrop(224) -> Normalize, against the same steps in torch (F.interpolate = torchvision's tensor resize)."""
+    from open_clip.modal_tactile.processors.tact_processor import TactileRGBProcessorEval
+    for (h, w), antialias in (((480, 640), True), ((320, 240), True), ((480, 640), False)):
+        img = _img(h, w, seed=5)
+        got = TactileRGBProcessorEval(antialias=antialias)(img)
+        assert got.is_cuda and got.shape == (3, 224, 224)
+        x = torch.from_numpy(img).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+        nh, nw = po.resized_output_size(h, w, 256)
+        r = torch.nn.functional.interpolate(x[None], (nh, nw), mode="bicubic", align_corners=False, antialias=antialias)[0]
+        top, left = po.center_crop_origin(nh, nw, 224)
+        r = r[:, top:top + 224, left:left + 224]
+        want = (r - torch.as_tensor(MEAN)[:, None, None]) / torch.as_tensor(STD)[:, None, None]
+        assert (got.cpu() - want).abs().max() < 1e-4, (h, w, antialias)
+        for c in range(3):                                                        # and the numpy restatement, channel by channel
+            o = po.resize_bicubic_f32(x[c].numpy(), nh, nw, antialias)[top:top + 224, left:left + 224]
+            assert np.abs(got[c].cpu().numpy() - (o - np.float32(MEAN[c])) / np.float32(STD[c])).max() < 1e-4
+
+
+def test_data_processors_from_files(tmp_path):
+    """mm_vit_lens.data_processors with the reference's inputs - lists of file paths - against the oracle on the decoded
+    arrays: PNG images (bit-exact), torch-saved disparity maps, .npy point clouds (FPS start drawn by np.random as in the
+    reference), a tactile PNG, torch-saved EEG."""
+    Image = pytest.importorskip("PIL.Image")
+    import vitlens_oracle as O
+    from mm_vit_lens import data_processors as DP
+    imgs = [_img(240, 320, seed=1), _img(400, 300, seed=2)]
+    paths = []
+    for i, im in enumerate(imgs):
+        paths.append(str(tmp_path / f"im{i}.png")); Image.fromarray(im).save(paths[-1])
+    got = DP.ImageProcessor()(paths, device="cuda")
+    assert got.shape == (2, 3, 224, 224) and got.is_cuda
+    for i, im in enumerate(imgs):
+        assert np.array_equal(got[i].cpu().numpy(), po.image_eval_transform(im, 224, MEAN, STD))
+    d = torch.rand(300, 410, generator=torch.Generator().manual_seed(4)) * 80
+    dp = str(tmp_path / "d.pt"); torch.save(d, dp)
+    gd = DP.DepthProcessor()([dp, d], device="cuda")
+    assert gd.shape == (2, 1, 224, 224) and np.abs(gd[0].cpu().numpy() - po.depth_eval_transform(d.numpy())).max() < 2e-4
+    assert torch.equal(gd[0], gd[1])
+    pc = np.random.default_rng(0).standard_normal((9000, 6)).astype(np.float32)
+    pp = str(tmp_path / "pc.npy"); np.save(pp, pc)
+    np.random.seed(7)
+    gp = DP.PointCloudProcessor(n_sample_points=1024)(pp, device="cuda")
+    np.random.seed(7)
+    start = np.random.randint(0, 9000)
+    assert gp.shape == (1, 1024, 6)
+    sel, _ = O.pc_farthest_point_sample(pc, 1024, start)
+    assert np.abs(gp[0].cpu().numpy() - O.pc_norm(sel)).max() < 2e-5
+    tac = _img(480, 640, seed=9)
+    tpath = str(tmp_path / "t.png"); Image.fromarray(tac).save(tpath)
+    gt = DP.TactileProcessor()([tpath, tac], device="cuda")
+    assert gt.shape == (2, 3, 224, 224) and torch.equal(gt[0], gt[1])
+    e = torch.randn(128, 500, generator=torch.Generator().manual_seed(1))
+    ep = str(tmp_path / "e.pth"); torch.save(e, ep)
+    ge = DP.EEGProcessor()(ep, device="cuda")
+    assert ge.shape == (1, 128, 512) and ge.is_cuda

@@ -1,9 +1,10 @@
 """`ViTLens.encode({ModalityType: inputs})` with the reference's call surface (mm_vit_lens/vitlens.py:21-189).
 
-Inputs are tensors already in model space (the reference's per-modality processors are file I/O + CPU
-preprocessing, outside the hot path -- SURVEY §2 A7):
+Inputs are either what the reference takes - file paths / captions, run through the per-modality processors of
+`mm_vit_lens.data_processors` (decode on the host, everything else on the GPU) - or tensors already in model space,
+which skip the processor:
    image [B,3,224,224] | text: list[str] or int64 [B,77] | depth [B,1,224,224] | audio [B,S,512,128] or [B,512,128]
-   | pc [B,8192,3]
+   | pc [B,8192,3] | tactile [B,3,224,224] | eeg [B,128,512]
 `encode` returns {modality: [B, 768]} (audio: mean over the S clips, vitlens.py:175-183), L2-normalised by default.
 """
 from typing import Dict, List, Optional
@@ -11,7 +12,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
-from open_clip import ModalityType, tokenize, tri_create_model
+from open_clip import ModalityType, tri_create_model
 from .model_cfg import fetch_model_cfg
 
 
@@ -23,6 +24,7 @@ class ViTLens(nn.Module):
         self.modality_loaded = modality_loaded or [ModalityType.IMAGE, ModalityType.TEXT]
         self.vitlens = nn.ModuleDict()
         self._dev = torch.device(device)
+        self.processors = {}
         base = None
         for m in self.modality_loaded:
             if m in (ModalityType.IMAGE, ModalityType.TEXT):
@@ -30,7 +32,7 @@ class ViTLens(nn.Module):
                     cfg = fetch_model_cfg("image", model_var)
                     base = tri_create_model(cfg.model, None, device=self._dev, args=cfg)
                 self.vitlens[m] = base
-            elif m in (ModalityType.DEPTH, ModalityType.AUDIO, ModalityType.PC):
+            elif m in (ModalityType.DEPTH, ModalityType.AUDIO, ModalityType.PC, ModalityType.TACTILE, ModalityType.EEG):
                 cfg = fetch_model_cfg(m, model_var)
                 self.vitlens[m] = tri_create_model(cfg.model, None, device=self._dev, args=cfg)
             else:
@@ -102,14 +104,25 @@ class ViTLens(nn.Module):
     def export_checkpoint(self, save_path="model_release/vitlens.pt"):
         torch.save(dict(model_var=self.model_var, modality_loaded=self.modality_loaded, state_dict=self.state_dict()), save_path)
 
+    def processor(self, m):
+        """The reference's per-modality input processor (built on first use: vitlens.py:108-116)."""
+        if m not in self.processors:
+            from . import data_processors as DP
+            cls = {ModalityType.IMAGE: DP.ImageProcessor, ModalityType.TEXT: DP.TextProcessor, ModalityType.PC: DP.PointCloudProcessor,
+                   ModalityType.DEPTH: DP.DepthProcessor, ModalityType.AUDIO: DP.AudioProcessor,
+                   ModalityType.TACTILE: DP.TactileProcessor, ModalityType.EEG: DP.EEGProcessor}[m]
+            self.processors[m] = cls()
+        return self.processors[m]
+
     @torch.no_grad()
     def encode(self, input_dict: Dict[str, object], normalize: bool = True) -> Dict[str, torch.Tensor]:
         out = {}
         for m, x in input_dict.items():
             model = self.vitlens[m]
+            if not isinstance(x, torch.Tensor):
+                x = self.processor(m)(x, device=self._dev)
             if m == ModalityType.TEXT:
-                ids = tokenize(x) if not isinstance(x, torch.Tensor) else x
-                f = model.encode_text(ids.to(self._dev), normalize=False)
+                f = model.encode_text(x.to(self._dev), normalize=False)
             elif m == ModalityType.IMAGE:
                 f = model.encode_image(x.to(self._dev), normalize=False)
             elif m == ModalityType.AUDIO and x.ndim == 4:

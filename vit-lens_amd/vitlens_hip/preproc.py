@@ -159,29 +159,54 @@ def image_to_tensor(img_u8, size, mean, std, out=None, box=None, want_u8=False):
     return (out, u8) if want_u8 else out
 
 
+def plane_to_tensor(plane, size, mean, std, clamp=None, antialias=True, out=None, crop=None):
+    """plane: float32 [H, W] CUDA tensor.  clamp = (lo, hi, divide_by) is applied as the source is read (DepthNorm;
+    (0, 255, 255) turns the float-cast bytes of an image channel into ToTensor's [0, 1] range).  Resize(size, bicubic)
+    -> CenterCrop(crop or size) -> (x - mean) / std -> float32 [crop, crop] written to `out` (any [.., crop, crop] view)."""
+    from . import ops
+    assert plane.dtype == torch.float32 and plane.dim() == 2 and plane.is_cuda
+    dev = plane.device
+    if plane.stride(1) != 1:
+        plane = plane.contiguous()
+    crop = size if crop is None else crop
+    H, W = plane.shape
+    nh, nw = resized_output_size(H, W, size)
+    ctop, cleft = center_crop_origin(nh, nw, crop)
+    if ctop < 0 or cleft < 0:
+        raise ValueError("input smaller than the crop after Resize")
+    hb, hw, hks, _ = _on_device(("aten", W, nw, antialias), lambda: aten_bicubic_tables(W, nw, antialias), dev)
+    vb, vw, vks, vb_host = _on_device(("aten", H, nh, antialias), lambda: aten_bicubic_tables(H, nh, antialias), dev)
+    row0, nrows = _window(vb_host, ctop, crop, H)
+    tmp = torch.empty(nrows, crop, device=dev, dtype=torch.float32)
+    lo, hi, div = clamp if clamp is not None else (0.0, 0.0, 1.0)
+    ops.check(ops._lib.vl_resample_h_f32(ops._p(plane), plane.stride(0), W, row0, nrows, ops._p(hb), ops._p(hw), hks, cleft, crop,
+                                         int(clamp is not None), float(lo), float(hi), float(div), ops._p(tmp), ops._stream()))
+    if out is None:
+        out = torch.empty(crop, crop, device=dev, dtype=torch.float32)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == crop * crop
+    ops.check(ops._lib.vl_resample_v_f32_norm(ops._p(tmp), crop, H, row0, ops._p(vb), ops._p(vw), vks, ctop, crop, float(mean),
+                                              float(std), ops._p(out), ops._stream()))
+    return out
+
+
 def depth_to_tensor(depth, size, mean, std, clamp=None, antialias=True, out=None):
     """depth: float32 [H, W] CUDA tensor.  clamp = (lo, hi, divide_by) = DepthNorm; Resize(size, bicubic) ->
     CenterCrop(size) -> (x - mean) / std -> float32 [1, size, size]."""
-    from . import ops
-    assert depth.dtype == torch.float32 and depth.dim() == 2 and depth.is_cuda
-    dev = depth.device
-    if depth.stride(1) != 1:
-        depth = depth.contiguous()
-    H, W = depth.shape
-    nh, nw = resized_output_size(H, W, size)
-    ctop, cleft = center_crop_origin(nh, nw, size)
-    if ctop < 0 or cleft < 0:
-        raise ValueError("depth map smaller than the crop after Resize")
-    hb, hw, hks, _ = _on_device(("aten", W, nw, antialias), lambda: aten_bicubic_tables(W, nw, antialias), dev)
-    vb, vw, vks, vb_host = _on_device(("aten", H, nh, antialias), lambda: aten_bicubic_tables(H, nh, antialias), dev)
-    row0, nrows = _window(vb_host, ctop, size, H)
-    tmp = torch.empty(nrows, size, device=dev, dtype=torch.float32)
-    lo, hi, div = clamp if clamp is not None else (0.0, 0.0, 1.0)
-    ops.check(ops._lib.vl_resample_h_f32(ops._p(depth), depth.stride(0), W, row0, nrows, ops._p(hb), ops._p(hw), hks, cleft, size,
-                                         int(clamp is not None), float(lo), float(hi), float(div), ops._p(tmp), ops._stream()))
     if out is None:
-        out = torch.empty(1, size, size, device=dev, dtype=torch.float32)
-    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == size * size
-    ops.check(ops._lib.vl_resample_v_f32_norm(ops._p(tmp), size, H, row0, ops._p(vb), ops._p(vw), vks, ctop, size, float(mean),
-                                              float(std), ops._p(out), ops._stream()))
+        out = torch.empty(1, size, size, device=depth.device, dtype=torch.float32)
+    plane_to_tensor(depth, size, mean, std, clamp=clamp, antialias=antialias, out=out)
+    return out
+
+
+def float_image_to_tensor(img_u8, size, crop, mean, std, antialias=True, out=None):
+    """ToTensor FIRST, then Resize on the float tensor (the tactile recipe, modal_tactile/processors/tact_processor.py:
+    286-295): img_u8 uint8 [H, W, C] CUDA -> float32 [C, crop, crop]; each channel through the float resampler with the
+    /255 of ToTensor fused into the read."""
+    assert img_u8.dtype == torch.uint8 and img_u8.dim() == 3 and img_u8.is_cuda
+    C = img_u8.shape[2]
+    planes = img_u8.permute(2, 0, 1).to(torch.float32).contiguous()               # dtype cast only; the arithmetic is in the kernels
+    if out is None:
+        out = torch.empty(C, crop, crop, device=img_u8.device, dtype=torch.float32)
+    for c in range(C):
+        plane_to_tensor(planes[c], size, mean[c], std[c], clamp=(0.0, 255.0, 255.0), antialias=antialias, out=out[c], crop=crop)
     return out
