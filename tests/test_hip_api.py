@@ -271,6 +271,23 @@ def test_vitlens_encode_api_at_full_size():
     refd = O.encode_visual(sdd, depth, O.TowerSpec(), O.LensSpec(modality="depth", perceiver_identity=True), normalize=True)
     cs = torch.nn.functional.cosine_similarity(out[ModalityType.DEPTH].float().cpu(), refd, dim=-1)
     assert float((1 - cs).max()) < 1e-3
+    # the reference's own input types (vitlens.py:170-173: every input goes through its processor): decoded images,
+    # captions with punctuation, raw disparity maps - against encode() on the tensors the oracle's preprocessing gives
+    import numpy as np
+    import preproc_oracle as po
+    from open_clip import tokenize
+    from open_clip.constants import OPENAI_DATASET_MEAN as MEAN, OPENAI_DATASET_STD as STD
+    rng = np.random.default_rng(0)
+    raw_img = [rng.integers(0, 256, (300, 400, 3), dtype=np.uint8), rng.integers(0, 256, (260, 224, 3), dtype=np.uint8)]
+    raw_depth = [torch.rand(300, 400, generator=g) * 80, torch.rand(240, 320, generator=g) * 80]
+    raw = vl.encode({ModalityType.IMAGE: raw_img, ModalityType.TEXT: ["A Bird!", "(crackling) fire."], ModalityType.DEPTH: raw_depth})
+    pre = vl.encode({ModalityType.IMAGE: torch.from_numpy(np.stack([po.image_eval_transform(i, 224, MEAN, STD) for i in raw_img])),
+                     ModalityType.TEXT: tokenize(["a bird", "crackling fire"]),
+                     ModalityType.DEPTH: torch.from_numpy(np.stack([po.depth_eval_transform(d.numpy()) for d in raw_depth]))})
+    assert torch.equal(raw[ModalityType.IMAGE], pre[ModalityType.IMAGE])          # bit-identical preprocessing, same kernels
+    assert torch.equal(raw[ModalityType.TEXT], pre[ModalityType.TEXT])
+    cs = torch.nn.functional.cosine_similarity(raw[ModalityType.DEPTH].float(), pre[ModalityType.DEPTH].float(), dim=-1)
+    assert float((1 - cs).max()) < 1e-4
 
 
 def test_zero_shot_logits_and_accuracy_on_gpu():
