@@ -69,3 +69,14 @@ def test_factory_arguments_and_crop_box():
     for top, left, h, w in a:
         assert 0 <= top and 0 <= left and top + h <= 300 and left + w <= 400 and h > 0 and w > 0
     assert random_resized_crop_params(10, 1000, (0.9, 1.0)) == (0, 493, 10, 13)   # no admissible draw: central fallback
+
+
+def test_device_table_cache_is_bounded():
+    preproc._DEVICE_TABLES.clear()
+    for i in range(preproc._DEVICE_TABLES_MAX + 40):
+        preproc._on_device(("pil", 300 + i, 224), lambda i=i: preproc.pil_bicubic_tables(300 + i, 224), "cpu")
+    assert len(preproc._DEVICE_TABLES) == preproc._DEVICE_TABLES_MAX
+    assert (("pil", 300, 224), "cpu") not in preproc._DEVICE_TABLES               # least recently used went first
+    hit = preproc._on_device(("pil", 340, 224), lambda: (_ for _ in ()).throw(AssertionError("must be cached")), "cpu")
+    assert hit[2] == preproc.pil_bicubic_tables(340, 224)[2]
+    preproc._DEVICE_TABLES.clear()

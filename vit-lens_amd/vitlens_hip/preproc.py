@@ -13,6 +13,7 @@ ATen build theirs - cached, and kept on the device.
 `image_to_tensor` / `depth_to_tensor` run Resize(shorter edge) -> CenterCrop -> Normalize restricted to the crop
 window (torchvision `_compute_resized_output_size`, `center_crop`); see open_clip/transform.py and
 open_clip/modal_depth/processors/vt_processor.py for the reference-facing classes."""
+import collections
 import ctypes
 import functools
 import math
@@ -98,15 +99,22 @@ def aten_bicubic_tables(in_size, out_size, antialias=True):
     return bounds, np.ascontiguousarray(w), 4
 
 
-_DEVICE_TABLES = {}
+_DEVICE_TABLES = collections.OrderedDict()      # (kind, in, out[, antialias], device) -> tables; LRU, a data set has few distinct sizes
+_DEVICE_TABLES_MAX = 512                        # <= ~10 KB each on the device
 
 
 def _on_device(key, builder, device):
     k = (key, str(device))
-    if k not in _DEVICE_TABLES:
-        bounds, coef, ksize = builder()
-        _DEVICE_TABLES[k] = (torch.from_numpy(bounds).to(device), torch.from_numpy(coef).to(device), ksize, bounds)
-    return _DEVICE_TABLES[k]
+    hit = _DEVICE_TABLES.get(k)
+    if hit is not None:
+        _DEVICE_TABLES.move_to_end(k)
+        return hit
+    bounds, coef, ksize = builder()
+    hit = (torch.from_numpy(bounds).to(device), torch.from_numpy(coef).to(device), ksize, bounds)
+    _DEVICE_TABLES[k] = hit
+    if len(_DEVICE_TABLES) > _DEVICE_TABLES_MAX:
+        _DEVICE_TABLES.popitem(last=False)      # tensors still referenced by kernels in flight stay alive through the allocator's stream ordering
+    return hit
 
 
 def _window(bounds_host, first, count, limit):
