@@ -209,6 +209,13 @@ int vl_resample_h_u8(const uint8_t* src, long row_stride, int C, int row0, int n
 int vl_resample_v_u8_norm(const uint8_t* src, int W, int C, int row0, const int* bounds, const int* kk, int ksize,
                           int yout0, int nyout, const float* mean, const float* stdv, float* out, uint8_t* out_u8,
                           hipStream_t stream);
+/* The 8-bit path for a LIST of images of different sizes in two launches (blockIdx.z = image).  desc: device array
+ * [n][16] int64 per image = {src pointer, row stride in bytes, source width, row0, nrows, xout0, yout0, horizontal
+ * bounds offset, horizontal coefficient offset, horizontal ksize, vertical bounds offset, vertical coefficient offset,
+ * vertical ksize, byte offset of the image's [nrows, crop_w, C] intermediate in tmp, 0, 0}; offsets count ints into
+ * `tables` (the per-axis bounds / coefficient tables of the distinct sizes, packed).  out [n, C, crop_h, crop_w] f32. */
+int vl_resample_batch_u8_norm(const int64_t* desc, int n, int C, int crop_h, int crop_w, int max_nrows, const int* tables,
+                              uint8_t* tmp, const float* mean, const float* stdv, float* out, hipStream_t stream);
 int vl_resample_h_f32(const float* src, long row_stride, int W, int row0, int nrows, const int* bounds,
                       const float* weights, int ksize, int xout0, int nxout, int clamp_on, float clamp_lo,
                       float clamp_hi, float divide_by, float* dst, hipStream_t stream);

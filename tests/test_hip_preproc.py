@@ -143,3 +143,34 @@ def test_data_processors_from_files(tmp_path):
     ep = str(tmp_path / "e.pth"); torch.save(e, ep)
     ge = DP.EEGProcessor()(ep, device="cuda")
     assert ge.shape == (1, 128, 512) and ge.is_cuda
+
+
+def test_batched_transform_equals_the_per_image_path():
+    """vl_resample_batch_u8_norm (a list of images of different sizes in two launches, host images in one packed copy)
+    against the per-image kernels: identical bits, for the evaluation transform and for given crop boxes; mixed host /
+    device inputs, greyscale and PIL images."""
+    from open_clip.transform import image_transform
+    from vitlens_hip import preproc
+    shapes = [(240, 320), (530, 730), (730, 530), (224, 224), (100, 80), (375, 500), (225, 224), (64, 48)]
+    host = [torch.from_numpy(_img(h, w, seed=i)) for i, (h, w) in enumerate(shapes)]
+    mixed = [im.cuda() if i % 2 else im for i, im in enumerate(host)]
+    got = preproc.images_to_tensor(mixed, 224, MEAN, STD)
+    assert got.shape == (len(shapes), 3, 224, 224)
+    for i, im in enumerate(host):
+        assert torch.equal(got[i], preproc.image_to_tensor(im.cuda(), 224, MEAN, STD)), shapes[i]
+        assert np.array_equal(got[i].cpu().numpy(), po.image_eval_transform(im.numpy(), 224, MEAN, STD))
+    boxes = [(3, 5, h - 20, w - 30) for h, w in shapes]
+    gb = preproc.images_to_tensor(mixed, (224, 224), MEAN, STD, boxes=boxes)
+    for i, im in enumerate(host):
+        assert torch.equal(gb[i], preproc.image_to_tensor(im.cuda(), (224, 224), MEAN, STD, box=boxes[i])), shapes[i]
+    t = image_transform(224, is_train=False)
+    items = [host[0].numpy(), _img(333, 250, 1)[..., 0], host[2].cuda()]
+    b = t.batch(items)
+    for i, it in enumerate(items):
+        assert torch.equal(b[i], t(it)), i
+    tt = image_transform(224, is_train=True, aug_cfg={"scale": (0.3, 1.0)})
+    torch.manual_seed(5)
+    bt = tt.batch(items)
+    torch.manual_seed(5)
+    for i, it in enumerate(items):
+        assert torch.equal(bt[i], tt(it)), i

@@ -74,6 +74,55 @@ __global__ void __launch_bounds__(256) resample_v_u8_norm_kernel(const unsigned 
   }
 }
 
+// ---- batched 8-bit path: one launch per pass for a list of images of DIFFERENT sizes (blockIdx.z = image) ----
+// desc [n][16] int64 per image: 0 src pointer, 1 row stride (bytes), 2 source width, 3 row0, 4 nrows (source rows the
+// vertical taps of the crop touch), 5 xout0, 6 yout0 (crop origin in the resized image), 7/8/9 horizontal bounds offset,
+// coefficient offset (in ints, into `tables`) and ksize, 10/11/12 the same for the vertical axis, 13 offset of this
+// image's intermediate in `tmp` (bytes), 14-15 unused.
+constexpr int DESC_LD = 16;
+
+__global__ void __launch_bounds__(256) resample_h_u8_batch_kernel(const long long* __restrict__ desc, int C, int nxout,
+                                                                  const int* __restrict__ tables, unsigned char* __restrict__ tmp) {
+  const long long* d = desc + (long)blockIdx.z * DESC_LD;
+  const int nrows = (int)d[4];
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)nrows * nxout) return;
+  const int r = (int)(i / nxout), x = (int)(i - (long)r * nxout);
+  const int xo = (int)d[5] + x, ksize = (int)d[9];
+  const int* bounds = tables + d[7];
+  const int xmin = bounds[2 * xo], n = bounds[2 * xo + 1];
+  const int* k = tables + d[8] + (long)xo * ksize;
+  const unsigned char* s = (const unsigned char*)d[0] + ((long)d[3] + r) * d[1] + (long)xmin * C;
+  unsigned char* dst = tmp + d[13] + ((long)r * nxout + x) * C;
+  for (int c = 0; c < C; ++c) {
+    int acc = 1 << (PRECISION_BITS - 1);
+    for (int j = 0; j < n; ++j) acc += (int)s[j * C + c] * k[j];
+    dst[c] = clip8(acc);
+  }
+}
+
+__global__ void __launch_bounds__(256) resample_v_u8_norm_batch_kernel(const long long* __restrict__ desc, int C, int nyout, int W,
+                                                                       const int* __restrict__ tables, const unsigned char* __restrict__ tmp,
+                                                                       const NormP np, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const long long* d = desc + (long)blockIdx.z * DESC_LD;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)nyout * W) return;
+  const int y = (int)(i / W), x = (int)(i - (long)y * W);
+  const int yo = (int)d[6] + y, ksize = (int)d[12], row0 = (int)d[3];
+  const int* bounds = tables + d[10];
+  const int ymin = bounds[2 * yo], n = bounds[2 * yo + 1];
+  const int* k = tables + d[11] + (long)yo * ksize;
+  const unsigned char* s = tmp + d[13] + ((long)(ymin - row0) * W + x) * C;
+  float* o = out + (long)blockIdx.z * C * nyout * W;
+  for (int c = 0; c < C; ++c) {
+    int acc = 1 << (PRECISION_BITS - 1);
+    for (int j = 0; j < n; ++j) acc += (int)s[(long)j * W * C + c] * k[j];
+    const float v = (float)clip8(acc) / 255.0f;
+    o[((long)c * nyout + y) * W + x] = (v - np.mean[c]) / np.std[c];
+  }
+}
+
 struct ClampP { float lo, hi, div; int on; };
 
 // dst[r, i] = sum_j w[xout0+i, j] * f(src[row0+r, clamp(xmin[xout0+i] + j, 0, W-1)]),  f = DepthNorm's clamp and scale
@@ -158,6 +207,20 @@ extern "C" int vl_resample_v_f32_norm(const float* src, int W, int H, int row0, 
     return vl_set_error("vl_resample_v_f32_norm: need W, H, nyout, ksize > 0 and std != 0");
   hipLaunchKernelGGL(resample_v_f32_norm_kernel, dim3(grid1((long)nyout * W)), dim3(256), 0, stream, src, W, H, row0, bounds, weights,
                      ksize, yout0, nyout, mean, stdv, out);
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vl_resample_batch_u8_norm(const int64_t* desc, int n, int C, int crop_h, int crop_w, int max_nrows, const int* tables,
+                                         uint8_t* tmp, const float* mean, const float* stdv, float* out, hipStream_t stream) {
+  if (n <= 0 || n > 65535 || C < 1 || C > 4 || crop_h <= 0 || crop_w <= 0 || max_nrows <= 0 || !desc || !tables || !tmp || !mean || !stdv || !out)
+    return vl_set_error("vl_resample_batch_u8_norm: need 1<=n<=65535, 1<=C<=4, crop and max_nrows > 0, all pointers");
+  NormP np{};
+  for (int c = 0; c < C; ++c) { np.mean[c] = mean[c]; np.std[c] = stdv[c]; }
+  hipLaunchKernelGGL(resample_h_u8_batch_kernel, dim3(grid1((long)max_nrows * crop_w), 1, n), dim3(256), 0, stream, (const long long*)desc, C,
+                     crop_w, tables, tmp);
+  hipLaunchKernelGGL(resample_v_u8_norm_batch_kernel, dim3(grid1((long)crop_h * crop_w), 1, n), dim3(256), 0, stream, (const long long*)desc,
+                     C, crop_h, crop_w, tables, (const unsigned char*)tmp, np, out);
   VL_HIP_OK(hipGetLastError());
   return 0;
 }

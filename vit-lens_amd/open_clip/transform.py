@@ -63,10 +63,15 @@ def random_resized_crop_params(height, width, scale, ratio=(3.0 / 4.0, 4.0 / 3.0
 def _to_device_u8(img, device):
     """PIL image / numpy / tensor -> uint8 [H, W, C] on the device.  The reference converts to RGB after Resize; for
     greyscale that commutes (replicating a channel, then resampling each copy), other PIL modes are converted first."""
-    if hasattr(img, "mode") and hasattr(img, "convert"):                          # PIL.Image without importing PIL
+    return _to_host_or_device_u8(img).to(device, non_blocking=True)
+
+
+def _to_host_or_device_u8(img):
+    """As _to_device_u8, but host data stays on the host (the batched path packs it into one copy)."""
+    if hasattr(img, "mode") and hasattr(img, "convert"):
         if img.mode not in ("RGB", "L"):
             img = img.convert("RGB")
-        img = np.array(img)                                                       # a writable copy of the decoded bytes
+        img = np.array(img)
     if isinstance(img, np.ndarray):
         img = torch.from_numpy(np.ascontiguousarray(img))
     if img.dtype != torch.uint8:
@@ -75,7 +80,7 @@ def _to_device_u8(img, device):
         img = img.unsqueeze(-1)
     if img.dim() != 3 or img.shape[-1] not in (1, 3):
         raise ValueError(f"expected an [H, W, 3] or [H, W(, 1)] image, got {tuple(img.shape)}")
-    return img.to(device, non_blocking=True)
+    return img if img.is_cuda else img.contiguous()
 
 
 class ImageTransform:
@@ -96,12 +101,18 @@ class ImageTransform:
         return preproc.image_to_tensor(x, size, self.mean, self.std, out=out)
 
     def batch(self, images):
-        """A list of images -> [B, 3, size, size] float32 on the GPU (what `encode_image` consumes)."""
-        s = self.image_size if isinstance(self.image_size, int) else self.image_size[0]
-        out = torch.empty(len(images), 3, s, s, device=self.device, dtype=torch.float32)
-        for i, im in enumerate(images):
-            self(im, out=out[i])
-        return out
+        """A list of images (any sizes) -> [B, 3, size, size] float32 on the GPU (what `encode_image` consumes) in two
+        kernel launches: host images travel as ONE packed copy, each image is described by one descriptor row."""
+        from vitlens_hip import preproc
+        xs = []
+        for im in images:
+            x = _to_host_or_device_u8(im)
+            xs.append(x.expand(-1, -1, 3).contiguous() if x.shape[-1] == 1 else x)
+        size = self.image_size
+        hw = tuple(size) if isinstance(size, (tuple, list)) else (size, size)
+        out = torch.empty(len(xs), 3, hw[0], hw[1], device=self.device, dtype=torch.float32)
+        boxes = [random_resized_crop_params(x.shape[0], x.shape[1], self.scale, self.ratio) for x in xs] if self.is_train else None
+        return preproc.images_to_tensor(xs, hw if self.is_train else hw[0], self.mean, self.std, out=out, boxes=boxes)
 
 
 def image_transform(image_size, is_train, mean=None, std=None, resize_longest_max=False, fill_color=0, aug_cfg=None,

@@ -218,3 +218,70 @@ def float_image_to_tensor(img_u8, size, crop, mean, std, antialias=True, out=Non
     for c in range(C):
         plane_to_tensor(planes[c], size, mean[c], std[c], clamp=(0.0, 255.0, 255.0), antialias=antialias, out=out[c], crop=crop)
     return out
+
+
+def images_to_tensor(images, size, mean, std, out=None, boxes=None):
+    """A LIST of uint8 [H, W, C] images of different sizes (CPU or CUDA tensors, same C) -> float32 [n, C, size, size]
+    in two kernel launches (vl_resample_batch_u8_norm): same arithmetic and bits as `image_to_tensor` per image.
+    Host images are packed into one buffer and copied once; the per-axis tables of the distinct sizes are packed into one
+    int32 array; one int64 descriptor row per image.  boxes[i] = (top, left, h, w): crop-then-resize (training)."""
+    from . import ops
+    n = len(images)
+    assert n > 0
+    dev = out.device if out is not None else next((im.device for im in images if im.is_cuda), torch.device("cuda"))
+    ch, cw = (size, size) if isinstance(size, int) else tuple(size)
+    C = images[0].shape[2]
+    # 1. bytes: CUDA images are read in place, host images travel as one packed buffer
+    host_idx = [i for i, im in enumerate(images) if not im.is_cuda]
+    host_off, total = {}, 0
+    for i in host_idx:
+        host_off[i] = total
+        total += images[i].numel()
+    packed = torch.cat([images[i].reshape(-1) for i in host_idx]).to(dev, non_blocking=True) if host_idx else None
+    # 2. geometry, packed tables, descriptors
+    parts, offsets, cursor = [], {}, 0
+
+    def table(in_size, out_size):
+        nonlocal cursor
+        key = (in_size, out_size)
+        if key not in offsets:
+            b, kk, ks = pil_bicubic_tables(in_size, out_size)
+            offsets[key] = (cursor, cursor + b.size, ks, b)
+            parts.extend((b.reshape(-1), kk.reshape(-1)))
+            cursor += b.size + kk.size
+        return offsets[key]
+    desc = np.zeros((n, 16), np.int64)
+    tmp_bytes, max_nrows = 0, 0
+    for i, im in enumerate(images):
+        assert im.dtype == torch.uint8 and im.dim() == 3 and im.shape[2] == C
+        H, W = im.shape[:2]
+        if im.is_cuda:
+            if im.stride(2) != 1 or im.stride(1) != C:
+                im = images[i] = im.contiguous()
+            base, stride = im.data_ptr(), im.stride(0)
+        else:
+            base, stride = packed.data_ptr() + host_off[i], W * C
+        if boxes is not None:
+            top, left, H, W = boxes[i]
+            base += top * stride + left * C
+            nh, nw, ctop, cleft = ch, cw, 0, 0
+        else:
+            nh, nw = resized_output_size(H, W, ch)
+            ctop, cleft = center_crop_origin(nh, nw, ch)
+            if ctop < 0 or cleft < 0:
+                raise ValueError("image smaller than the crop after Resize")
+        hb_off, hk_off, hks, _ = table(W, nw)
+        vb_off, vk_off, vks, vb_host = table(H, nh)
+        row0, nrows = _window(vb_host, ctop, ch, H)
+        desc[i, :14] = (base, stride, W, row0, nrows, cleft, ctop, hb_off, hk_off, hks, vb_off, vk_off, vks, tmp_bytes)
+        tmp_bytes += nrows * cw * C
+        max_nrows = max(max_nrows, nrows)
+    tables = torch.from_numpy(np.concatenate(parts)).to(dev, non_blocking=True)
+    desc_d = torch.from_numpy(desc).to(dev, non_blocking=True)
+    tmp = torch.empty(tmp_bytes, device=dev, dtype=torch.uint8)
+    if out is None:
+        out = torch.empty(n, C, ch, cw, device=dev, dtype=torch.float32)
+    assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (n, C, ch, cw)
+    ops.check(ops._lib.vl_resample_batch_u8_norm(ops._p(desc_d), n, C, ch, cw, max_nrows, ops._p(tables), ops._p(tmp), _floats(mean),
+                                                 _floats(std), ops._p(out), ops._stream()))
+    return out
