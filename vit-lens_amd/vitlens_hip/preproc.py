@@ -220,25 +220,39 @@ def float_image_to_tensor(img_u8, size, crop, mean, std, antialias=True, out=Non
     return out
 
 
-def images_to_tensor(images, size, mean, std, out=None, boxes=None):
-    """A LIST of uint8 [H, W, C] images of different sizes (CPU or CUDA tensors, same C) -> float32 [n, C, size, size]
-    in two kernel launches (vl_resample_batch_u8_norm): same arithmetic and bits as `image_to_tensor` per image.
-    Host images are packed into one buffer and copied once; the per-axis tables of the distinct sizes are packed into one
-    int32 array; one int64 descriptor row per image.  boxes[i] = (top, left, h, w): crop-then-resize (training)."""
-    from . import ops
+class BatchPlan:
+    """Device-side description of one batched transform: descriptors, packed tables, intermediate, and the tensors that
+    keep the source bytes alive.  `launch()` enqueues the two kernels; it can be repeated (same inputs, same output)."""
+
+    def __init__(self, desc, tables, tmp, out, n, C, ch, cw, max_nrows, mean, std, keep):
+        self.desc, self.tables, self.tmp, self.out, self.keep = desc, tables, tmp, out, keep
+        self.n, self.C, self.ch, self.cw, self.max_nrows, self.mean, self.std = n, C, ch, cw, max_nrows, mean, std
+
+    def launch(self):
+        from . import ops
+        ops.check(ops._lib.vl_resample_batch_u8_norm(ops._p(self.desc), self.n, self.C, self.ch, self.cw, self.max_nrows,
+                                                     ops._p(self.tables), ops._p(self.tmp), _floats(self.mean), _floats(self.std),
+                                                     ops._p(self.out), ops._stream()))
+        return self.out
+
+
+def plan_images(images, size, mean, std, out=None, boxes=None):
+    """Host side of `images_to_tensor`: copies host images to the device (one buffer, one slice per image - small
+    pageable copies are the fast path of the HIP runtime, a single 100 MB pageable copy is not), builds the packed
+    per-axis tables of the distinct sizes and one int64 descriptor row per image."""
     n = len(images)
     assert n > 0
     dev = out.device if out is not None else next((im.device for im in images if im.is_cuda), torch.device("cuda"))
     ch, cw = (size, size) if isinstance(size, int) else tuple(size)
     C = images[0].shape[2]
-    # 1. bytes: CUDA images are read in place, host images travel as one packed buffer
     host_idx = [i for i, im in enumerate(images) if not im.is_cuda]
     host_off, total = {}, 0
     for i in host_idx:
         host_off[i] = total
         total += images[i].numel()
-    packed = torch.cat([images[i].reshape(-1) for i in host_idx]).to(dev, non_blocking=True) if host_idx else None
-    # 2. geometry, packed tables, descriptors
+    packed = torch.empty(total, device=dev, dtype=torch.uint8) if host_idx else None
+    for i in host_idx:
+        packed[host_off[i]:host_off[i] + images[i].numel()].copy_(images[i].reshape(-1), non_blocking=True)
     parts, offsets, cursor = [], {}, 0
 
     def table(in_size, out_size):
@@ -251,13 +265,14 @@ def images_to_tensor(images, size, mean, std, out=None, boxes=None):
             cursor += b.size + kk.size
         return offsets[key]
     desc = np.zeros((n, 16), np.int64)
-    tmp_bytes, max_nrows = 0, 0
+    tmp_bytes, max_nrows, keep = 0, 0, [packed]
     for i, im in enumerate(images):
         assert im.dtype == torch.uint8 and im.dim() == 3 and im.shape[2] == C
         H, W = im.shape[:2]
         if im.is_cuda:
             if im.stride(2) != 1 or im.stride(1) != C:
-                im = images[i] = im.contiguous()
+                im = im.contiguous()
+            keep.append(im)
             base, stride = im.data_ptr(), im.stride(0)
         else:
             base, stride = packed.data_ptr() + host_off[i], W * C
@@ -282,6 +297,11 @@ def images_to_tensor(images, size, mean, std, out=None, boxes=None):
     if out is None:
         out = torch.empty(n, C, ch, cw, device=dev, dtype=torch.float32)
     assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (n, C, ch, cw)
-    ops.check(ops._lib.vl_resample_batch_u8_norm(ops._p(desc_d), n, C, ch, cw, max_nrows, ops._p(tables), ops._p(tmp), _floats(mean),
-                                                 _floats(std), ops._p(out), ops._stream()))
-    return out
+    return BatchPlan(desc_d, tables, tmp, out, n, C, ch, cw, max_nrows, mean, std, keep)
+
+
+def images_to_tensor(images, size, mean, std, out=None, boxes=None):
+    """A LIST of uint8 [H, W, C] images of different sizes (CPU or CUDA tensors, same C) -> float32 [n, C, size, size]
+    in two kernel launches (vl_resample_batch_u8_norm): same arithmetic and bits as `image_to_tensor` per image.
+    boxes[i] = (top, left, h, w): crop-then-resize (training)."""
+    return plan_images(images, size, mean, std, out=out, boxes=boxes).launch()
