@@ -302,7 +302,7 @@ _colreduce_ws = {}
 
 def _ws_for(device, rows, cols, planes):
     """Workspace of the deterministic two-stage column reductions (cached per device, grown on demand)."""
-    need = ((rows + 255) // 256) * planes * cols
+    need = int(_lib.vl_colreduce_ws_floats(rows, cols, planes))             # the kernels' own slab geometry, not a copy of it
     t = _colreduce_ws.get(device)
     if t is None or t.numel() < need:
         t = torch.empty(need, device=device, dtype=torch.float32)
