@@ -201,14 +201,15 @@ int vl_pc_gather_normalize(const float* pts, const int64_t* idx, float* out, int
  * axis; xout0/nxout (yout0/nyout) select the crop.  8-bit path = Pillow's Image.resize(BICUBIC) (22-bit fixed-point
  * int32 taps, 8-bit intermediate; byte-exact), replacing torchvision Resize+CenterCrop+ToTensor+Normalize of
  * open_clip/transform.py:138-155: the vertical pass writes out [C,nyout,W] f32 = (u8/255 - mean[c]) / std[c] (mean/std:
- * HOST arrays of C floats) and/or the resized bytes out_u8 [nyout,W,C].  Float path = ATen bicubic (antialiased or the
+ * HOST arrays of C floats) and/or the resized bytes out_u8 [nyout,W,C]; W = source width of the horizontal pass, and in
+ * the vertical pass src is the [nrows, W, C] intermediate whose row 0 is image row row0 (nothing beyond it is read).  Float path = ATen bicubic (antialiased or the
  * 4-tap border-clamped form) with DepthNorm's clamp(lo,hi)/divide_by fused into the read, replacing
  * modal_depth/processors/vt_processor.py:292-337; taps are clamped to the image, so bounds may start at -1. */
-int vl_resample_h_u8(const uint8_t* src, long row_stride, int C, int row0, int nrows, const int* bounds, const int* kk,
-                     int ksize, int xout0, int nxout, uint8_t* dst, hipStream_t stream);
-int vl_resample_v_u8_norm(const uint8_t* src, int W, int C, int row0, const int* bounds, const int* kk, int ksize,
-                          int yout0, int nyout, const float* mean, const float* stdv, float* out, uint8_t* out_u8,
-                          hipStream_t stream);
+int vl_resample_h_u8(const uint8_t* src, long row_stride, int W, int C, int row0, int nrows, const int* bounds,
+                     const int* kk, int ksize, int xout0, int nxout, uint8_t* dst, hipStream_t stream);
+int vl_resample_v_u8_norm(const uint8_t* src, int W, int C, int row0, int nrows, const int* bounds, const int* kk,
+                          int ksize, int yout0, int nyout, const float* mean, const float* stdv, float* out,
+                          uint8_t* out_u8, hipStream_t stream);
 /* The 8-bit path for a LIST of images of different sizes in two launches (blockIdx.z = image).  desc: device array
  * [n][16] int64 per image = {src pointer, row stride in bytes, source width, row0, nrows, xout0, yout0, horizontal
  * bounds offset, horizontal coefficient offset, horizontal ksize, vertical bounds offset, vertical coefficient offset,

@@ -29,49 +29,108 @@ __device__ __forceinline__ unsigned char clip8(int acc) {
   return (unsigned char)min(max(v, 0), 255);
 }
 
+// Tap loop of one output pixel: acc[c] += k[j] * s[j * step + c] for the C channels.  With 3 or 4 channels the bytes of a
+// pixel come from ONE unaligned 4-byte load (gfx950 runs with unaligned access enabled; hipcc itself lowers an align-1
+// 4-byte copy to global_load_dword) instead of C byte loads - the loop is bound by load instructions, not by bytes.  The
+// fourth byte of a 3-channel pixel belongs to the next pixel; `end` is one past the last readable byte, and a thread whose
+// last tap would read beyond it (the final pixel of a buffer only) takes the byte loop.
+template <int C>
+__device__ __forceinline__ void tap_loop(const unsigned char* __restrict__ s, long step, const int* __restrict__ k, int n,
+                                         const unsigned char* end, int (&acc)[C]) {
+  if (C >= 3 && s + (long)(n - 1) * step + 4 <= end) {
+    for (int j = 0; j < n; ++j) {
+      unsigned v;
+      __builtin_memcpy(&v, s + (long)j * step, 4);
+      const int kj = k[j];
+#pragma unroll
+      for (int c = 0; c < C; ++c) acc[c] += (int)((v >> (8 * c)) & 0xffu) * kj;
+    }
+  } else {
+    for (int j = 0; j < n; ++j) {
+      const int kj = k[j];
+#pragma unroll
+      for (int c = 0; c < C; ++c) acc[c] += (int)s[(long)j * step + c] * kj;
+    }
+  }
+}
+
+template <int C>
+__device__ __forceinline__ void h_pixel(const unsigned char* __restrict__ s, const int* __restrict__ k, int n, const unsigned char* end,
+                                        unsigned char* __restrict__ dst) {
+  int acc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = 1 << (PRECISION_BITS - 1);
+  tap_loop<C>(s, C, k, n, end, acc);
+#pragma unroll
+  for (int c = 0; c < C; ++c) dst[c] = clip8(acc[c]);
+}
+
+__device__ __forceinline__ void h_pixel_any(int C, const unsigned char* s, const int* k, int n, const unsigned char* end, unsigned char* dst) {
+  switch (C) {
+    case 1: h_pixel<1>(s, k, n, end, dst); break;
+    case 2: h_pixel<2>(s, k, n, end, dst); break;
+    case 3: h_pixel<3>(s, k, n, end, dst); break;
+    default: h_pixel<4>(s, k, n, end, dst); break;
+  }
+}
+
 // dst[r, i, c] = clip8(2^21 + sum_j kk[xout0+i, j] * src[row0+r, bounds[xout0+i].min + j, c])
-__global__ void __launch_bounds__(256) resample_h_u8_kernel(const unsigned char* __restrict__ src, long row_stride, int C, int row0, int nrows,
-                                                            const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
+__global__ void __launch_bounds__(256) resample_h_u8_kernel(const unsigned char* __restrict__ src, long row_stride, int W, int C, int row0,
+                                                            int nrows, const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
                                                             int xout0, int nxout, unsigned char* __restrict__ dst) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)nrows * nxout) return;
   const int r = (int)(i / nxout), x = (int)(i - (long)r * nxout);
   const int xo = xout0 + x;
   const int xmin = bounds[2 * xo], n = bounds[2 * xo + 1];
-  const int* k = kk + (long)xo * ksize;
-  const unsigned char* s = src + (long)(row0 + r) * row_stride + (long)xmin * C;
-  for (int c = 0; c < C; ++c) {
-    int acc = 1 << (PRECISION_BITS - 1);
-    for (int j = 0; j < n; ++j) acc += (int)s[j * C + c] * k[j];
-    dst[((long)r * nxout + x) * C + c] = clip8(acc);
-  }
+  const unsigned char* end = src + (long)(row0 + nrows - 1) * row_stride + (long)W * C;
+  h_pixel_any(C, src + (long)(row0 + r) * row_stride + (long)xmin * C, kk + (long)xo * ksize, n, end, dst + ((long)r * nxout + x) * C);
 }
 
 struct NormP { float mean[4], std[4]; };
 
 // out[c, y, x] = (clip8(2^21 + sum_j kk[yout0+y, j] * src[bounds[yout0+y].min + j - row0, x, c]) / 255 - mean[c]) / std[c]
-__global__ void __launch_bounds__(256) resample_v_u8_norm_kernel(const unsigned char* __restrict__ src, int W, int C, int row0,
+template <int C>
+__device__ __forceinline__ void v_pixel(const unsigned char* __restrict__ s, long step, const int* __restrict__ k, int n,
+                                        const unsigned char* end, const NormP& np, float* __restrict__ out, long plane,
+                                        unsigned char* __restrict__ out_u8) {
+#pragma clang fp contract(off)
+  int acc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = 1 << (PRECISION_BITS - 1);
+  tap_loop<C>(s, step, k, n, end, acc);
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const unsigned char u = clip8(acc[c]);
+    if (out_u8) out_u8[c] = u;
+    if (out) {
+      const float v = (float)u / 255.0f;
+      out[c * plane] = (v - np.mean[c]) / np.std[c];
+    }
+  }
+}
+
+__device__ __forceinline__ void v_pixel_any(int C, const unsigned char* s, long step, const int* k, int n, const unsigned char* end,
+                                            const NormP& np, float* out, long plane, unsigned char* out_u8) {
+  switch (C) {
+    case 1: v_pixel<1>(s, step, k, n, end, np, out, plane, out_u8); break;
+    case 2: v_pixel<2>(s, step, k, n, end, np, out, plane, out_u8); break;
+    case 3: v_pixel<3>(s, step, k, n, end, np, out, plane, out_u8); break;
+    default: v_pixel<4>(s, step, k, n, end, np, out, plane, out_u8); break;
+  }
+}
+
+__global__ void __launch_bounds__(256) resample_v_u8_norm_kernel(const unsigned char* __restrict__ src, int W, int C, int row0, int nrows,
                                                                  const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
                                                                  int yout0, int nyout, const NormP np, float* __restrict__ out,
                                                                  unsigned char* __restrict__ out_u8) {
-#pragma clang fp contract(off)
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)nyout * W) return;
   const int y = (int)(i / W), x = (int)(i - (long)y * W);
   const int yo = yout0 + y;
   const int ymin = bounds[2 * yo], n = bounds[2 * yo + 1];
-  const int* k = kk + (long)yo * ksize;
-  const unsigned char* s = src + ((long)(ymin - row0) * W + x) * C;
-  for (int c = 0; c < C; ++c) {
-    int acc = 1 << (PRECISION_BITS - 1);
-    for (int j = 0; j < n; ++j) acc += (int)s[(long)j * W * C + c] * k[j];
-    const unsigned char u = clip8(acc);
-    if (out_u8) out_u8[((long)y * W + x) * C + c] = u;
-    if (out) {
-      const float v = (float)u / 255.0f;
-      out[((long)c * nyout + y) * W + x] = (v - np.mean[c]) / np.std[c];
-    }
-  }
+  v_pixel_any(C, src + ((long)(ymin - row0) * W + x) * C, (long)W * C, kk + (long)yo * ksize, n, src + (long)nrows * W * C, np,
+              out ? out + (long)y * W + x : nullptr, (long)nyout * W, out_u8 ? out_u8 + ((long)y * W + x) * C : nullptr);
 }
 
 // ---- batched 8-bit path: one launch per pass for a list of images of DIFFERENT sizes (blockIdx.z = image) ----
@@ -91,20 +150,14 @@ __global__ void __launch_bounds__(256) resample_h_u8_batch_kernel(const long lon
   const int xo = (int)d[5] + x, ksize = (int)d[9];
   const int* bounds = tables + d[7];
   const int xmin = bounds[2 * xo], n = bounds[2 * xo + 1];
-  const int* k = tables + d[8] + (long)xo * ksize;
-  const unsigned char* s = (const unsigned char*)d[0] + ((long)d[3] + r) * d[1] + (long)xmin * C;
-  unsigned char* dst = tmp + d[13] + ((long)r * nxout + x) * C;
-  for (int c = 0; c < C; ++c) {
-    int acc = 1 << (PRECISION_BITS - 1);
-    for (int j = 0; j < n; ++j) acc += (int)s[j * C + c] * k[j];
-    dst[c] = clip8(acc);
-  }
+  const unsigned char* src = (const unsigned char*)d[0];
+  const unsigned char* end = src + (d[3] + nrows - 1) * d[1] + d[2] * C;
+  h_pixel_any(C, src + (d[3] + r) * d[1] + (long)xmin * C, tables + d[8] + (long)xo * ksize, n, end, tmp + d[13] + ((long)r * nxout + x) * C);
 }
 
 __global__ void __launch_bounds__(256) resample_v_u8_norm_batch_kernel(const long long* __restrict__ desc, int C, int nyout, int W,
                                                                        const int* __restrict__ tables, const unsigned char* __restrict__ tmp,
                                                                        const NormP np, float* __restrict__ out) {
-#pragma clang fp contract(off)
   const long long* d = desc + (long)blockIdx.z * DESC_LD;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)nyout * W) return;
@@ -112,15 +165,9 @@ __global__ void __launch_bounds__(256) resample_v_u8_norm_batch_kernel(const lon
   const int yo = (int)d[6] + y, ksize = (int)d[12], row0 = (int)d[3];
   const int* bounds = tables + d[10];
   const int ymin = bounds[2 * yo], n = bounds[2 * yo + 1];
-  const int* k = tables + d[11] + (long)yo * ksize;
-  const unsigned char* s = tmp + d[13] + ((long)(ymin - row0) * W + x) * C;
-  float* o = out + (long)blockIdx.z * C * nyout * W;
-  for (int c = 0; c < C; ++c) {
-    int acc = 1 << (PRECISION_BITS - 1);
-    for (int j = 0; j < n; ++j) acc += (int)s[(long)j * W * C + c] * k[j];
-    const float v = (float)clip8(acc) / 255.0f;
-    o[((long)c * nyout + y) * W + x] = (v - np.mean[c]) / np.std[c];
-  }
+  const unsigned char* t = tmp + d[13];
+  v_pixel_any(C, t + ((long)(ymin - row0) * W + x) * C, (long)W * C, tables + d[11] + (long)yo * ksize, n, t + d[4] * W * C, np,
+              out + (long)blockIdx.z * C * nyout * W + (long)y * W + x, (long)nyout * W, nullptr);
 }
 
 struct ClampP { float lo, hi, div; int on; };
@@ -167,24 +214,25 @@ inline unsigned grid1(long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
 
-extern "C" int vl_resample_h_u8(const uint8_t* src, long row_stride, int C, int row0, int nrows, const int* bounds, const int* kk,
+extern "C" int vl_resample_h_u8(const uint8_t* src, long row_stride, int W, int C, int row0, int nrows, const int* bounds, const int* kk,
                                 int ksize, int xout0, int nxout, uint8_t* dst, hipStream_t stream) {
-  if (C < 1 || C > 4 || nrows <= 0 || nxout <= 0 || ksize <= 0 || row0 < 0 || xout0 < 0)
-    return vl_set_error("vl_resample_h_u8: need 1<=C<=4, nrows, nxout, ksize > 0");
-  hipLaunchKernelGGL(resample_h_u8_kernel, dim3(grid1((long)nrows * nxout)), dim3(256), 0, stream, src, row_stride, C, row0, nrows, bounds,
+  if (C < 1 || C > 4 || W <= 0 || nrows <= 0 || nxout <= 0 || ksize <= 0 || row0 < 0 || xout0 < 0)
+    return vl_set_error("vl_resample_h_u8: need 1<=C<=4, W, nrows, nxout, ksize > 0");
+  hipLaunchKernelGGL(resample_h_u8_kernel, dim3(grid1((long)nrows * nxout)), dim3(256), 0, stream, src, row_stride, W, C, row0, nrows, bounds,
                      kk, ksize, xout0, nxout, dst);
   VL_HIP_OK(hipGetLastError());
   return 0;
 }
 
-extern "C" int vl_resample_v_u8_norm(const uint8_t* src, int W, int C, int row0, const int* bounds, const int* kk, int ksize, int yout0,
-                                     int nyout, const float* mean, const float* stdv, float* out, uint8_t* out_u8, hipStream_t stream) {
-  if (C < 1 || C > 4 || W <= 0 || nyout <= 0 || ksize <= 0 || row0 < 0 || yout0 < 0 || (!out && !out_u8) || (out && (!mean || !stdv)))
-    return vl_set_error("vl_resample_v_u8_norm: need 1<=C<=4, W, nyout, ksize > 0, a destination, and mean/std for the float one");
+extern "C" int vl_resample_v_u8_norm(const uint8_t* src, int W, int C, int row0, int nrows, const int* bounds, const int* kk, int ksize,
+                                     int yout0, int nyout, const float* mean, const float* stdv, float* out, uint8_t* out_u8,
+                                     hipStream_t stream) {
+  if (C < 1 || C > 4 || W <= 0 || nrows <= 0 || nyout <= 0 || ksize <= 0 || row0 < 0 || yout0 < 0 || (!out && !out_u8) || (out && (!mean || !stdv)))
+    return vl_set_error("vl_resample_v_u8_norm: need 1<=C<=4, W, nrows, nyout, ksize > 0, a destination, and mean/std for the float one");
   NormP np{};
   for (int c = 0; c < C && out; ++c) { np.mean[c] = mean[c]; np.std[c] = stdv[c]; }
-  hipLaunchKernelGGL(resample_v_u8_norm_kernel, dim3(grid1((long)nyout * W)), dim3(256), 0, stream, src, W, C, row0, bounds, kk, ksize,
-                     yout0, nyout, np, out, out_u8);
+  hipLaunchKernelGGL(resample_v_u8_norm_kernel, dim3(grid1((long)nyout * W)), dim3(256), 0, stream, src, W, C, row0, nrows, bounds, kk,
+                     ksize, yout0, nyout, np, out, out_u8);
   VL_HIP_OK(hipGetLastError());
   return 0;
 }

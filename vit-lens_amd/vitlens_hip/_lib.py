@@ -41,8 +41,8 @@ SIGNATURES = {
     "vl_gemm_bf16_ex": [P, P, P, P, P, P, I, I, I, I, I, I, F, I, I, I, I, P],
     "vl_fps": [P, P, P, P, I, I, I, P],
     "vl_pc_gather_normalize": [P, P, P, I, I, I, I, P],
-    "vl_resample_h_u8": [P, L, I, I, I, P, P, I, I, I, P, P],
-    "vl_resample_v_u8_norm": [P, I, I, I, P, P, I, I, I, P, P, P, P, P],
+    "vl_resample_h_u8": [P, L, I, I, I, I, P, P, I, I, I, P, P],
+    "vl_resample_v_u8_norm": [P, I, I, I, I, P, P, I, I, I, P, P, P, P, P],
     "vl_resample_batch_u8_norm": [P, I, I, I, I, I, P, P, P, P, P, P],
     "vl_resample_h_f32": [P, L, I, I, I, P, P, I, I, I, I, F, F, F, P, P],
     "vl_resample_v_f32_norm": [P, I, I, I, P, P, I, I, I, F, F, P, P],

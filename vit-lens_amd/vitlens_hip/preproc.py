@@ -156,13 +156,13 @@ def image_to_tensor(img_u8, size, mean, std, out=None, box=None, want_u8=False):
     vb, vk, vks, vb_host = _on_device(("pil", H, nh), lambda: pil_bicubic_tables(H, nh), dev)
     row0, nrows = _window(vb_host, ctop, ch, H)
     tmp = torch.empty(nrows, cw, C, device=dev, dtype=torch.uint8)
-    ops.check(ops._lib.vl_resample_h_u8(ops._p(img_u8), img_u8.stride(0), C, row0, nrows, ops._p(hb), ops._p(hk), hks, cleft, cw,
+    ops.check(ops._lib.vl_resample_h_u8(ops._p(img_u8), img_u8.stride(0), W, C, row0, nrows, ops._p(hb), ops._p(hk), hks, cleft, cw,
                                         ops._p(tmp), ops._stream()))
     if out is None:
         out = torch.empty(C, ch, cw, device=dev, dtype=torch.float32)
     assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (C, ch, cw)
     u8 = torch.empty(ch, cw, C, device=dev, dtype=torch.uint8) if want_u8 else None
-    ops.check(ops._lib.vl_resample_v_u8_norm(ops._p(tmp), cw, C, row0, ops._p(vb), ops._p(vk), vks, ctop, ch, _floats(mean), _floats(std),
+    ops.check(ops._lib.vl_resample_v_u8_norm(ops._p(tmp), cw, C, row0, nrows, ops._p(vb), ops._p(vk), vks, ctop, ch, _floats(mean), _floats(std),
                                              ops._p(out), ops._p(u8), ops._stream()))
     return (out, u8) if want_u8 else out
 
