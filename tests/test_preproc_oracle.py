@@ -84,3 +84,31 @@ def test_depth_eval_transform_matches_the_torch_pipeline():
     want = (r[top:top + 224, left:left + 224] - 0.0418) / 0.0295
     got = po.depth_eval_transform(d.numpy())
     assert got.shape == (1, 224, 224) and np.abs(got[0] - want.numpy()).max() < 1e-4
+
+
+@pytest.mark.needs_reference
+def test_oracle_on_the_reference_example_photographs():
+    """BASELINE config C1's inputs: the four JPEGs of /root/reference/assets/example (build container only) through
+    Pillow + torch (what `image_transform(224, is_train=False)` of the reference computes) against the restatement -
+    real photographs with smooth gradients and saturated regions instead of noise; and the product's tables on the
+    same geometries."""
+    import glob
+    from open_clip.constants import OPENAI_DATASET_MEAN, OPENAI_DATASET_STD
+    from vitlens_hip import preproc
+    files = sorted(glob.glob("/root/reference/assets/example/image_*.jpg"))
+    if len(files) < 4:
+        pytest.skip("reference example images not present")
+    for f in files:
+        im = Image.open(f).convert("RGB")
+        w, h = im.size
+        nh, nw = po.resized_output_size(h, w, 224)
+        top, left = po.center_crop_origin(nh, nw, 224)
+        r = im.resize((nw, nh), Image.BICUBIC).crop((left, top, left + 224, top + 224))
+        t = torch.from_numpy(np.array(r)).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+        want = t.sub_(torch.as_tensor(OPENAI_DATASET_MEAN)[:, None, None]).div_(torch.as_tensor(OPENAI_DATASET_STD)[:, None, None])
+        got = po.image_eval_transform(np.array(im), 224, OPENAI_DATASET_MEAN, OPENAI_DATASET_STD)
+        assert np.array_equal(got, want.numpy()), f
+        for n_in, n_out in ((w, nw), (h, nh)):
+            b, kk, ks = preproc.pil_bicubic_tables(n_in, n_out)
+            ob, okk, oks = po.pil_coeffs(n_in, n_out)
+            assert ks == oks and np.array_equal(b, ob) and np.array_equal(kk, okk)
