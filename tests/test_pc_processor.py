@@ -37,6 +37,21 @@ def test_oracle_pc_processing_equals_reference_functions():
     got, idx = O.pc_farthest_point_sample(pts, 128, start)
     assert np.array_equal(got, want)
     assert np.allclose(O.pc_norm(got), ref.pc_norm(want), rtol=0, atol=0)
+    # the random-subset branch (pc_processor.py:41-45,81-84): the product draws np.random.permutation(N)[:n], the reference
+    # shuffles arange(N) in place - the same draws of the legacy global RNG
+    np.random.seed(9)
+    want = ref.random_sample(pts, 100)
+    np.random.seed(9)
+    assert np.array_equal(pts[np.random.permutation(700)[:100]], want)
+    # and the example clouds of the reference (8192 points = npoint: the processor takes the random-subset branch)
+    files = sorted(__import__("glob").glob("/root/reference/assets/example/pc_*.npy"))
+    for f in files[:2]:
+        pc = np.load(f)
+        np.random.seed(3)
+        want = ref.PCProcessorEval(8192, True)(pc).numpy()
+        np.random.seed(3)
+        sub = np.random.permutation(pc.shape[0])[:8192]
+        assert np.array_equal(O.pc_norm(pc[sub]), want), f
 
 
 @pytest.mark.gpu
