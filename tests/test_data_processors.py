@@ -64,3 +64,42 @@ def test_processor_table_and_vitlens_wiring():
     assert vl.processor("eeg") is vl.processor("eeg")
     with pytest.raises(RuntimeError):                                             # no GPU here: the towers refuse CPU tensors loudly
         vl.encode({ModalityType.EEG: torch.zeros(1, 128, 512)})
+
+
+_REF_PRE = r'''
+import json, sys, types
+sys.path.insert(0, sys.argv[1])
+import ref_loader
+ref_loader.load()
+sys.modules.setdefault("omegaconf", types.SimpleNamespace(OmegaConf=types.SimpleNamespace(create=lambda *a, **k: {})))
+from mm_vit_lens.data_processors import TextProcessor
+from easydict import EasyDict
+tp = TextProcessor(cfg=EasyDict(model="ViT-L-14"))
+tp5 = TextProcessor(max_words=5, cfg=EasyDict(model="ViT-L-14"))
+texts = json.load(open(sys.argv[2]))
+print("JSON" + json.dumps({"pre": [tp.pre_caption(t) for t in texts], "pre5": [tp5.pre_caption(t) for t in texts],
+                           "ids": tp(texts[:64]).tolist()}))
+'''
+
+
+def test_text_processor_against_the_reference(tmp_path):
+    """TextProcessor.pre_caption / __call__ of the imported reference (build container only) on the tokenizer fuzz set."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/vitlens/src/mm_vit_lens"):
+        pytest.skip("/root/reference not present")
+    from test_tokenizer import _fuzz_texts
+    from mm_vit_lens.data_processors import TextProcessor
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    texts = _fuzz_texts(600, seed=1)
+    p = tmp_path / "texts.json"
+    json.dump(texts, open(p, "w"))
+    r = subprocess.run([sys.executable, "-c", _REF_PRE, os.path.join(root, "oracle"), str(p)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = json.loads(r.stdout[r.stdout.index("JSON") + 4:])
+    tp, tp5 = TextProcessor(), TextProcessor(max_words=5)
+    assert [tp.pre_caption(t) for t in texts] == ref["pre"]
+    assert [tp5.pre_caption(t) for t in texts] == ref["pre5"]
+    assert tp(texts[:64]).tolist() == ref["ids"]

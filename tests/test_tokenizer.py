@@ -36,3 +36,53 @@ def test_decode_roundtrip_ascii():
     n = int(ids.argmax())
     assert decode(ids[1:n]).strip() == "a photo of a cat ."[:0] + decode(ids[1:n]).strip()
     assert "photo" in decode(ids[1:n]) and "cat" in decode(ids[1:n])
+
+
+_REF_TOK = r'''
+import json, sys
+sys.path.insert(0, sys.argv[1])
+import ref_loader
+oc = ref_loader.load()
+texts = json.load(open(sys.argv[2]))
+print("JSON" + json.dumps({"ids77": oc.tokenize(texts).tolist(), "ids20": oc.tokenize(texts, context_length=20).tolist()}))
+'''
+
+
+def _fuzz_texts(n=1500, seed=0):
+    """ASCII captions (the reference runs `ftfy.fix_text` first, which is absent here and the identity on ASCII): words,
+    digits, contractions, punctuation runs, mixed case, irregular white space, HTML entities (unescaped twice by the
+    reference's basic_clean), and over-length inputs that hit the truncation rule."""
+    import random
+    rng = random.Random(seed)
+    words = ["a", "photo", "of", "the", "Bird", "DOG's", "don't", "I'll", "we've", "they're", "he'd", "I'm", "cat", "3d", "2023", "x86_64",
+             "point", "cloud", "depth-map", "e.g.", "hello!!!", "(test)", "$9.99", "50%", "a/b", "C++", "#tag", "@user", "&amp;", "&lt;b&gt;",
+             "&amp;amp;", "co-op", "re_use", "...", "?!", "--", "'quoted'", '"double"', "naive", "semi;colon", "new\nline", "tab\there",
+             "UPPER", "MiXeD", "end.", "a1b2", "007", "1,000", "3.14159", "~tilde~", "[brackets]", "{curly}", "<angle>", "back\\slash",
+             "under_score", "pipe|pipe", "caret^", "`tick`", "plus+minus", "equal=sign", "star*star", "colon:"]
+    seps = [" ", " ", " ", "  ", "   ", "\t", "\n", " , ", ". ", ""]
+    out = []
+    for i in range(n):
+        k = rng.choice([1, 2, 3, 5, 8, 13, 30, 90]) if i % 50 else 0
+        out.append("".join(rng.choice(words) + rng.choice(seps) for _ in range(k)) + rng.choice(["", " ", ".", "\n"]))
+    return out
+
+
+def test_tokenizer_fuzz_against_the_reference(tmp_path):
+    """1500 generated captions through the imported reference tokenizer (build container only) and through the product:
+    identical int64 ids at context lengths 77 and 20 (bit-exact row a1 of the scope table beyond the 52 committed KATs)."""
+    import subprocess
+    import sys
+    import pytest
+    if not os.path.isdir("/root/reference/vitlens/src/open_clip"):
+        pytest.skip("/root/reference not present")
+    from open_clip.tokenizer import tokenize
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    texts = _fuzz_texts()
+    p = tmp_path / "texts.json"
+    json.dump(texts, open(p, "w"))
+    r = subprocess.run([sys.executable, "-c", _REF_TOK, os.path.join(root, "oracle"), str(p)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = json.loads(r.stdout[r.stdout.index("JSON") + 4:])
+    got77, got20 = tokenize(texts), tokenize(texts, context_length=20)
+    bad = [i for i in range(len(texts)) if got77[i].tolist() != ref["ids77"][i] or got20[i].tolist() != ref["ids20"][i]]
+    assert not bad, (len(bad), [texts[i] for i in bad[:3]])
