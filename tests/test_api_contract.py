@@ -211,3 +211,47 @@ def test_set_bn_sync_is_a_noop_without_ranks():
     assert m.set_bn_sync(False)._bn_sync is None
     m.modality = "depth"
     assert m.set_bn_sync(True, comm=comm, world_size=2)._bn_sync is None
+
+
+_REF_RESIZE = r'''
+import json, sys, torch
+from types import SimpleNamespace
+sys.path.insert(0, sys.argv[1])
+import ref_loader
+oc = ref_loader.load()
+from open_clip.model import resize_pos_embed
+g = torch.Generator().manual_seed(0)
+pe = torch.randn(50, 8, generator=g)
+out = {}
+for name, n_lat, grid in (("p16", 16, 7), ("p20", 20, 7), ("p49", 49, 7), ("p100", 100, 7), ("g14", None, 14), ("g7", None, 7)):
+    vis = SimpleNamespace(grid_size=(grid, grid), use_perceiver=n_lat is not None,
+                          vision_cfg=SimpleNamespace(exp_args=SimpleNamespace(perceiver_num_latents=n_lat)))
+    sd = {"visual.positional_embedding": pe.clone()}
+    resize_pos_embed(sd, SimpleNamespace(visual=vis))
+    out[name] = sd["visual.positional_embedding"].tolist()
+print("JSON" + json.dumps(out))
+'''
+
+
+@pytest.mark.needs_reference
+def test_resize_pos_embed_equals_the_reference():
+    """open_clip/model.py:1079-1150 (imported, build container only) against the product's factory.resize_pos_embed: grid
+    -> latent counts that are / are not perfect squares (bicubic, then the nearest resample), equal lengths, plain grids."""
+    from types import SimpleNamespace
+    r = subprocess.run([sys.executable, "-c", _REF_RESIZE, os.path.join(ROOT, "oracle")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = json.loads(r.stdout[r.stdout.index("JSON") + 4:])
+    import importlib
+    for k in [k for k in sys.modules if k == "open_clip" or k.startswith("open_clip.")]:
+        del sys.modules[k]
+    F = importlib.import_module("open_clip.factory")
+    g = torch.Generator().manual_seed(0)
+    pe = torch.randn(50, 8, generator=g)
+    for name, n_lat, grid in (("p16", 16, 7), ("p20", 20, 7), ("p49", 49, 7), ("p100", 100, 7), ("g14", None, 14), ("g7", None, 7)):
+        vis = SimpleNamespace(cfg=SimpleNamespace(image_size=32 * grid, patch_size=32, exp_args=SimpleNamespace(perceiver_num_latents=n_lat)),
+                              use_perceiver=n_lat is not None)
+        sd = {"visual.positional_embedding": pe.clone()}
+        F.resize_pos_embed(sd, SimpleNamespace(visual=vis))
+        want = torch.tensor(ref[name])
+        assert sd["visual.positional_embedding"].shape == want.shape, name
+        assert torch.allclose(sd["visual.positional_embedding"], want, atol=1e-6), name
