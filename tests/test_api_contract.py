@@ -255,3 +255,65 @@ def test_resize_pos_embed_equals_the_reference():
         want = torch.tensor(ref[name])
         assert sd["visual.positional_embedding"].shape == want.shape, name
         assert torch.allclose(sd["visual.positional_embedding"], want, atol=1e-6), name
+
+
+_REF_LOAD = r'''
+import json, os, sys, tempfile, torch
+sys.path.insert(0, sys.argv[1])
+import ref_loader
+oc = ref_loader.load()
+import gen_golden as G
+from open_clip.factory import load_checkpoint
+work = sys.argv[2]
+json.dump(G.TINY, open(os.path.join(work, "tiny-lens.json"), "w"))
+oc.add_model_config(work)
+args = G.tiny_args("depth")
+torch.manual_seed(0)
+a = oc.tri_create_model("tiny-lens", None, precision="fp32", device="cpu", output_dict=True, args=args)
+# an open_clip-style training checkpoint: the image encoder is called `visual`, DDP prefix, wrapped in {"state_dict": ...}
+sd = {k: v for k, v in a.state_dict().items() if not k.startswith(("image.", "visual."))}
+sd.update({"visual." + k[len("image."):]: v for k, v in a.state_dict().items() if k.startswith("image.")})
+torch.save({"epoch": 3, "state_dict": {"module." + k: v.clone() for k, v in sd.items()}}, os.path.join(work, "clip.pt"))
+torch.manual_seed(1)
+b = oc.tri_create_model("tiny-lens", None, precision="fp32", device="cpu", output_dict=True, args=args)
+inc = load_checkpoint(b, os.path.join(work, "clip.pt"), strict=False, args=args)
+torch.save({k: v.clone() for k, v in b.state_dict().items()}, os.path.join(work, "loaded.pt"))
+print("JSON" + json.dumps({"missing": sorted(inc.missing_keys), "unexpected": sorted(inc.unexpected_keys),
+                           "args": {k: v for k, v in args.items() if isinstance(v, (int, float, str, bool, type(None)))}}))
+'''
+
+
+@pytest.mark.needs_reference
+def test_load_checkpoint_equals_the_reference(tmp_path):
+    """factory.load_checkpoint (factory.py:119-160, imported, build container only) on an open_clip-style checkpoint
+    (`visual.*` = the image encoder, `module.` prefix, {"state_dict": ...}): the same tensors end up in every parameter
+    of the tri-modal model (`visual.* -> image.*` duplication AND the modality tower initialised from the ViT), the same
+    keys are reported missing / unexpected."""
+    from types import SimpleNamespace
+    r = subprocess.run([sys.executable, "-c", _REF_LOAD, os.path.join(ROOT, "oracle"), str(tmp_path)], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = json.loads(r.stdout[r.stdout.index("JSON") + 4:])
+    want = torch.load(tmp_path / "loaded.pt")
+    import importlib
+    for k in [k for k in sys.modules if k == "open_clip" or k.startswith("open_clip.")]:
+        del sys.modules[k]
+    oc = importlib.import_module("open_clip")
+    oc.add_model_config(str(tmp_path))
+    args = SimpleNamespace(**ref["args"])
+    torch.manual_seed(2)
+    model = oc.tri_create_model("tiny-lens", None, device="cpu", output_dict=True, args=args)
+    inc = oc.load_checkpoint(model, str(tmp_path / "clip.pt"), strict=False, args=args)
+    assert sorted(inc.missing_keys) == ref["missing"], set(inc.missing_keys) ^ set(ref["missing"])
+    assert sorted(inc.unexpected_keys) == ref["unexpected"], set(inc.unexpected_keys) ^ set(ref["unexpected"])
+    got = model.state_dict()
+    assert set(got) == set(want)
+    loaded = [k for k in want if k not in ref["missing"]]
+    assert len(loaded) > 50
+    for k in loaded:
+        assert torch.equal(got[k].cpu(), want[k]), k
+    # and through tri_create_model(pretrained=path), the way the training mains call it
+    torch.manual_seed(3)
+    m2 = oc.tri_create_model("tiny-lens", str(tmp_path / "clip.pt"), device="cpu", output_dict=True, args=args)
+    for k in loaded:
+        assert torch.equal(m2.state_dict()[k].cpu(), want[k]), k
