@@ -317,3 +317,36 @@ def test_load_checkpoint_equals_the_reference(tmp_path):
     m2 = oc.tri_create_model("tiny-lens", str(tmp_path / "clip.pt"), device="cpu", output_dict=True, args=args)
     for k in loaded:
         assert torch.equal(m2.state_dict()[k].cpu(), want[k]), k
+
+
+_REF_CFG = r'''
+import json, sys
+sys.path.insert(0, sys.argv[1])
+import ref_loader
+ref_loader.load()
+from mm_vit_lens.model_cfg import fetch_model_cfg
+out = {}
+for m in ("image", "pc", "depth", "audio", "tactile", "eeg"):
+    try:
+        c = fetch_model_cfg(modality=m, model_option="vitlensL")
+    except Exception as e:
+        out[m] = {"__error__": repr(e)}
+        continue
+    out[m] = {k: v for k, v in dict(c).items() if isinstance(v, (int, float, str, bool, type(None)))}
+print("JSON" + json.dumps(out))
+'''
+
+
+@pytest.mark.needs_reference
+def test_model_cfg_values_equal_the_reference():
+    """mm_vit_lens/model_cfg.py (imported, build container only): for every modality the configuration has exactly the
+    reference's keys and values, plus the four attributes TriCLIP.forward / lock read and the reference's defaults omit."""
+    r = subprocess.run([sys.executable, "-c", _REF_CFG, os.path.join(ROOT, "oracle")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = json.loads(r.stdout[r.stdout.index("JSON") + 4:])
+    from mm_vit_lens.model_cfg import fetch_model_cfg
+    for m, want in ref.items():
+        assert "__error__" not in want, (m, want)
+        mine = vars(fetch_model_cfg(m))
+        assert {k: mine.get(k, "<missing>") for k in want} == want, m
+        assert set(mine) - set(want) == {"unlock_from_head", "vid_use_fpos", "vid_use_ltpos", "vid_distill_tokens"}, m
