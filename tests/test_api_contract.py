@@ -89,7 +89,7 @@ def test_cpu_model_forward_fails_loudly():
     import importlib
     oc = importlib.import_module("open_clip")
     from mm_vit_lens.model_cfg import fetch_model_cfg
-    m = oc.tri_create_model("ViT-B-32", device="cpu", args=fetch_model_cfg("image"))
+    m = oc.tri_create_model("ViT-B-32", device="cpu", args=fetch_model_cfg(modality="image"))
     with pytest.raises(RuntimeError):
         m.encode_image(torch.zeros(1, 3, 224, 224))
 
@@ -347,6 +347,73 @@ def test_model_cfg_values_equal_the_reference():
     from mm_vit_lens.model_cfg import fetch_model_cfg
     for m, want in ref.items():
         assert "__error__" not in want, (m, want)
-        mine = vars(fetch_model_cfg(m))
+        mine = vars(fetch_model_cfg(modality=m))
         assert {k: mine.get(k, "<missing>") for k in want} == want, m
         assert set(mine) - set(want) == {"unlock_from_head", "vid_use_fpos", "vid_use_ltpos", "vid_distill_tokens"}, m
+
+
+_SIG_TARGETS = [
+    ("open_clip", "tokenize"), ("open_clip", "get_tokenizer"), ("open_clip", "tri_create_model"),
+    ("open_clip", "tri_create_model_and_transforms"), ("open_clip", "create_loss"), ("open_clip", "add_model_config"),
+    ("open_clip", "get_model_config"), ("open_clip", "image_transform"),
+    ("open_clip.model", "TriCLIP.encode_image"), ("open_clip.model", "TriCLIP.encode_text"), ("open_clip.model", "TriCLIP.encode_visual"),
+    ("open_clip.model", "TriCLIP.forward"), ("open_clip.model", "TriCLIP.lock_image_tower"), ("open_clip.model", "TriCLIP.lock_visual_tower"),
+    ("open_clip.model", "TriCLIP.lock_text_tower"), ("open_clip.model", "TriCLIP.set_grad_checkpointing"),
+    ("open_clip.loss", "ClipLoss.__init__"), ("open_clip.loss", "ClipLoss.forward"), ("open_clip.loss", "ClipLossGeneral.__init__"),
+    ("open_clip.loss", "ClipLossGeneral.forward"), ("open_clip.loss", "TriClipLoss.__init__"), ("open_clip.loss", "TriClipLoss.forward"),
+    ("open_clip.loss", "gather_features"), ("open_clip.factory", "load_checkpoint"), ("open_clip.factory", "resize_pos_embed"),
+    ("open_clip.zero_shot_classifier", "build_zero_shot_classifier"),
+    ("mm_vit_lens.model_cfg", "fetch_model_cfg"),
+]
+
+_REF_SIG = r'''
+import importlib, inspect, json, sys
+sys.path.insert(0, sys.argv[1])
+import ref_loader
+ref_loader.load()
+out = {}
+for mod, name in json.loads(sys.argv[2]):
+    obj = importlib.import_module(mod)
+    for part in name.split("."):
+        obj = getattr(obj, part)
+    out[mod + ":" + name] = [[p.name, None if p.default is inspect.Parameter.empty else repr(p.default), str(p.kind)]
+                             for p in inspect.signature(obj).parameters.values()]
+print("JSON" + json.dumps(out))
+'''
+
+
+@pytest.mark.needs_reference
+def test_public_signatures_equal_the_reference():
+    """SURVEY 8(b) "callables to keep": parameter names, order and defaults of the drop-in surface against the imported
+    reference (build container only).  The product may only APPEND optional parameters (e.g. `device`, `chunk_rows`)."""
+    import importlib
+    import inspect
+    r = subprocess.run([sys.executable, "-c", _REF_SIG, os.path.join(ROOT, "oracle"), json.dumps(_SIG_TARGETS)], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = json.loads(r.stdout[r.stdout.index("JSON") + 4:])
+    for k in [k for k in sys.modules if k == "open_clip" or k.startswith("open_clip.") or k.startswith("mm_vit_lens")]:
+        del sys.modules[k]
+    bad = []
+    for mod, name in _SIG_TARGETS:
+        obj = importlib.import_module(mod)
+        for part in name.split("."):
+            obj = getattr(obj, part)
+        mine = [[p.name, None if p.default is inspect.Parameter.empty else repr(p.default), str(p.kind)]
+                for p in inspect.signature(obj).parameters.values()]
+        want = ref[mod + ":" + name]
+        want_names = [w[0] for w in want if w[2] not in ("VAR_KEYWORD", "VAR_POSITIONAL")]
+        mine_names = [m[0] for m in mine if m[2] not in ("VAR_KEYWORD", "VAR_POSITIONAL")]
+        if mine_names[:len(want_names)] != want_names:
+            bad.append((name, "names", mine_names, want_names))
+            continue
+        for m, w in zip(mine, want):
+            if w[2] in ("VAR_KEYWORD", "VAR_POSITIONAL"):
+                continue
+            site = w[0] == "cache_dir" or (name == "build_zero_shot_classifier" and w[0] == "device")
+            if m[1] != w[1] and not site:          # cache_dir: a site path; the classifier's device defaults to the GPU (there is no CPU path)
+                bad.append((name, m[0], m[1], w[1]))
+        extra = [m for m in mine[len(want_names):] if m[2] not in ("VAR_KEYWORD", "VAR_POSITIONAL")]
+        if any(m[1] is None for m in extra):
+            bad.append((name, "appended parameter without default", extra))
+    assert not bad, bad

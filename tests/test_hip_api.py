@@ -40,7 +40,7 @@ def test_c1_vitb32_image_text_pairs_through_api():
     oc = _oc()
     from mm_vit_lens.model_cfg import fetch_model_cfg
     torch.manual_seed(0)
-    model = oc.tri_create_model("ViT-B-32", None, precision="fp32", device="cuda", output_dict=True, args=fetch_model_cfg("image"))
+    model = oc.tri_create_model("ViT-B-32", None, precision="fp32", device="cuda", output_dict=True, args=fetch_model_cfg(modality="image"))
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     g = torch.Generator().manual_seed(11)
     image = torch.randn(4, 3, 224, 224, generator=g)

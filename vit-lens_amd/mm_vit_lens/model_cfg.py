@@ -38,8 +38,14 @@ _MODALITY = {
 MODEL = {"vitlensL": dict(model="ViT-L-14", pretrained="datacomp_xl_s13b_b90k")}
 
 
-def fetch_model_cfg(modality="pc", model_option="vitlensL"):
+def fetch_model_cfg(model_keys=["model", "pretrained"], modality="pc", model_option="vitlensL"):
+    """model_cfg.py:185-197: defaults, the listed keys of the model option, then the modality's overrides ("image",
+    "video" and "text" have none)."""
     if model_option not in MODEL:
         raise NotImplementedError(model_option)
-    d = dict(_DEFAULT); d.update(MODEL[model_option]); d.update(_MODALITY[modality])
+    d = dict(_DEFAULT)
+    for k in model_keys:
+        d[k] = MODEL[model_option][k]
+    if modality not in ("image", "video", "text"):
+        d.update(_MODALITY[modality])
     return SimpleNamespace(**d)

@@ -29,11 +29,11 @@ class ViTLens(nn.Module):
         for m in self.modality_loaded:
             if m in (ModalityType.IMAGE, ModalityType.TEXT):
                 if base is None:
-                    cfg = fetch_model_cfg("image", model_var)
+                    cfg = fetch_model_cfg(modality="image", model_option=model_var)
                     base = tri_create_model(cfg.model, None, device=self._dev, args=cfg)
                 self.vitlens[m] = base
             elif m in (ModalityType.DEPTH, ModalityType.AUDIO, ModalityType.PC, ModalityType.TACTILE, ModalityType.EEG):
-                cfg = fetch_model_cfg(m, model_var)
+                cfg = fetch_model_cfg(modality=m, model_option=model_var)
                 self.vitlens[m] = tri_create_model(cfg.model, None, device=self._dev, args=cfg)
             else:
                 raise NotImplementedError(f"modality {m!r} is outside the hot path (SURVEY §8)")
