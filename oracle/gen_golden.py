@@ -307,8 +307,58 @@ def pc_bn_train_case(oc, seed):
     print(f"tiny_pc_bntrain: {len(res)} arrays, loss {float(loss):.6f}")
 
 
+def pnsa_case(seed: int):
+    """The `pnsa` point tokenizer (pointnet_util.py:345-368) alone, eval- and train-mode BatchNorm: weights, inputs, the
+    FPS start the reference's fallback sampler drew, tokens, FPS / ball-query indices, and the gradients of a random
+    upstream gradient w.r.t. every parameter (train mode).  10 000 x 6 inputs are the OpenShape geometry; the tiny case
+    keeps the channel layout (xyz + 3 feature channels) at 600 points."""
+    from types import SimpleNamespace
+    ref = ref_loader.load_pointnet_util()
+    cfg = SimpleNamespace(num_group=32, radius=0.3, group_size=16, in_dim=3, encoder_dims=64, trans_dim=64)
+    torch.manual_seed(seed)
+    tok = ref.PointNSATokenizer(cfg)
+    with torch.no_grad():
+        for bn in tok.sa.mlp_bns:
+            bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5)
+            bn.weight.normal_(1, 0.1); bn.bias.normal_(0, 0.1)
+    g = torch.Generator().manual_seed(seed + 1)
+    B, N = 4, 600
+    xyz = torch.rand(B, N, 3, generator=g) * 2 - 1
+    feats = torch.rand(B, N, 3, generator=g)
+    res = {"meta": np.array(json.dumps({"cfg": vars(cfg), "B": B, "N": N}))}
+    for k, v in tok.state_dict().items():
+        res["sd/" + k] = v.numpy().copy()
+    res["in/xyz"], res["in/features"] = xyz.numpy(), feats.numpy()
+    torch.manual_seed(seed + 2)
+    res["in/fps_start"] = torch.randint(0, N, (B,), dtype=torch.long).numpy()
+    for mode in ("eval", "train"):
+        tok.train(mode == "train")
+        torch.manual_seed(seed + 2)
+        out = tok(feats, xyz=xyz)["x"]
+        res[f"out/{mode}/tokens"] = out.detach().numpy()
+        if mode == "train":
+            dctx = torch.randn(out.shape, generator=g)
+            res["in/dctx"] = dctx.numpy()
+            tok.zero_grad()
+            out.backward(dctx)
+            for name, prm in tok.named_parameters():
+                res["grad/" + name] = prm.grad.numpy().copy()
+            for k, v in tok.state_dict().items():
+                if "running_" in k:
+                    res["sd_after/" + k] = v.numpy().copy()
+    torch.manual_seed(seed + 2)
+    cidx = ref.farthest_point_sample(xyz, cfg.num_group)
+    res["out/fps_idx"] = cidx.numpy()
+    res["out/ball_idx"] = ref.query_ball_point(cfg.radius, cfg.group_size, xyz, ref.index_points(xyz, cidx)).numpy()
+    np.savez_compressed(os.path.join(OUT, "tiny_pnsa.npz"), **res)
+    print(f"tiny_pnsa: {len(res)} arrays")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "pnsa":
+        pnsa_case(seed=int(sys.argv[3]))
+        return
     oc = ref_loader.load()
     if len(sys.argv) > 2 and sys.argv[1] == "--only":      # e.g. `--only eeg 23`: add one case without touching the others
         with tempfile.TemporaryDirectory() as td:

@@ -147,3 +147,42 @@ def lens_args(modality: str, **overrides):
             cfg[k] = v
     cfg.update(overrides)
     return cfg
+
+
+def load_pointnet_util():
+    """The reference's modal_3d/models/pointnet/pointnet_util.py as a stand-alone module (the `pnsa` tokenizer).  It
+    imports `dgl.geometry` and `torch_redstone` at module level; neither is installed.  They are provided as shells: with
+    `dgl.geometry.farthest_point_sampler` missing, the reference's own `farthest_point_sample` takes its fallback
+    (pointnet_util.py:83-98, a torch FPS whose start index comes from `torch.randint`), and `rst.Lambda` is the one-line
+    module wrapper it is in torch_redstone.  Used by tests / gen_golden only."""
+    import importlib.util
+    import types
+    import torch.nn as nn
+    path = os.path.join(REF_SRC, "open_clip", "modal_3d", "models", "pointnet", "pointnet_util.py")
+    if "dgl" not in sys.modules:
+        dgl = types.ModuleType("dgl"); dgl.geometry = types.ModuleType("dgl.geometry")
+        sys.modules["dgl"], sys.modules["dgl.geometry"] = dgl, dgl.geometry
+    if "torch_redstone" not in sys.modules:
+        class Lambda(nn.Module):
+            def __init__(self, fn):
+                super().__init__(); self.fn = fn
+
+            def forward(self, *a, **k):
+                return self.fn(*a, **k)
+        sys.modules["torch_redstone"] = types.SimpleNamespace(Lambda=Lambda)
+    sample = types.ModuleType("open_clip.util.Sample")
+    sample.Sample = dict
+    names = ("open_clip", "open_clip.util", "open_clip.util.Sample")
+    saved = {k: sys.modules.get(k) for k in names}
+    sys.modules.update({"open_clip": types.ModuleType("open_clip"), "open_clip.util": types.ModuleType("open_clip.util"),
+                        "open_clip.util.Sample": sample})
+    try:
+        spec = importlib.util.spec_from_file_location("ref_pointnet_util", path)
+        mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return mod

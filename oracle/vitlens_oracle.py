@@ -257,6 +257,58 @@ def point_tokens(sd: SD, p: str, pts: Tensor, lens: LensSpec, fps_start: Tensor,
     return tok, pos, cidx, nidx
 
 
+# ----------------------------------------------------------------------------- PointNet set-abstraction tokenizer ("pnsa")
+def ball_query_indices(radius: float, nsample: int, xyz: Tensor, new_xyz: Tensor) -> Tensor:
+    """query_ball_point, modal_3d/models/pointnet/pointnet_util.py:101-123 (+ square_distance :24-46): for every centre
+    the FIRST `nsample` point indices (ascending) with squared distance <= radius^2, the distance taken as
+    -2 c.p + |c|^2 + |p|^2 in that order of accumulation; short groups are filled with their first index."""
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    d = -2 * torch.matmul(new_xyz, xyz.permute(0, 2, 1))
+    d = d + torch.sum(new_xyz ** 2, -1).view(B, S, 1)
+    d = d + torch.sum(xyz ** 2, -1).view(B, 1, N)
+    idx = torch.arange(N, dtype=torch.long).view(1, 1, N).repeat(B, S, 1)
+    idx[d > radius ** 2] = N
+    idx = idx.sort(dim=-1)[0][:, :, :nsample]
+    first = idx[..., :1].repeat(1, 1, nsample)
+    mask = idx == N
+    idx[mask] = first[mask]
+    return idx
+
+
+def batch_norm_rows(x: Tensor, sd: SD, p: str, training: bool, eps: float = 1e-5) -> Tensor:
+    """nn.BatchNorm2d of [B, C, n, S] expressed on [rows, C] (every position of every sample is one row)."""
+    if training:
+        mu = x.mean(0, keepdim=True)
+        var = ((x - mu) ** 2).mean(0, keepdim=True)
+    else:
+        mu, var = sd[p + "running_mean"][None], sd[p + "running_var"][None]
+    return (x - mu) / torch.sqrt(var + eps) * sd[p + "weight"][None] + sd[p + "bias"][None]
+
+
+def pnsa_tokens(sd: SD, a: str, features: Tensor, xyz: Tensor, num_group: int, radius: float, group_size: int,
+                fps_start: Tensor, training: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
+    """PointNSATokenizer.forward, pointnet_util.py:345-368: PointNetSetAbstraction (:184-227 - sample_and_group :126-161:
+    FPS centres with the random start passed in, ball query, centre-subtracted xyz ++ point features; three 1x1
+    Conv2d + BatchNorm2d + ReLU; max over the group) then `lift`: Conv1d over [centre xyz ++ group feature], LayerNorm.
+    features [B,N,D], xyz [B,N,3] -> (tokens [B,S,trans], fps idx [B,S], ball idx [B,S,nsample])."""
+    B, N, _ = xyz.shape
+    S, ns = num_group, group_size
+    cidx = fps_indices(xyz, S, fps_start)
+    new_xyz = torch.gather(xyz, 1, cidx[:, :, None].expand(B, S, 3))
+    bidx = ball_query_indices(radius, ns, xyz, new_xyz)
+    ar = torch.arange(B).view(B, 1, 1)
+    g_xyz = xyz[ar, bidx] - new_xyz.view(B, S, 1, 3)
+    x = torch.cat([g_xyz, features[ar, bidx]], dim=-1)                    # [B,S,ns,3+D]
+    x = x.reshape(B * S * ns, -1)
+    for i in range(3):
+        w = sd[f"{a}sa.mlp_convs.{i}.weight"][:, :, 0, 0]
+        x = torch.relu(batch_norm_rows(x @ w.t() + sd[f"{a}sa.mlp_convs.{i}.bias"], sd, f"{a}sa.mlp_bns.{i}.", training))
+    feat = x.view(B, S, ns, -1).max(dim=2).values                         # [B,S,C']
+    y = torch.cat([new_xyz, feat], dim=-1) @ sd[a + "lift.0.weight"][:, :, 0].t() + sd[a + "lift.0.bias"]
+    return layer_norm(y, sd[a + "lift.2.weight"], sd[a + "lift.2.bias"]), cidx, bidx
+
+
 # ----------------------------------------------------------------------------- Perceiver ("Lens")
 def lens_attention(sd: SD, p: str, x: Tensor, ctx: Tensor, heads: int, dim_head: int) -> Tensor:
     """perceiver.Attention.forward, perceiver.py:121-154 (no mask, no xformers):
