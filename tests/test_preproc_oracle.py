@@ -112,3 +112,39 @@ def test_oracle_on_the_reference_example_photographs():
             b, kk, ks = preproc.pil_bicubic_tables(n_in, n_out)
             ob, okk, oks = po.pil_coeffs(n_in, n_out)
             assert ks == oks and np.array_equal(b, ob) and np.array_equal(kk, okk)
+
+
+def test_pil_resize_random_geometries_byte_exact():
+    """60 random (in, out) geometries incl. 1-pixel axes, extreme aspect ratios, up- and down-scaling by up to 12x:
+    the restatement AND the product's vectorised tables (through the oracle's integer passes) against Image.resize."""
+    from vitlens_hip import preproc
+    rng = np.random.default_rng(2024)
+    for t in range(60):
+        h, w = int(rng.integers(1, 90)), int(rng.integers(1, 90))
+        oh, ow = int(rng.integers(1, 90)), int(rng.integers(1, 90))
+        if t % 6 == 0:
+            h, ow = int(rng.integers(200, 400)), int(rng.integers(1, 30))         # strong down-scale on one axis, up on the other
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        want = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BICUBIC))
+        assert np.array_equal(po.pil_resize_bicubic_u8(img, ow, oh), want), (h, w, oh, ow)
+        for n_in, n_out in ((w, ow), (h, oh)):
+            b, kk, ks = preproc.pil_bicubic_tables(n_in, n_out)
+            ob, okk, oks = po.pil_coeffs(n_in, n_out)
+            assert ks == oks and np.array_equal(b, ob) and np.array_equal(kk, okk), (n_in, n_out)
+
+
+@pytest.mark.parametrize("antialias", [True, False])
+def test_float_bicubic_random_geometries(antialias):
+    """40 random geometries of the float path: tables of the product, applied with numpy, against F.interpolate."""
+    from vitlens_hip import preproc
+    rng = np.random.default_rng(7)
+    for _ in range(40):
+        h, w, oh, ow = (int(v) for v in rng.integers(2, 120, 4))
+        x = torch.from_numpy(rng.random((h, w), dtype=np.float32))
+        want = torch.nn.functional.interpolate(x[None, None], (oh, ow), mode="bicubic", align_corners=False, antialias=antialias)[0, 0].numpy()
+        hb, hw, _ = preproc.aten_bicubic_tables(w, ow, antialias)
+        vb, vw, _ = preproc.aten_bicubic_tables(h, oh, antialias)
+        xs = x.numpy()
+        tmp = np.stack([(xs[:, np.clip(hb[i, 0] + np.arange(hb[i, 1]), 0, w - 1)] * hw[i, :hb[i, 1]]).sum(1) for i in range(ow)], 1)
+        got = np.stack([(tmp[np.clip(vb[i, 0] + np.arange(vb[i, 1]), 0, h - 1)] * vw[i, :vb[i, 1]][:, None]).sum(0) for i in range(oh)], 0)
+        assert np.abs(got - want).max() < 5e-6, (h, w, oh, ow, antialias, np.abs(got - want).max())
