@@ -209,6 +209,8 @@ def test_set_bn_sync_is_a_noop_without_ranks():
     comm = SimpleNamespace(all_gather=None, all_reduce_sum=None)
     assert m.set_bn_sync(True, comm=comm, world_size=2)._bn_sync == (comm, 2)
     assert m.set_bn_sync(False)._bn_sync is None
+    with pytest.raises(ValueError):
+        m.set_bn_sync(True, comm=comm)
     m.modality = "depth"
     assert m.set_bn_sync(True, comm=comm, world_size=2)._bn_sync is None
 

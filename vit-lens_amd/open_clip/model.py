@@ -204,6 +204,8 @@ class VisionTransformer(nn.Module):
                 return self
             from vitlens_hip.step import TorchComm
             comm, world_size = TorchComm(), dist.get_world_size()
+        elif world_size is None:
+            raise ValueError("set_bn_sync(comm=...) needs world_size: the number of ranks `comm` spans")
         self._bn_sync = (comm, int(world_size))
         return self
 
