@@ -160,7 +160,7 @@ def tiny_case(oc, modality, seed):
 
 def per_op_case(oc):
     """Per-op vectors from reference modules at small shapes."""
-    from open_clip.transformer import ResidualAttentionBlock, LayerNorm, TextTransformer
+    from open_clip.transformer import ResidualAttentionBlock, LayerNorm
     from open_clip.perceiver import FeedForward, Attention
     from open_clip.modal_audio.models.AST_tokenizer import AST_tokenizer
     torch.manual_seed(11)

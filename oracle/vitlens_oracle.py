@@ -16,8 +16,8 @@ Reference citations are `vitlens/src/open_clip/<file>:<line>`.
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence, Tuple
+from dataclasses import dataclass
+from typing import Dict, Optional, Sequence, Tuple
 
 import torch
 import torch.nn.functional as F

@@ -7,13 +7,12 @@ are (re)built from the parameters whenever their versions change.  There is no e
 forward needs a GPU and libvitlens_hip.so.
 """
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Any, Optional
 
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 
 @dataclass

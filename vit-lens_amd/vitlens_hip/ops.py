@@ -1,7 +1,6 @@
 """Tensor-level wrappers over the C ABI.  Every function enqueues HIP kernels on the current
 torch stream and returns immediately.  Inputs must live on a GPU: there is no CPU fallback."""
 import ctypes as C
-import math
 
 import torch
 

@@ -8,7 +8,6 @@ batch statistics (and SyncBN) for the PC recipe are not implemented yet and rais
 import torch
 
 from . import ops
-from .engine import _dev
 
 BF = torch.bfloat16
 

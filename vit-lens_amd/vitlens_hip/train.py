@@ -14,7 +14,7 @@ from typing import Dict, Iterable, Optional
 import torch
 
 from . import ops
-from .engine import VitEngine, _dev
+from .engine import VitEngine
 
 BF = torch.bfloat16
 
