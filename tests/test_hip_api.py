@@ -303,3 +303,25 @@ def test_zero_shot_logits_and_accuracy_on_gpu():
     assert float((got.cpu() - ref).abs().max()) < 2e-3
     tgt = ref.argmax(dim=1)
     assert oc.accuracy(got.cpu(), tgt, topk=(1, 5)) == [37.0, 37.0]
+
+
+def test_recall_metric_similarity_on_gpu():
+    """open_clip.metrics.Recall (reference metrics/recall.py:22-36): the image x text similarity GEMM on the HIP kernel, then
+    the ranking - against the same protocol on an fp32 torch similarity matrix (CPU).  23 captions: not a multiple of 4."""
+    _oc()
+    from open_clip.metrics import Recall
+    g = torch.Generator().manual_seed(4)
+    img = torch.nn.functional.normalize(torch.randn(37, 768, generator=g), dim=-1)
+    txt = torch.nn.functional.normalize(torch.randn(23, 768, generator=g), dim=-1)
+    img = torch.nn.functional.normalize(img + 0.6 * txt[torch.arange(37) % 23], dim=-1)      # a real signal: recall well above chance
+    img_ids, txt_ids = torch.arange(37) % 23, torch.arange(23)
+    r = Recall(); r.initialize(txt_ids.cuda(), txt.cuda())
+    for lo, hi in ((0, 16), (16, 37)):
+        r.compute(img_ids[lo:hi].cuda(), img[lo:hi].cuda())
+    got = r.merge_results(output_predict=True)
+    ref = Recall(); ref.initialize(txt_ids, txt)
+    ref.image_ids = img_ids
+    sim = img @ txt.t()
+    want = ref.retrieval_eval(sim, sim.t(), output_predict=True)
+    assert got == want
+    assert got["txt_r1"] > 50 and got["img_count"] == 37 and got["txt_count"] == 23
