@@ -79,3 +79,41 @@ def test_classifier_equals_reference_builder():
     oc = _oc()
     w = oc.build_zero_shot_classifier(_StubModel(), oc.tokenize, CLASSES, TEMPLATES[:2], num_classes_per_batch=3, device="cpu")
     assert torch.allclose(w, ref, atol=1e-6)
+
+
+_REF_ACC = r'''
+import json, sys, torch
+sys.path.insert(0, sys.argv[1])
+import ref_loader
+ref_loader.load()
+import training.zero_shot as Z
+g = torch.Generator().manual_seed(3)
+out = torch.randn(64, 12, generator=g)
+tgt = torch.randint(0, 12, (64,), generator=g)
+res = {"accuracy": Z.accuracy(out, tgt, topk=(1, 5))}
+r, c = Z.acc(out, tgt, topk=(1, 3, 5))
+res["acc"] = [float(x) for x in r]; res["acc_correct"] = c.int().tolist()
+t2 = tgt.clone()
+r, c = Z.cond_acc(out, t2, idx_mapping=[2, 7, 9], merge_idx=100, topk=(1, 3, 5))
+res["cond"] = [float(x) for x in r]; res["cond_correct"] = c.int().tolist(); res["cond_target"] = t2.tolist()
+print("JSON" + json.dumps(res))
+'''
+
+
+@pytest.mark.needs_reference
+def test_accuracy_helpers_equal_reference():
+    """accuracy / acc / cond_acc of training/zero_shot.py:36-81 (imported, build container only)."""
+    import json
+    r = subprocess.run([sys.executable, "-c", _REF_ACC, os.path.join(ROOT, "oracle")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = json.loads(r.stdout[r.stdout.index("JSON") + 4:])
+    oc = _oc()
+    g = torch.Generator().manual_seed(3)
+    out = torch.randn(64, 12, generator=g)
+    tgt = torch.randint(0, 12, (64,), generator=g)
+    assert oc.accuracy(out, tgt, topk=(1, 5)) == ref["accuracy"]
+    res, c = oc.acc(out, tgt, topk=(1, 3, 5))
+    assert [float(x) for x in res] == ref["acc"] and c.int().tolist() == ref["acc_correct"]
+    t2 = tgt.clone()
+    res, c = oc.cond_acc(out, t2, idx_mapping=[2, 7, 9], merge_idx=100, topk=(1, 3, 5))
+    assert [float(x) for x in res] == ref["cond"] and c.int().tolist() == ref["cond_correct"] and t2.tolist() == ref["cond_target"]

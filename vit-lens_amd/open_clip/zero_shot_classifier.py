@@ -63,3 +63,29 @@ def accuracy(output: torch.Tensor, target: torch.Tensor, topk=(1,)):
     pred = output.topk(k, dim=1, largest=True, sorted=True).indices          # [N, k]
     hit = pred.eq(target.view(-1, 1))
     return [float(hit[:, :kk].any(dim=1).float().sum().item()) for kk in topk]
+
+
+def acc(output: torch.Tensor, target: torch.Tensor, topk=(1,)):
+    """Top-k accuracy in PERCENT of the batch plus the [maxk, N] hit matrix (training/zero_shot.py:45-59; the 3D
+    evaluation accumulates `correct` per class from it)."""
+    with torch.no_grad():
+        maxk = max(topk)
+        pred = output.topk(maxk, 1, True, True).indices.t()
+        correct = pred.eq(target.reshape(1, -1).expand_as(pred))
+        n = target.size(0)
+        return [correct[:k].reshape(-1).float().sum(0, keepdim=True).mul_(100.0 / n) for k in topk], correct
+
+
+def cond_acc(output: torch.Tensor, target: torch.Tensor, idx_mapping, merge_idx: int = 100, topk=(1,)):
+    """`acc` after merging the classes in `idx_mapping` into `merge_idx`, in the targets (IN PLACE, as the reference) and
+    in the predictions; a sample counts once within the top-k (training/zero_shot.py:62-81)."""
+    with torch.no_grad():
+        maxk = max(topk)
+        pred = output.topk(maxk, 1, True, True).indices
+        for idx in idx_mapping:
+            target[target == idx] = merge_idx
+            pred[pred == idx] = merge_idx
+        pred = pred.t()
+        correct = pred.eq(target.reshape(1, -1).expand_as(pred))
+        n = target.size(0)
+        return [correct[:k].float().max(dim=0)[0].sum(0, keepdim=True).mul_(100.0 / n) for k in topk], correct
