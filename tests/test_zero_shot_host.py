@@ -117,3 +117,27 @@ def test_accuracy_helpers_equal_reference():
     t2 = tgt.clone()
     res, c = oc.cond_acc(out, t2, idx_mapping=[2, 7, 9], merge_idx=100, topk=(1, 3, 5))
     assert [float(x) for x in res] == ref["cond"] and c.int().tolist() == ref["cond_correct"] and t2.tolist() == ref["cond_target"]
+
+
+def test_zero_shot_run_loop_counts(monkeypatch):
+    """training.zero_shot.run (reference training/zero_shot.py:84-110) on a stub model: batches of unequal size, top-1 /
+    top-5 fractions over all samples; the scoring GEMM is replaced by torch here (it is the HIP kernel on the GPU)."""
+    import importlib
+    _oc()
+    Z = importlib.import_module("training.zero_shot")
+    monkeypatch.setattr(Z, "zero_shot_logits", lambda f, w, logit_scale=100.0: logit_scale * f @ w)
+    g = torch.Generator().manual_seed(0)
+    w = torch.nn.functional.normalize(torch.randn(16, 10, generator=g), dim=0)
+    feats = torch.nn.functional.normalize(torch.randn(50, 16, generator=g), dim=-1)
+    target = (feats @ w).argmax(1)
+    target[:10] = (target[:10] + 1) % 10                                         # 10 wrong labels
+
+    class Model:
+        def __call__(self, image=None):
+            return {"image_features": image}
+    batches = [(feats[:7], target[:7]), (feats[7:30], target[7:30]), (feats[30:], target[30:])]
+    from types import SimpleNamespace
+    top1, top5 = Z.run(Model(), w, batches, SimpleNamespace(device="cpu"))
+    logits = 100.0 * feats @ w
+    assert top1 == int((logits.argmax(1) == target).sum()) / 50 == 0.8
+    assert top1 <= top5 <= 1.0
