@@ -278,10 +278,21 @@ class AdamW:
     (reference: depth_tri_main.py:394-419 -- two groups: no weight decay for ndim<2 / bn / ln / bias / logit_scale)."""
 
     def __init__(self, params: Dict[str, torch.Tensor], lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.2):
-        self.params, self.lr, self.betas, self.eps, self.wd = params, lr, betas, eps, weight_decay
+        # `param_groups[i]["lr"]` is what the reference's schedulers assign (training/scheduler.py:4-6); one group here,
+        # weight decay is decided per tensor by `decays`
+        self.param_groups = [{"lr": lr}]
+        self.params, self.betas, self.eps, self.wd = params, betas, eps, weight_decay
         self.m = {k: torch.zeros_like(v) for k, v in params.items()}
         self.v = {k: torch.zeros_like(v) for k, v in params.items()}
         self.t = 0
+
+    @property
+    def lr(self) -> float:
+        return float(self.param_groups[0]["lr"])
+
+    @lr.setter
+    def lr(self, value):
+        self.param_groups[0]["lr"] = float(value)
 
     @staticmethod
     def decays(name: str, p: torch.Tensor) -> bool:
