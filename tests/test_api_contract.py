@@ -356,7 +356,8 @@ def test_model_cfg_values_equal_the_reference():
 
 _SIG_TARGETS = [
     ("open_clip", "tokenize"), ("open_clip", "get_tokenizer"), ("open_clip", "tri_create_model"),
-    ("open_clip", "tri_create_model_and_transforms"), ("open_clip", "create_loss"), ("open_clip", "add_model_config"),
+    ("open_clip", "tri_create_model_and_transforms"), ("open_clip", "tri_create_model_from_pretrained"), ("open_clip", "get_cast_dtype"),
+    ("open_clip", "get_input_dtype"), ("open_clip", "create_loss"), ("open_clip", "add_model_config"),
     ("open_clip", "get_model_config"), ("open_clip", "image_transform"),
     ("open_clip.model", "TriCLIP.encode_image"), ("open_clip.model", "TriCLIP.encode_text"), ("open_clip.model", "TriCLIP.encode_visual"),
     ("open_clip.model", "TriCLIP.forward"), ("open_clip.model", "TriCLIP.lock_image_tower"), ("open_clip.model", "TriCLIP.lock_visual_tower"),
@@ -419,3 +420,64 @@ def test_public_signatures_equal_the_reference():
         if any(m[1] is None for m in extra):
             bad.append((name, "appended parameter without default", extra))
     assert not bad, bad
+
+
+_REF_CONST = r'''
+import json, sys, torch
+sys.path.insert(0, sys.argv[1])
+import ref_loader
+oc = ref_loader.load()
+import open_clip.constants as K
+out = {"const": {k: getattr(K, k) for k in dir(K) if k.isupper() and isinstance(getattr(K, k), (str, tuple, list))},
+       "modality": vars(K.ModalityType),
+       "cast": {p: str(oc.get_cast_dtype(p)) for p in ("fp32", "amp", "bf16", "fp16", "pure_bf16", "pure_fp16", "amp_bf16")},
+       "input": {p: str(oc.get_input_dtype(p)) for p in ("fp32", "amp", "bf16", "fp16", "pure_bf16", "pure_fp16", "amp_bf16")}}
+print("JSON" + json.dumps(out))
+'''
+
+
+@pytest.mark.needs_reference
+def test_constants_and_dtype_helpers_equal_the_reference():
+    r = subprocess.run([sys.executable, "-c", _REF_CONST, os.path.join(ROOT, "oracle")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = json.loads(r.stdout[r.stdout.index("JSON") + 4:])
+    import importlib
+    for k in [k for k in sys.modules if k == "open_clip" or k.startswith("open_clip.")]:
+        del sys.modules[k]
+    oc = importlib.import_module("open_clip")
+    K = importlib.import_module("open_clip.constants")
+    for k, v in ref["const"].items():
+        got = getattr(K, k)
+        assert (list(got) if isinstance(got, tuple) else got) == v, k
+    assert vars(K.ModalityType) == ref["modality"]
+    for p, v in ref["cast"].items():
+        assert str(oc.get_cast_dtype(p)) == v, p
+    for p, v in ref["input"].items():
+        assert str(oc.get_input_dtype(p)) == v, p
+
+
+def test_tri_create_model_from_pretrained(tmp_path):
+    """factory.py:425-464: weights are required; the checkpoint's tensors arrive in the model; the evaluation transform comes
+    along unless `return_transform=False`."""
+    import importlib
+    oc = importlib.import_module("open_clip")
+    cfg = oc.get_model_config("ViT-B-32")
+    cfg["vision_cfg"].update(width=64, layers=2, patch_size=32)
+    cfg["text_cfg"].update(width=64, heads=2, layers=2)
+    cfg["embed_dim"] = 32
+    json.dump(cfg, open(tmp_path / "tiny-b32.json", "w"))
+    oc.add_model_config(str(tmp_path))
+    with pytest.raises(RuntimeError):
+        oc.tri_create_model_from_pretrained("tiny-b32", None)
+    torch.manual_seed(0)
+    src = oc.tri_create_model("tiny-b32", None, device="cpu")
+    torch.save({"state_dict": src.state_dict()}, tmp_path / "w.pt")
+    torch.manual_seed(1)
+    model, preprocess = oc.tri_create_model_from_pretrained("tiny-b32", str(tmp_path / "w.pt"))
+    sd = src.state_dict()
+    for k, v in sd.items():
+        # load_checkpoint's rule (factory.py:141-151): whatever the file calls `visual.*` is ALSO the image encoder
+        want = sd.get("visual." + k[len("image."):], v) if k.startswith("image.") else v
+        assert torch.equal(model.state_dict()[k], want), k
+    assert preprocess.image_size == 224 and not preprocess.is_train
+    assert isinstance(oc.tri_create_model_from_pretrained("tiny-b32", str(tmp_path / "w.pt"), return_transform=False), type(src))

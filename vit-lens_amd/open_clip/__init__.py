@@ -2,9 +2,9 @@
 `from open_clip import ModalityType, tokenize, tri_create_model, create_loss, ...`)."""
 from .constants import OPENAI_DATASET_MEAN, OPENAI_DATASET_STD, ModalityType
 from .factory import (add_model_config, create_loss, get_model_config, get_tokenizer, list_models, load_checkpoint,
-                      tri_create_model, tri_create_model_and_transforms)
+                      tri_create_model, tri_create_model_and_transforms, tri_create_model_from_pretrained)
 from .loss import ClipLoss, ClipLossGeneral, TriClipLoss, gather_features
-from .model import CLIPTextCfg, CLIPVisionCfg, TriCLIP
+from .model import CLIPTextCfg, CLIPVisionCfg, TriCLIP, get_cast_dtype, get_input_dtype
 from .tokenizer import SimpleTokenizer, decode, tokenize
 from .transform import AugmentationCfg, image_transform
 from .utils import all_gather, concat_all_gather, scaled_all_reduce

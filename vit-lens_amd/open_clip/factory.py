@@ -184,6 +184,24 @@ def tri_create_model_and_transforms(model_name: str, pretrained: Optional[str] =
     return model, preprocess_train, preprocess_val
 
 
+def tri_create_model_from_pretrained(model_name: str, pretrained: Optional[str] = None, precision: str = "fp32",
+                                     device: Union[str, torch.device] = "cpu", jit: bool = False, force_quick_gelu: bool = False,
+                                     force_custom_text: bool = False, force_image_size=None, return_transform: bool = True,
+                                     image_mean=None, image_std=None, cache_dir: Optional[str] = None):
+    """factory.py:425-464: a model that MUST come with weights (`pretrained` = a local checkpoint path here), optionally
+    with the evaluation transform."""
+    model = tri_create_model(model_name, pretrained, precision=precision, device=device, jit=jit, force_quick_gelu=force_quick_gelu,
+                             force_custom_text=force_custom_text, force_image_size=force_image_size, cache_dir=cache_dir,
+                             require_pretrained=True)
+    if not return_transform:
+        return model
+    from .transform import image_transform
+    tdev = device if torch.device(device).type == "cuda" else "cuda"
+    preprocess = image_transform(model.visual.cfg.image_size, is_train=False, mean=image_mean or getattr(model.visual, "image_mean", None),
+                                 std=image_std or getattr(model.visual, "image_std", None), device=tdev)
+    return model, preprocess
+
+
 def create_loss(args):
     """factory.py:750-851 restricted to the hot-path losses (general contrastive, tri / dual / plain)."""
     kw = dict(local_loss=args.local_loss, gather_with_grad=args.gather_with_grad, cache_labels=True,

@@ -41,6 +41,16 @@ class CLIPTextCfg:
     layers: int = 12
 
 
+def get_cast_dtype(precision: str):
+    """model.py:100-106."""
+    return {"bf16": torch.bfloat16, "fp16": torch.float16}.get(precision)
+
+
+def get_input_dtype(precision: str):
+    """model.py:109-115."""
+    return {"bf16": torch.bfloat16, "pure_bf16": torch.bfloat16, "fp16": torch.float16, "pure_fp16": torch.float16}.get(precision)
+
+
 class _Node(nn.Module):
     """Bare parameter container; children are attached by dotted name."""
 
