@@ -365,7 +365,7 @@ _SIG_TARGETS = [
     ("open_clip.loss", "ClipLoss.__init__"), ("open_clip.loss", "ClipLoss.forward"), ("open_clip.loss", "ClipLossGeneral.__init__"),
     ("open_clip.loss", "ClipLossGeneral.forward"), ("open_clip.loss", "TriClipLoss.__init__"), ("open_clip.loss", "TriClipLoss.forward"),
     ("open_clip.loss", "gather_features"), ("open_clip.factory", "load_checkpoint"), ("open_clip.factory", "resize_pos_embed"),
-    ("open_clip.zero_shot_classifier", "build_zero_shot_classifier"),
+    ("open_clip.zero_shot_classifier", "build_zero_shot_classifier"), ("open_clip.zero_shot_classifier", "build_zero_shot_classifier_legacy"),
     ("mm_vit_lens.model_cfg", "fetch_model_cfg"),
 ]
 
@@ -413,7 +413,7 @@ def test_public_signatures_equal_the_reference():
         for m, w in zip(mine, want):
             if w[2] in ("VAR_KEYWORD", "VAR_POSITIONAL"):
                 continue
-            site = w[0] == "cache_dir" or (name == "build_zero_shot_classifier" and w[0] == "device")
+            site = w[0] == "cache_dir" or (name.startswith("build_zero_shot_classifier") and w[0] == "device")
             if m[1] != w[1] and not site:          # cache_dir: a site path; the classifier's device defaults to the GPU (there is no CPU path)
                 bad.append((name, m[0], m[1], w[1]))
         extra = [m for m in mine[len(want_names):] if m[2] not in ("VAR_KEYWORD", "VAR_POSITIONAL")]

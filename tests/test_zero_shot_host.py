@@ -66,7 +66,10 @@ class M:
     def encode_text(self, ids): return table[ids].sum(dim=1)
 w = build_zero_shot_classifier(M(), oc.tokenize, ["dog", "cat", "guitar", "airplane", "chair", "tree", "piano"],
                                ["a photo of a {}.", "a depth map of a {}."], num_classes_per_batch=3, device="cpu")
-print("JSON" + json.dumps(w.tolist()))
+from open_clip.zero_shot_classifier import build_zero_shot_classifier_legacy
+w2 = build_zero_shot_classifier_legacy(M(), oc.tokenize, ["dog", "cat", "guitar", "airplane", "chair", "tree", "piano"],
+                                       ["a photo of a {}.", "a depth map of a {}."], device="cpu")
+print("JSON" + json.dumps([w.tolist(), w2.tolist()]))
 '''
 
 
@@ -75,10 +78,12 @@ def test_classifier_equals_reference_builder():
     import json
     r = subprocess.run([sys.executable, "-c", _REF, os.path.join(ROOT, "oracle")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    ref = torch.tensor(json.loads(r.stdout[r.stdout.index("JSON") + 4:]))
+    ref, ref_legacy = (torch.tensor(t) for t in json.loads(r.stdout[r.stdout.index("JSON") + 4:]))
     oc = _oc()
     w = oc.build_zero_shot_classifier(_StubModel(), oc.tokenize, CLASSES, TEMPLATES[:2], num_classes_per_batch=3, device="cpu")
     assert torch.allclose(w, ref, atol=1e-6)
+    w2 = oc.build_zero_shot_classifier_legacy(_StubModel(), oc.tokenize, CLASSES, TEMPLATES[:2], device="cpu")
+    assert torch.allclose(w2, ref_legacy, atol=1e-6) and torch.allclose(w2, w, atol=1e-6)
 
 
 _REF_ACC = r'''

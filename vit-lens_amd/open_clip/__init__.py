@@ -8,4 +8,5 @@ from .model import CLIPTextCfg, CLIPVisionCfg, TriCLIP, get_cast_dtype, get_inpu
 from .tokenizer import SimpleTokenizer, decode, tokenize
 from .transform import AugmentationCfg, image_transform
 from .utils import all_gather, concat_all_gather, scaled_all_reduce
-from .zero_shot_classifier import acc, accuracy, build_zero_shot_classifier, cond_acc, zero_shot_logits
+from .zero_shot_classifier import (acc, accuracy, build_zero_shot_classifier, build_zero_shot_classifier_legacy, cond_acc,
+                                   zero_shot_logits)

@@ -41,6 +41,14 @@ def build_zero_shot_classifier(model, tokenizer, classnames: Sequence[str], temp
     return torch.cat(cols, dim=1)
 
 
+@torch.no_grad()
+def build_zero_shot_classifier_legacy(model, tokenizer, classnames: Sequence[str], templates: Sequence[Union[Callable, str]],
+                                      device: Union[str, torch.device] = "cuda", use_tqdm: bool = False) -> torch.Tensor:
+    """The one-class-at-a-time variant (zero_shot_classifier.py:93-133): same weights as `build_zero_shot_classifier`
+    with one text-tower call per class."""
+    return build_zero_shot_classifier(model, tokenizer, classnames, templates, num_classes_per_batch=1, device=device, use_tqdm=use_tqdm)
+
+
 def zero_shot_logits(features: torch.Tensor, classifier: torch.Tensor, logit_scale: float = 100.0) -> torch.Tensor:
     """logit_scale * features [N, E] @ classifier [E, C] on the HIP GEMM (fp32-accurate operands via the bf16 hi/lo split)."""
     from vitlens_hip import ops
