@@ -104,6 +104,10 @@ class ViTLens(nn.Module):
     def export_checkpoint(self, save_path="model_release/vitlens.pt"):
         torch.save(dict(model_var=self.model_var, modality_loaded=self.modality_loaded, state_dict=self.state_dict()), save_path)
 
+    def reduce_list(self, modality):
+        """Modalities whose input is a LIST of clips per sample, encoded clip by clip and averaged (vitlens.py:165-168)."""
+        return modality in [ModalityType.AUDIO]
+
     def processor(self, m):
         """The reference's per-modality input processor (built on first use: vitlens.py:108-116)."""
         if m not in self.processors:
@@ -125,7 +129,7 @@ class ViTLens(nn.Module):
                 f = model.encode_text(x.to(self._dev), normalize=False)
             elif m == ModalityType.IMAGE:
                 f = model.encode_image(x.to(self._dev), normalize=False)
-            elif m == ModalityType.AUDIO and x.ndim == 4:
+            elif self.reduce_list(m) and x.ndim == 4:
                 B, S = x.shape[:2]
                 f = model.encode_visual(x.reshape(B * S, *x.shape[2:]).to(self._dev), normalize=False)
                 f = f.reshape(B, S, -1).mean(dim=1).contiguous()
