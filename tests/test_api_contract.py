@@ -367,6 +367,9 @@ _SIG_TARGETS = [
     ("open_clip.loss", "gather_features"), ("open_clip.factory", "load_checkpoint"), ("open_clip.factory", "resize_pos_embed"),
     ("open_clip.zero_shot_classifier", "build_zero_shot_classifier"), ("open_clip.zero_shot_classifier", "build_zero_shot_classifier_legacy"),
     ("mm_vit_lens.model_cfg", "fetch_model_cfg"),
+    ("training.train", "tri_train_one_epoch"), ("training.train", "train_dual_one_epoch"), ("training.train", "backward"),
+    ("training.scheduler", "cosine_lr"), ("training.scheduler", "const_lr"), ("training.scheduler", "const_lr_cooldown"),
+    ("training.zero_shot", "run"),
 ]
 
 _REF_SIG = r'''
@@ -395,7 +398,7 @@ def test_public_signatures_equal_the_reference():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     ref = json.loads(r.stdout[r.stdout.index("JSON") + 4:])
-    for k in [k for k in sys.modules if k == "open_clip" or k.startswith("open_clip.") or k.startswith("mm_vit_lens")]:
+    for k in [k for k in sys.modules if k.split(".")[0] in ("open_clip", "mm_vit_lens", "training")]:
         del sys.modules[k]
     bad = []
     for mod, name in _SIG_TARGETS:

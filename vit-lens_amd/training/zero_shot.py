@@ -8,7 +8,7 @@ import torch
 from open_clip import accuracy, zero_shot_logits
 
 
-def run(model, classifier, dataloader, args=None, input_key="image", feature_key="image_features", logit_scale=100.0):
+def run(model, classifier, dataloader, args, input_key="image", feature_key="image_features", logit_scale=100.0):
     """-> (top1, top5) as fractions of the samples seen.  `input_key` / `feature_key`: ("image", "image_features") is the
     reference's `run`; ("visual_x", "visual_features") scores the modality tower."""
     device = getattr(args, "device", None) or "cuda"
