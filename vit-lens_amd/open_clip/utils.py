@@ -1,7 +1,9 @@
 """Distributed helpers of the evaluation path with the reference's names (open_clip/utils.py:134-175, 295-330),
 restated for RCCL over xGMI: every helper issues ONE collective on ONE contiguous buffer (ring collectives on xGMI
 are latency-bound at these sizes, so fewer, fused calls win) instead of one call per tensor."""
-from typing import List, Sequence
+from typing import collections.abc
+import itertools
+import List, Sequence
 
 import torch
 import torch.distributed as dist
@@ -68,3 +70,20 @@ def all_gather(q: torch.Tensor, exclude_self: bool = False) -> torch.Tensor:
     dist.all_gather_into_tensor(out, pad)
     parts: List[torch.Tensor] = [out[r * longest:r * longest + sizes[r]] for r in range(world) if not (exclude_self and r == rank)]
     return torch.cat(parts, dim=0) if parts else out[:0]
+
+
+def get_model(model):
+    """The module behind a DataParallel / DistributedDataParallel wrapper (utils.py:178-184)."""
+    if isinstance(model, (torch.nn.DataParallel, torch.nn.parallel.DistributedDataParallel)):
+        return model.module
+    return model
+
+
+def _ntuple(n):
+    def parse(x):
+        return x if isinstance(x, collections.abc.Iterable) else tuple(itertools.repeat(x, n))
+    return parse
+
+
+to_1tuple, to_2tuple, to_3tuple, to_4tuple = _ntuple(1), _ntuple(2), _ntuple(3), _ntuple(4)
+to_ntuple = lambda n, x: _ntuple(n)(x)

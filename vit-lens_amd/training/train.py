@@ -22,6 +22,7 @@ import time
 import torch
 
 from open_clip import get_input_dtype
+from open_clip.utils import get_model
 
 
 class AverageMeter(object):
@@ -158,7 +159,7 @@ def train_dual_one_epoch(model, data, loss, epoch, optimizer, scaler, scheduler,
     device, dtype = torch.device(args.device), get_input_dtype(args.precision)
     to_image = args.align_to in ("image", "video")
     key = args.align_to if to_image else "caption"
-    net = unwrap_model(model)
+    net = get_model(model)
     encode_anchor = net.encode_image if to_image else net.encode_text
 
     def fetch(batch):
