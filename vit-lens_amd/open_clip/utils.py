@@ -1,9 +1,9 @@
 """Distributed helpers of the evaluation path with the reference's names (open_clip/utils.py:134-175, 295-330),
 restated for RCCL over xGMI: every helper issues ONE collective on ONE contiguous buffer (ring collectives on xGMI
 are latency-bound at these sizes, so fewer, fused calls win) instead of one call per tensor."""
-from typing import collections.abc
+import collections.abc
 import itertools
-import List, Sequence
+from typing import List, Sequence
 
 import torch
 import torch.distributed as dist
