@@ -86,3 +86,30 @@ def test_tokenizer_fuzz_against_the_reference(tmp_path):
     got77, got20 = tokenize(texts), tokenize(texts, context_length=20)
     bad = [i for i in range(len(texts)) if got77[i].tolist() != ref["ids77"][i] or got20[i].tolist() != ref["ids20"][i]]
     assert not bad, (len(bad), [texts[i] for i in bad[:3]])
+
+
+def test_tokenizer_unicode_fuzz_against_the_reference(tmp_path):
+    """Non-ASCII captions (accents, Greek, Cyrillic, CJK, emoji, combining marks, non-breaking / ideographic spaces) with
+    `ftfy.fix_text` as the identity on BOTH sides (it is not installed; the product calls it when present): everything
+    after the ftfy step - html unescape, white-space cleaning, the unicode-class regex split, byte-level BPE - is pinned."""
+    import random
+    import subprocess
+    import sys
+    import pytest
+    if not os.path.isdir("/root/reference/vitlens/src/open_clip"):
+        pytest.skip("/root/reference not present")
+    from open_clip.tokenizer import tokenize
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = random.Random(5)
+    words = ["café", "naïve", "Ångström", "straße", "ΑΒΓ", "λόγος", "Москва", "привет", "東京", "深度图", "점군", "🙂", "👍🏽", "é", "ﬁ", "№5",
+             "½", "x²", "100€", "a b", "全角　空白", "ＡＢＣ", "İstanbul", "ǅ", "don’t", "“quoted”", "—dash—", "…", "a photo of", "the"]
+    seps = [" ", "  ", "\t", " ", " , ", ". ", ""]
+    texts = ["".join(rng.choice(words) + rng.choice(seps) for _ in range(rng.choice([1, 2, 4, 9, 40]))) for _ in range(500)]
+    p = tmp_path / "texts.json"
+    json.dump(texts, open(p, "w"))
+    r = subprocess.run([sys.executable, "-c", _REF_TOK, os.path.join(root, "oracle"), str(p)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = json.loads(r.stdout[r.stdout.index("JSON") + 4:])
+    got77, got20 = tokenize(texts), tokenize(texts, context_length=20)
+    bad = [i for i in range(len(texts)) if got77[i].tolist() != ref["ids77"][i] or got20[i].tolist() != ref["ids20"][i]]
+    assert not bad, (len(bad), [texts[i] for i in bad[:3]])
