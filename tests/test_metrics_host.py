@@ -109,7 +109,7 @@ def _worker(rank, world, port, ret):
 def test_metrics_merge_across_ranks_on_gloo():
     world = 2
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(world, 29870 + os.getpid() % 100, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, 30070 + os.getpid() % 100, ret), nprocs=world, join=True)
     one = _norm(_mine(_data()))
     for r in range(world):
         assert ret[r] == one, r

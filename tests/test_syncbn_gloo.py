@@ -93,7 +93,7 @@ def _worker(rank, world, port, ret):
 
 def test_syncbn_host_logic_world2_gloo():
     world = 2
-    port = 29900 + os.getpid() % 90
+    port = 30200 + os.getpid() % 90
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     x, dy, gamma, beta = _data()
