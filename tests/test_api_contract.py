@@ -144,6 +144,16 @@ def test_vitlens_checkpoint_roundtrip_and_reference_format(monkeypatch, tmp_path
     assert not missing and not unexpected
     sa, sb = a.state_dict(), b.state_dict()
     assert sa.keys() == sb.keys() and all(torch.equal(sa[k], sb[k]) for k in sa)
+    # the reference's `load_from_ckpt` is the DIRECTORY holding <model_var>.pt (vitlens.py:24,118-133); no download here
+    rel = tmp_path / "model_release"
+    rel.mkdir()
+    with pytest.raises(FileNotFoundError):
+        b.load_checkpoint(str(rel))
+    a.export_checkpoint(str(rel / "vitlensL.pt"))
+    torch.manual_seed(5)
+    e = _tiny_vitlens(monkeypatch, mods)
+    assert e.load_checkpoint(str(rel)) == ([], [])
+    assert all(torch.equal(sa[k], v) for k, v in e.state_dict().items())
     # a release-format file built from the reference-generated golden weights
     sd = split(load_npz("tiny_depth.npz"))[0]
     ref_fmt = {"vitlens.depth." + k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}

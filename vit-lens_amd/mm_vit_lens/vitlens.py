@@ -90,6 +90,13 @@ class ViTLens(nn.Module):
         return missing, unexpected
 
     def load_checkpoint(self, path):
+        """`path`: a release file, or - as the reference's `load_from_ckpt` (vitlens.py:24,118-133) - the directory that holds
+        `<model_var>.pt` (there is no download: a missing file is an error)."""
+        import os
+        if os.path.isdir(path):
+            path = os.path.join(path, f"{self.model_var}.pt")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"ViT-Lens weights not found at {path} (no network access: place the release file there)")
         ckpt = torch.load(path, map_location="cpu", weights_only=False)
         return self.load_state_dict(ckpt.get("state_dict", ckpt), strict=False)
 
