@@ -21,7 +21,8 @@ class ViTLens(nn.Module):
                  load_from_ckpt: Optional[str] = None, device="cuda"):
         super().__init__()
         self.model_var = model_var
-        self.modality_loaded = modality_loaded or [ModalityType.IMAGE, ModalityType.TEXT]
+        # the reference's default (vitlens.py:22-25): every modality of the release
+        self.modality_loaded = modality_loaded or ["image", "text", "pc", "depth", "audio", "tactile", "eeg"]
         self.vitlens = nn.ModuleDict()
         self._dev = torch.device(device)
         self.processors = {}
