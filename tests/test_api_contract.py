@@ -374,7 +374,7 @@ _SIG_TARGETS = [
     ("open_clip.model", "TriCLIP.lock_text_tower"), ("open_clip.model", "TriCLIP.set_grad_checkpointing"),
     ("open_clip.loss", "ClipLoss.__init__"), ("open_clip.loss", "ClipLoss.forward"), ("open_clip.loss", "ClipLossGeneral.__init__"),
     ("open_clip.loss", "ClipLossGeneral.forward"), ("open_clip.loss", "TriClipLoss.__init__"), ("open_clip.loss", "TriClipLoss.forward"),
-    ("open_clip.loss", "gather_features"), ("open_clip.factory", "load_checkpoint"), ("open_clip.factory", "resize_pos_embed"),
+    ("open_clip.loss", "gather_features"), ("open_clip.factory", "load_checkpoint"), ("open_clip.factory", "resize_pos_embed"), ("open_clip.model", "resize_pos_embed"),
     ("open_clip.zero_shot_classifier", "build_zero_shot_classifier"), ("open_clip.zero_shot_classifier", "build_zero_shot_classifier_legacy"),
     ("mm_vit_lens.model_cfg", "fetch_model_cfg"),
     ("training.train", "tri_train_one_epoch"), ("training.train", "train_dual_one_epoch"), ("training.train", "backward"),

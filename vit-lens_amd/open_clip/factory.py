@@ -12,7 +12,7 @@ from typing import Optional, Union
 import torch
 
 from .loss import ClipLoss, ClipLossGeneral, TriClipLoss
-from .model import TriCLIP
+from .model import TriCLIP, resize_pos_embed
 from .tokenizer import tokenize
 
 _CONFIG_PATHS = [Path(__file__).parent / "model_configs"]
@@ -66,36 +66,6 @@ def load_state_dict(checkpoint_path: str, map_location="cpu"):
     if next(iter(sd)).startswith("module"):
         sd = {k[7:]: v for k, v in sd.items()}
     return sd
-
-
-def resize_pos_embed(state_dict, model, interpolation: str = "bicubic", antialias: bool = True):
-    """Rescale `visual.positional_embedding` of a checkpoint to the model's token count (open_clip/model.py:1079-1150):
-    bicubic resize of the square grid to grid_size - or to floor(sqrt(num_latents))^2 followed by a nearest resample to
-    exactly num_latents when the tower resamples with a Perceiver (e.g. a ViT-B/16 checkpoint, grid 196, into 256 latents)."""
-    import math
-    import torch.nn.functional as F
-    old = state_dict.get("visual.positional_embedding", None)
-    vis = getattr(model, "visual", None)
-    if old is None or vis is None:
-        return
-    g = vis.cfg.image_size // vis.cfg.patch_size
-    new_len = g * g + 1
-    n_lat = None
-    if vis.use_perceiver:
-        n_lat = getattr(vis.cfg.exp_args, "perceiver_num_latents", g * g)
-        new_len = n_lat + 1
-    if new_len == old.shape[0]:
-        return
-    tok, img = old[:1], old[1:]
-    og = int(math.sqrt(len(img)))
-    to = (int(math.sqrt(n_lat)),) * 2 if n_lat is not None else (g, g)
-    logging.info("Resizing position embedding grid-size from %s to %s", (og, og), to)
-    img = img.reshape(1, og, og, -1).permute(0, 3, 1, 2)
-    img = F.interpolate(img.float(), size=to, mode=interpolation, antialias=antialias, align_corners=False)
-    img = img.permute(0, 2, 3, 1).reshape(1, to[0] * to[1], -1)[0]
-    if n_lat is not None and to[0] * to[1] != n_lat:
-        img = F.interpolate(img.unsqueeze(0).transpose(1, 2), size=n_lat, mode="nearest").transpose(1, 2).squeeze(0)
-    state_dict["visual.positional_embedding"] = torch.cat([tok.float(), img], dim=0).to(old.dtype)
 
 
 def load_checkpoint(model, checkpoint_path, strict=True, args=None):

@@ -6,6 +6,7 @@ run the towers through vitlens_hip engines (bf16 MFMA GEMMs, fp32 accumulation /
 are (re)built from the parameters whenever their versions change.  There is no eager fallback: the
 forward needs a GPU and libvitlens_hip.so.
 """
+import logging
 import math
 from dataclasses import dataclass
 from typing import Any, Optional
@@ -49,6 +50,36 @@ def get_cast_dtype(precision: str):
 def get_input_dtype(precision: str):
     """model.py:109-115."""
     return {"bf16": torch.bfloat16, "pure_bf16": torch.bfloat16, "fp16": torch.float16, "pure_fp16": torch.float16}.get(precision)
+
+
+def resize_pos_embed(state_dict, model, interpolation: str = "bicubic", antialias: bool = True):
+    """Rescale `visual.positional_embedding` of a checkpoint to the model's token count (open_clip/model.py:1079-1150):
+    bicubic resize of the square grid to grid_size - or to floor(sqrt(num_latents))^2 followed by a nearest resample to
+    exactly num_latents when the tower resamples with a Perceiver (e.g. a ViT-B/16 checkpoint, grid 196, into 256 latents)."""
+    import math
+    import torch.nn.functional as F
+    old = state_dict.get("visual.positional_embedding", None)
+    vis = getattr(model, "visual", None)
+    if old is None or vis is None:
+        return
+    g = vis.cfg.image_size // vis.cfg.patch_size
+    new_len = g * g + 1
+    n_lat = None
+    if vis.use_perceiver:
+        n_lat = getattr(vis.cfg.exp_args, "perceiver_num_latents", g * g)
+        new_len = n_lat + 1
+    if new_len == old.shape[0]:
+        return
+    tok, img = old[:1], old[1:]
+    og = int(math.sqrt(len(img)))
+    to = (int(math.sqrt(n_lat)),) * 2 if n_lat is not None else (g, g)
+    logging.info("Resizing position embedding grid-size from %s to %s", (og, og), to)
+    img = img.reshape(1, og, og, -1).permute(0, 3, 1, 2)
+    img = F.interpolate(img.float(), size=to, mode=interpolation, antialias=antialias, align_corners=False)
+    img = img.permute(0, 2, 3, 1).reshape(1, to[0] * to[1], -1)[0]
+    if n_lat is not None and to[0] * to[1] != n_lat:
+        img = F.interpolate(img.unsqueeze(0).transpose(1, 2), size=n_lat, mode="nearest").transpose(1, 2).squeeze(0)
+    state_dict["visual.positional_embedding"] = torch.cat([tok.float(), img], dim=0).to(old.dtype)
 
 
 class _Node(nn.Module):
