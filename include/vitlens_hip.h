@@ -8,7 +8,9 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer borrowed for the duration of the call; nothing is
- *     retained or freed; workspaces are supplied by the caller
+ *     retained or freed; workspaces are supplied by the caller.  The few HOST arrays are named as
+ *     such at their declaration (stride tables of the attention entries, mean / stdv of the
+ *     image resampler) and are read before the call returns
  *   - all matrices are row-major; "bf16" is a 16-bit brain-float bit pattern (uint16_t)
  *   - every function is stream-ordered and non-blocking on `stream` (a hipStream_t)
  *   - return value: 0 on success, non-zero on failure; vl_last_error() gives the message
