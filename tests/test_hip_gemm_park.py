@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[8])
+@pytest.fixture(params=[8, 10])
 def pcfg(request):
     return request.param
 

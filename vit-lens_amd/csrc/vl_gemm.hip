@@ -694,20 +694,50 @@ hipError_t launch_persist(const GemmP& p, hipStream_t s) {
 // vl_gemm_park.hip: the round-2 persistent kernel (bf16-output epilogues, whole 256x256 tiles, K >= 512)
 bool vl_gemm_park_supported(int epi, const void* params);
 int vl_gemm_park_launch(int epi, const void* params, int ncu, hipStream_t s);
+// vl_gemm_pp.hip: the round-3 ping-pong kernel (two 4-wave workgroups per CU, 256x128 tiles, K >= 128)
+bool vl_gemm_pp_supported(int epi, const void* params);
+int vl_gemm_pp_launch(int epi, const void* params, int ncu, hipStream_t s);
 namespace {
 
-// the persistent kernel for a problem whose M is a whole number of tiles: the round-2 kernel where it applies
+// Kernel selection / tuning inputs of the persistent kernels.  Read once from the environment so that one build can be
+// A/B-measured on the GPU box (tools/kernel_bench.py, bench.py); the defaults are the measured best.
+struct GemmTune { int prefer_pp, pp_delay; };
+inline int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+inline const GemmTune& gemm_tune() {
+  static const GemmTune t{env_int("VL_GEMM_PP", 0), env_int("VL_PP_DELAY", 4)};
+  return t;
+}
+inline GemmP tuned(const GemmP& p) {
+  GemmP q = p;
+  q.pp_delay = gemm_tune().pp_delay;
+  return q;
+}
+
+// the persistent kernel for a problem whose M is a whole number of tiles: the round-3 / round-2 kernels where they apply
 template <int EPI>
-hipError_t launch_best_persist(const GemmP& p, hipStream_t s) {
+hipError_t launch_best_persist(const GemmP& p0, hipStream_t s) {
+  const GemmP p = tuned(p0);
+  // 256x256 tiles where N allows them (fewer operand bytes per flop: the chip is power-bound on these GEMMs, DESIGN.md
+  // section 7); the ping-pong kernel's 256x128 tiles take N % 256 == 128 (ViT-bigG: 1664 = 13 x 128)
+  if (gemm_tune().prefer_pp && vl_gemm_pp_supported(EPI, &p)) return (hipError_t)vl_gemm_pp_launch(EPI, &p, num_cus(), s);
   if (vl_gemm_park_supported(EPI, &p)) return (hipError_t)vl_gemm_park_launch(EPI, &p, num_cus(), s);
+  if (vl_gemm_pp_supported(EPI, &p)) return (hipError_t)vl_gemm_pp_launch(EPI, &p, num_cus(), s);
   return launch_persist<EPI>(p, s);
 }
 
 template <int EPI>
-hipError_t dispatch(const GemmP& p, int cfg, hipStream_t s) {
+hipError_t dispatch(const GemmP& p0, int cfg, hipStream_t s) {
+  const GemmP p = tuned(p0);
   if (cfg == 8) {
     if (!vl_gemm_park_supported(EPI, &p)) return hipErrorInvalidValue;
     return (hipError_t)vl_gemm_park_launch(EPI, &p, num_cus(), s);
+  }
+  if (cfg == 10) {
+    if (!vl_gemm_pp_supported(EPI, &p)) return hipErrorInvalidValue;
+    return (hipError_t)vl_gemm_pp_launch(EPI, &p, num_cus(), s);
   }
   // cfg bit0: 0 = 256x256 tile (8 waves), 1 = 128x128 tile (4 waves); bit1: 1 = register staging
   if (cfg == 4 || cfg == 5) return launch_persist<EPI>(p, s);       // 4: historical alias
@@ -737,8 +767,13 @@ static hipError_t run_gemm(const GemmP& p, int cfg, hipStream_t s) {
   const int G = num_cus() & ~7;
   const int tiles_n = (p.N + 255) / 256, full_m = p.M / 256;
   if ((long)full_m * tiles_n < G) return dispatch<EPI>(p, 1, s);
-  const int step = G / gcd_i(G, tiles_n);
-  const int main_m = (full_m / step) * step;
+  int step = G / gcd_i(G, tiles_n);
+  int main_m = (full_m / step) * step;
+  if ((p.N & 255) == 128) {       // 256x128 tiles on the ping-pong kernel (two workgroups per CU): whole rounds where the row
+    step = 2 * G / gcd_i(2 * G, p.N >> 7);      // count allows, otherwise every full row tile (an uneven last round beats 128x128 tiles)
+    main_m = (full_m / step) * step;
+    if (main_m == 0) main_m = full_m;
+  }
   if (main_m == 0) return launch_persist<EPI>(p, s);
   const int rows_main = main_m * 256;
   GemmP pm = p; pm.M = rows_main;
@@ -809,10 +844,13 @@ extern "C" int vl_gemm_splitk_accum_f32(const void* A, const void* W, float* out
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.out = ws; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldo = N;
   p.alpha = alpha; p.res_div = 1;
   p.split_stride = (long)M * N;
-  if (nk % splits == 0) {       // whole 256x256 tiles and equal slices: the round-2 persistent kernel writes the partials
+  if (nk % splits == 0) {       // whole 256x256 tiles and equal slices: the persistent kernels write the partials
     p.ksplit_len = nk / splits;
-    if (vl_gemm_park_supported(EPI_F32, &p)) {
-      hipError_t e = (hipError_t)vl_gemm_park_launch(EPI_F32, &p, num_cus(), stream);
+    p = tuned(p);
+    const bool use_pp = gemm_tune().prefer_pp && vl_gemm_pp_supported(EPI_F32, &p);
+    if (use_pp || vl_gemm_park_supported(EPI_F32, &p)) {
+      hipError_t e = use_pp ? (hipError_t)vl_gemm_pp_launch(EPI_F32, &p, num_cus(), stream)
+                            : (hipError_t)vl_gemm_park_launch(EPI_F32, &p, num_cus(), stream);
       if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)M * (N >> 2) + 255) / 256)), dim3(256), 0, stream, ws, splits, M, N, out, ldo);
       e = hipGetLastError();

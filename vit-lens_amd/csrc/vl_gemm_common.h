@@ -34,6 +34,9 @@ struct GemmP {
   // partial product to out + y*split_stride (f32 elements); ksplit_len == 0 -> whole K, no offset
   int ksplit_len;
   long split_stride;
+  // kernel tuning input set by the dispatcher (not part of the C ABI): start-up phase shift of the second workgroup of a
+  // CU (vl_gemm_pp.hip, units of 4096 cycles)
+  int pp_delay;
 };
 
 template <int BM, int BN>
