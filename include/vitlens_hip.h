@@ -228,6 +228,13 @@ int vl_resample_v_f32_norm(const float* src, int W, int H, int row0, const int* 
  * centre subtraction: nidx [B,G,k] int32 optional, patches bf16 [B*G*k, Kp] optional (xyz in cols 0..2). */
 int vl_knn_group(const float* xyz, const int64_t* center_idx, int* nidx, void* patches, int B, int N, int G,
                  int k, int Kp, hipStream_t stream);
+/* Ball query + grouping of the `pnsa` tokenizer (query_ball_point + sample_and_group,
+ * open_clip/modal_3d/models/pointnet/pointnet_util.py:101-161): for every centre center_idx[b,s] the first `nsample`
+ * point indices in ascending order with -2ab+|a|^2+|b|^2 <= radius2 (short groups repeat their first index) -> idx
+ * [B,S,nsample] int32 (optional) and patches [B*S*nsample, Kp] bf16 (optional) = (xyz_j - centre, feats[b,j,0:D], 0...):
+ * the rows of the first 1x1 convolution.  xyz [B,N,3] f32, feats [B,N,D] f32 or NULL with D = 0. */
+int vl_ball_group(const float* xyz, const float* feats, const int64_t* center_idx, int* idx, void* patches, int B, int N,
+                  int S, int D, float radius2, int nsample, int Kp, hipStream_t stream);
 int vl_group_max(const void* x, long ldx, void* out, int out_dtype, long ldo, long groups, int M, int C, hipStream_t stream);
 int vl_pad3_bf16(const float* c, void* out, long R, int Kp, hipStream_t stream);
 /* ---- trainable point tokenizer: nn.BatchNorm1d over [R = B*G*M, C] bf16 activations (dvae.py:184-194) ----

@@ -98,3 +98,22 @@ def test_p4_is_what_auto_dispatch_uses_at_bench_geometry():
     ref = res.float() + a.float() @ w.float().t() + bias
     assert bool(torch.isfinite(out).all()) and relerr(out, ref) < 4e-3
     assert relerr(out[-600:], ref[-600:]) < 4e-3 and relerr(out[:256], ref[:256]) < 4e-3
+
+
+@pytest.mark.parametrize("M", [256 * 40, 256 * 6 + 77])
+def test_auto_dispatch_width_1664(M):
+    """ViT-bigG-14 geometry (width 1664 = 13 x 128, model_configs/ViT-bigG-14.json): N % 256 == 128 reaches the persistent
+    256x128-tile (ping-pong) kernel through cfg=-1; the ragged rows go to the small-tile kernels."""
+    ops = _ops()
+    N = K = 1664
+    a = rnd(M, K, seed=31).bfloat16().cuda(); w = rnd(N, K, seed=32, scale=K ** -0.5).bfloat16().cuda()
+    bias = rnd(N, seed=33).cuda()
+    res = rnd(M, N, seed=34).bfloat16().cuda()
+    acc = a.float() @ w.float().t() + bias
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ops.gemm(a, w, bias, out=out, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=-1)
+    assert bool(torch.isfinite(out).all()) and relerr(out, torch.nn.functional.gelu(acc)) < 4e-3
+    out2 = ops.gemm(a, w, bias, res=res, epi=ops.EPI_RES_BF16, cfg=-1)
+    assert relerr(out2, res.float() + acc) < 4e-3
+    if M % 256 == 0:
+        assert torch.equal(out2, ops.gemm(a, w, bias, res=res, epi=ops.EPI_RES_BF16, cfg=10))

@@ -1,0 +1,174 @@
+"""GPU: the `pnsa` point tokenizer (PointNSATokenizer, open_clip/modal_3d/models/pointnet/pointnet_util.py:101-227,345-368)
+on the HIP path against the reference-generated fixture tests/golden/tiny_pnsa.npz (oracle/gen_golden.py --only pnsa 31:
+weights, inputs, FPS start, tokens in eval / train mode, FPS and ball-query indices, all 16 parameter gradients, running
+statistics after the train-mode forward), then through the drop-in API (`tri_create_model(args.pc_tokenizer="pnsa")`,
+`model.visual(features, xyz=xyz)` as VitLens-OpenShape/src/train.py:214 calls it) against the oracle's autograd."""
+import importlib
+import json
+import os
+import sys
+import tempfile
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+import vitlens_oracle as O
+from golden_util import GOLDEN, load_npz, split, specs_from_meta
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _case():
+    z = np.load(os.path.join(GOLDEN, "tiny_pnsa.npz"))
+    cfg = json.loads(str(z["meta"]))["cfg"]
+    return z, cfg
+
+
+def _lens(cfg):
+    from vitlens_hip import engine
+    return engine.LensCfg(modality="pc", pc_tokenizer="pnsa", pc_num_group=cfg["num_group"], pc_group_size=cfg["group_size"],
+                          pc_radius=cfg["radius"], pc_in_dim=cfg["in_dim"], pc_encoder_dims=cfg["encoder_dims"],
+                          pc_trans_dim=cfg["trans_dim"], input_chan=cfg["trans_dim"])
+
+
+def test_ball_query_indices_bit_exact_incl_short_groups():
+    """vl_ball_group against the oracle's restatement of query_ball_point on clouds of the OpenShape size (10 000 points,
+    512 centres, 64 samples, radius 0.2) and with a tiny radius that leaves groups holding only their centre."""
+    from vitlens_hip import ops
+    g = torch.Generator().manual_seed(5)
+    B, N, S = 2, 10000, 512
+    xyz = torch.rand(B, N, 3, generator=g) * 2 - 1
+    feats = torch.rand(B, N, 6, generator=g)
+    start = torch.randint(0, N, (B,), generator=g)
+    cidx, centers = ops.fps(xyz.cuda(), start.cuda(), S)
+    assert torch.equal(cidx.cpu(), O.fps_indices(xyz, S, start))
+    new_xyz = torch.gather(xyz, 1, cidx.cpu()[:, :, None].expand(B, S, 3))
+    for radius, ns in ((0.2, 64), (0.02, 16), (0.5, 128)):
+        patches, idx = ops.ball_group(xyz.cuda(), feats.cuda(), cidx, radius, ns, Kp=64, want_idx=True)
+        want = O.ball_query_indices(radius, ns, xyz, new_xyz)
+        assert torch.equal(idx.cpu().long(), want), radius
+        # rows of the first convolution: centre-subtracted xyz ++ features, zero padding
+        ar = torch.arange(B).view(B, 1, 1)
+        ref = torch.cat([xyz[ar, want] - new_xyz.view(B, S, 1, 3), feats[ar, want]], -1).reshape(-1, 9)
+        got = patches.float().cpu()
+        assert torch.equal(got[:, :9], ref.bfloat16().float()) and float(got[:, 9:].abs().max()) == 0.0
+    tight = O.ball_query_indices(0.02, 16, xyz, new_xyz)
+    assert bool((tight == tight[..., :1]).all(-1).any())           # the short-group padding was exercised
+
+
+def test_pnsa_tokenizer_vs_reference_golden():
+    from vitlens_hip.points import PNSATokenizerTrainer
+    z, cfg = _case()
+    sd = {"a." + k[3:]: torch.tensor(z[k]) for k in z.files if k.startswith("sd/")}
+    xyz, feats, start = torch.tensor(z["in/xyz"]).cuda(), torch.tensor(z["in/features"]).cuda(), torch.tensor(z["in/fps_start"]).cuda()
+    B, S, Tr = xyz.shape[0], cfg["num_group"], cfg["trans_dim"]
+    # eval mode: running statistics
+    ev = PNSATokenizerTrainer(sd, "a.", _lens(cfg), "cuda", bn_training=False)
+    tok = ev.forward(feats, xyz=xyz, fps_start=start)
+    cidx, bidx = ev.last_idx
+    assert torch.equal(cidx.cpu(), torch.tensor(z["out/fps_idx"]))                       # FPS picks: bit-exact
+    assert torch.equal(bidx.cpu().long(), torch.tensor(z["out/ball_idx"]))               # ball query: bit-exact
+    want = torch.tensor(z["out/eval/tokens"]).reshape(B * S, Tr)
+    assert relerr(tok, want) < 2e-2, relerr(tok, want)
+    # train mode: batch statistics, running-stat update, every parameter gradient
+    tr = PNSATokenizerTrainer(sd, "a.", _lens(cfg), "cuda", bn_training=True)
+    tok = tr.forward(feats, xyz=xyz, fps_start=start)
+    want = torch.tensor(z["out/train/tokens"]).reshape(B * S, Tr)
+    assert relerr(tok, want) < 2e-2, relerr(tok, want)
+    for i in range(3):
+        rm, rv = tr.running[f"sa.mlp_bns.{i}"]
+        assert relerr(rm, torch.tensor(z[f"sd_after/sa.mlp_bns.{i}.running_mean"])) < 2e-2
+        assert relerr(rv, torch.tensor(z[f"sd_after/sa.mlp_bns.{i}.running_var"])) < 2e-2
+    tr.backward(torch.tensor(z["in/dctx"]).reshape(B * S, Tr).cuda())
+    n = 0
+    for k in z.files:
+        if not k.startswith("grad/"):
+            continue
+        g, want = tr.grads["a." + k[5:]].float().cpu().reshape(-1), torch.tensor(z[k]).reshape(-1)
+        if "mlp_convs" in k and k.endswith(".bias"):
+            # a per-channel constant in front of a train-mode BatchNorm has an identically zero gradient: round-off on both sides
+            wn = float(torch.tensor(z[k[:-4] + "weight"]).norm())
+            assert float(g.norm()) < 2e-2 * wn, k
+        else:
+            assert relerr(g, want) < 6e-2, (k, relerr(g, want))
+        n += 1
+    assert n == 16
+
+
+def _oc():
+    for k in [k for k in sys.modules if k == "open_clip" or k.startswith("open_clip.")]:
+        f = getattr(sys.modules[k], "__file__", "") or ""
+        if "vit-lens_amd" not in f:
+            del sys.modules[k]
+    oc = importlib.import_module("open_clip")
+    assert "vit-lens_amd" in oc.__file__
+    return oc
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_pnsa_through_tri_create_model(training):
+    """tri_create_model with args.pc_tokenizer = "pnsa": the tokenizer weights of the reference fixture inside a tiny Lens +
+    ViT tower; forward `model.visual(features, xyz=xyz)` and, in train mode, the gradient of every unlocked parameter of
+    the tower (pnsa tokenizer, Perceiver, cls) against the oracle's autograd of pnsa_tokens -> perceiver -> vit_trunk."""
+    oc = _oc()
+    z, cfg = _case()
+    _, _, _, _, meta = split(load_npz("tiny_pc.npz"))
+    a = dict(meta["args"])
+    a.update(pc_tokenizer="pnsa", pc_in_channel=cfg["in_dim"], pc_num_group=cfg["num_group"], pc_group_size=cfg["group_size"],
+             pc_radius=cfg["radius"], pc_encoder_dims=cfg["encoder_dims"], pc_trans_dim=cfg["trans_dim"],
+             perceiver_input_chan=cfg["trans_dim"])
+    meta = {"args": a, "model_cfg": meta["model_cfg"]}
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "tiny-lens.json"), "w") as f:
+            json.dump(meta["model_cfg"], f)
+        oc.add_model_config(td)
+        torch.manual_seed(3)
+        model = oc.tri_create_model("tiny-lens", None, precision="fp32", device="cuda", output_dict=True, args=SimpleNamespace(**a))
+    tok_sd = {"visual.visual_adapter." + k[3:]: torch.tensor(z[k]) for k in z.files if k.startswith("sd/")}
+    miss = model.load_state_dict(tok_sd, strict=False)
+    assert not miss.unexpected_keys, miss.unexpected_keys
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    tower, _, lens = specs_from_meta(meta)
+    xyz, feats, start = torch.tensor(z["in/xyz"]), torch.tensor(z["in/features"]), torch.tensor(z["in/fps_start"])
+    model.lock_visual_tower(unlocked_groups=0, freeze_bn_stats=False, unlock_cls=True)
+    model.train(training)
+
+    def oracle(sdo):
+        t, _, _ = O.pnsa_tokens(sdo, "visual.visual_adapter.", feats, xyz, cfg["num_group"], cfg["radius"], cfg["group_size"], start,
+                                training=training)
+        return O.vit_trunk(sdo, "visual.", O.perceiver(sdo, "visual.perceiver.", t, lens), tower, lens.use_orig_pos)
+    if not training:
+        with torch.no_grad():
+            got = model.visual(feats.cuda(), xyz=xyz.cuda(), fps_start=start.cuda())
+        assert relerr(got, oracle(sd)) < 3e-2
+        return
+    names = [n for n, p in model.visual.named_parameters() if p.requires_grad]
+    assert any("visual_adapter.sa.mlp_convs" in n for n in names) and any(n.startswith("perceiver.") for n in names) and "class_embedding" in names
+    got = model.visual(feats.cuda(), xyz=xyz.cuda(), fps_start=start.cuda())
+    gsel = torch.Generator().manual_seed(9)
+    dfeat = torch.randn(got.shape, generator=gsel)
+    (got * dfeat.cuda()).sum().backward()
+    sdr = dict(sd)
+    for n in names:
+        sdr["visual." + n] = sd["visual." + n].clone().requires_grad_(True)
+    ref = oracle(sdr)
+    assert relerr(got.detach(), ref.detach()) < 3e-2
+    (ref * dfeat).sum().backward()
+    params = dict(model.visual.named_parameters())
+    checked = 0
+    for n in names:
+        g, want = params[n].grad, sdr["visual." + n].grad
+        assert g is not None, n
+        if "mlp_convs" in n and n.endswith(".bias"):
+            continue                          # zero by construction in front of a train-mode BatchNorm
+        tol = 0.30 if "visual_adapter.sa" in n else 8e-2     # arg-max routing of the group max over bf16 activations (as for PointBERT)
+        assert relerr(g, want) < tol, (n, relerr(g, want))
+        checked += 1
+    assert checked >= 20

@@ -12,6 +12,11 @@
 //                 -2ab + |a|^2 + |b|^2 (dvae.py:107-140) via an exact radix select of the k-th smallest
 //                 key (no sort, no N x G distance matrix in HBM), then gather + centre-subtract
 //                 (Group.forward, dvae.py:150-176) straight into the bf16 GEMM operand of the first conv.
+//   vl_ball_group ball query + grouping of the `pnsa` tokenizer (query_ball_point / sample_and_group,
+//                 open_clip/modal_3d/models/pointnet/pointnet_util.py:101-161): per centre the FIRST nsample point indices
+//                 (ascending) with -2ab + |a|^2 + |b|^2 <= r^2, short groups padded with their first index; one wave per
+//                 centre scans the cloud in index order (ballot + prefix popcount, stops at nsample hits - no N x S
+//                 distance matrix, no sort), then writes the centre-subtracted xyz ++ point features as bf16 GEMM rows
 //   vl_group_max  max over the points of a group (torch.max(feature, dim=2), dvae.py:206,211)
 //   vl_pc_gather_normalize  the data-loader side of the 3D path on the GPU: gather the sampled points and
 //                 scale them into the unit sphere (pc_norm, modal_3d/processors/pc_processor.py:32-38); with vl_fps in
@@ -149,6 +154,63 @@ __global__ void __launch_bounds__(256) knn_group_kernel(const float* xyz, const 
   }
 }
 
+// one wave per centre.  The distance is the reference's expression with the CPU's rounding (pinned on 10.24 M distances
+// against torch: the K = 3 matmul is an FMA chain x, y, z; the squared norms are plain sums; tests/test_oracle_pnsa.py).
+__global__ void __launch_bounds__(256) ball_group_kernel(const float* xyz, const float* feats, const int64_t* cidx, int N, int S,
+                                                         int D, float r2, int ns, int* out_idx, bf16_t* patches, int Kp) {
+  extern __shared__ int s_ball[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int* my = s_ball + wv * ns;
+  const long w = (long)blockIdx.x * 4 + wv;                        // global centre index b*S + s
+  const int b = (int)(w / S);
+  const float* P = xyz + (size_t)b * N * 3;
+  const int ci = (int)cidx[w];
+  const float cx = P[ci * 3], cy = P[ci * 3 + 1], cz = P[ci * 3 + 2];
+  int count = 0, first = 0;
+  {
+#pragma clang fp contract(off)
+    const float cc = (cx * cx + cy * cy) + cz * cz;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int base = 0; base < N && count < ns; base += 64) {
+      const int i = base + lane;
+      bool in = false;
+      if (i < N) {
+        const float x = P[i * 3], y = P[i * 3 + 1], z = P[i * 3 + 2];
+        const float dot = __builtin_fmaf(cz, z, __builtin_fmaf(cy, y, cx * x));
+        const float pp = (x * x + y * y) + z * z;
+        const float d = (-2.0f * dot + cc) + pp;                   // (-2 is a power of two: a fused -2*dot + cc rounds identically)
+        in = !(d > r2);                                            // the reference drops d > r^2
+      }
+      const unsigned long long m = __ballot(in);
+      if (m) {
+        if (count == 0) first = base + __ffsll((long long)m) - 1;
+        const int rank = count + __popcll(m & lt_mask);
+        if (in && rank < ns) my[rank] = i;
+        count += __popcll(m);
+      }
+    }
+  }
+  count = min(count, ns);
+  for (int t = lane; t < ns; t += 64)
+    if (t >= count) my[t] = first;                                 // group_idx[mask] = group_first[mask]
+  __syncthreads();
+  if (out_idx)
+    for (int t = lane; t < ns; t += 64) out_idx[w * ns + t] = my[t];
+  if (patches) {
+    const float* F = feats ? feats + (size_t)b * N * D : nullptr;
+    for (int t = 0; t < ns; ++t) {
+      const int i = my[t];
+      bf16_t* o = patches + ((size_t)w * ns + t) * Kp;
+      for (int e = lane; e < Kp; e += 64) {
+        float v = 0.f;
+        if (e < 3) v = P[i * 3 + e] - (e == 0 ? cx : (e == 1 ? cy : cz));
+        else if (e < 3 + D) v = F[(size_t)i * D + (e - 3)];
+        o[e] = f2bf(v);
+      }
+    }
+  }
+}
+
 // out[g, c] = max_{m < M} x[g*M + m, c]
 template <typename TOUT>
 __global__ void __launch_bounds__(256) group_max_kernel(const bf16_t* x, long ldx, TOUT* out, long ldo, long groups, int M, int C) {
@@ -245,6 +307,19 @@ extern "C" int vl_knn_group(const float* xyz, const int64_t* center_idx, int* ni
   static bool attr = false;
   if (!attr) { VL_HIP_OK(hipFuncSetAttribute((const void*)knn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
   hipLaunchKernelGGL(knn_group_kernel, grid, block, smem, stream, xyz, center_idx, N, G, k, nidx, (bf16_t*)patches, Kp);
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vl_ball_group(const float* xyz, const float* feats, const int64_t* center_idx, int* idx, void* patches, int B,
+                             int N, int S, int D, float radius2, int nsample, int Kp, hipStream_t stream) {
+  if (B <= 0 || N <= 0 || S <= 0 || nsample <= 0 || D < 0) return vl_set_error("vl_ball_group: bad shape");
+  if (((long)B * S) % 4) return vl_set_error("vl_ball_group: B*S must be a multiple of 4");
+  if (D > 0 && !feats) return vl_set_error("vl_ball_group: D > 0 without point features");
+  if (patches && Kp < 3 + D) return vl_set_error("vl_ball_group: Kp < 3 + D");
+  if (nsample > 2048) return vl_set_error("vl_ball_group: at most 2048 samples per group");
+  hipLaunchKernelGGL(ball_group_kernel, dim3((unsigned)(((long)B * S) / 4)), dim3(256), (size_t)4 * nsample * sizeof(int), stream,
+                     xyz, feats, center_idx, N, S, D, radius2, nsample, idx, (bf16_t*)patches, Kp);
   VL_HIP_OK(hipGetLastError());
   return 0;
 }

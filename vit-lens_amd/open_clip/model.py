@@ -185,9 +185,24 @@ class VisionTransformer(nn.Module):
                 bufs[f"visual_adapter.{name}.running_mean"] = torch.zeros(c)
                 bufs[f"visual_adapter.{name}.running_var"] = torch.ones(c)
                 bufs[f"visual_adapter.{name}.num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
-            lin("encoder.first_conv.0", 128, 3, True); bn("encoder.first_conv.1", 128); lin("encoder.first_conv.3", 256, 128, True)
-            lin("encoder.second_conv.0", 512, 512, True); bn("encoder.second_conv.1", 512); lin("encoder.second_conv.3", E, 512, True)
-            lin("reduce_dim", Tr, E); lin("pos_embed.0", 128, 3); lin("pos_embed.2", Tr, 128)
+            if _g(a, "pc_tokenizer", "pointbert") == "pnsa":
+                # PointNSATokenizer (modal_3d/models/pointnet/pointnet_util.py:345-360): set abstraction over
+                # [xyz - centre ++ point features] with mlp [64, 64, encoder_dims], then lift = Conv1d + LayerNorm
+                last = _g(a, "pc_in_channel", 3) + 3
+                for i, oc in enumerate((64, 64, E)):
+                    prm[f"visual_adapter.sa.mlp_convs.{i}.weight"] = _uni((oc, last, 1, 1), last ** -0.5)
+                    prm[f"visual_adapter.sa.mlp_convs.{i}.bias"] = _uni((oc,), last ** -0.5)
+                    last = oc
+                for i, oc in enumerate((64, 64, E)):
+                    bn(f"sa.mlp_bns.{i}", oc)
+                lin("lift.0", Tr, E + 3, True)
+                prm["visual_adapter.lift.2.weight"] = torch.ones(Tr); prm["visual_adapter.lift.2.bias"] = torch.zeros(Tr)
+            elif _g(a, "pc_tokenizer", "pointbert") == "pointbert":
+                lin("encoder.first_conv.0", 128, 3, True); bn("encoder.first_conv.1", 128); lin("encoder.first_conv.3", 256, 128, True)
+                lin("encoder.second_conv.0", 512, 512, True); bn("encoder.second_conv.1", 512); lin("encoder.second_conv.3", E, 512, True)
+                lin("reduce_dim", Tr, E); lin("pos_embed.0", 128, 3); lin("pos_embed.2", Tr, 128)
+            else:
+                raise NotImplementedError(f"pc_tokenizer {a.pc_tokenizer!r} (visual_adapter.py:11-22 knows pointbert and pnsa)")
         else:
             raise NotImplementedError(f"modality {self.modality!r}")
         if self.use_perceiver and not self.perceiver_identity:
@@ -322,7 +337,9 @@ class VisionTransformer(nn.Module):
                 eeg_time_len=_g(a, "eeg_time_len", 512), eeg_window_size=_g(a, "eeg_window_size", 1),
                 eeg_stride=_g(a, "eeg_stride", 1), pc_num_group=_g(a, "pc_num_group", 512),
                 pc_group_size=_g(a, "pc_group_size", 32), pc_encoder_dims=_g(a, "pc_encoder_dims", 256),
-                pc_trans_dim=_g(a, "pc_trans_dim", 384), use_orig_pos=not _g(a, "disable_orig_pos", False),
+                pc_trans_dim=_g(a, "pc_trans_dim", 384), pc_tokenizer=_g(a, "pc_tokenizer", "pointbert"),
+                pc_radius=_g(a, "pc_radius", 0.2), pc_in_dim=_g(a, "pc_in_channel", 3),
+                use_orig_pos=not _g(a, "disable_orig_pos", False),
                 disable_adapter_pos=bool(_g(a, "disable_visual_adapter_pos", False)),
                 weight_tie_layers=bool(_g(a, "perceiver_weight_tie_layers", False)))
         return tower, lens
@@ -370,11 +387,12 @@ class VisionTransformer(nn.Module):
             elif self.modality == "eeg" and not self.perceiver_identity:
                 tr = T.EEGLensTrainer(eng, tower_kw=kw)
             elif self.modality == "pc" and not self.perceiver_identity:
-                from vitlens_hip.points import PointTokenizerTrainer
+                from vitlens_hip.points import PNSATokenizerTrainer, PointTokenizerTrainer
                 sd = {("t." + k): v for k, v in self.state_dict().items() if k.startswith("visual_adapter.")}
                 sync = self._bn_sync or (None, 1)
-                tok = PointTokenizerTrainer(sd, "t.visual_adapter.", eng.lens, eng.device, bn_training=bn_train, bn_sync=sync[0],
-                                            world_size=sync[1])
+                cls_tok = PNSATokenizerTrainer if eng.lens.pc_tokenizer == "pnsa" else PointTokenizerTrainer
+                tok = cls_tok(sd, "t.visual_adapter.", eng.lens, eng.device, bn_training=bn_train, bn_sync=sync[0],
+                              world_size=sync[1])
                 tr = T.PCLensTrainer(eng, tok, tower_kw=kw)
             else:
                 raise NotImplementedError(f"training recipe for modality {self.modality!r} "
@@ -407,10 +425,29 @@ class VisionTransformer(nn.Module):
         if torch.is_grad_enabled() and trainable:
             names = tuple(n for n, _ in trainable)
             return _TowerFn.apply(self, x, kwargs, names, *[p for _, p in trainable])
+        if self.modality == "pc" and self.training and not self._freeze_bn:
+            # a no-grad forward in TRAIN mode (the feature-caching pass of the accumulation loop, training/train.py:154-178):
+            # the reference's BatchNorm layers use the batch statistics there and update their running statistics, exactly
+            # as in the pass with a graph - not the folded running statistics of the inference engine
+            tr = self._trainer()
+            self._gen += 1            # a pending backward of an earlier forward must not use the overwritten activations
+            feat = tr.forward(x, **kwargs)
+            self._sync_bn_buffers(tr)
+            return feat.clone()
         eng = self.engine()
         if self.modality in ("image", "tactile"):
             return eng.encode_image(x)
         return eng.encode(x, **kwargs)
+
+    def _sync_bn_buffers(self, tr):
+        """Running statistics of the point tokenizer's BatchNorm layers after a train-mode forward -> this module's buffers."""
+        bufs = dict(self.named_buffers())
+        for k, (rm, rv) in tr.tok.running.items():
+            for nm, src in ((".running_mean", rm), (".running_var", rv)):
+                dst = bufs["visual_adapter." + k + nm]
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
+            bufs["visual_adapter." + k + ".num_batches_tracked"] += 1
 
 
 class _TowerFn(torch.autograd.Function):
@@ -426,13 +463,7 @@ class _TowerFn(torch.autograd.Function):
         ctx.shapes = [tuple(p.shape) for p in params]
         feat = tr.forward(x.detach(), **kwargs)
         if module.modality == "pc" and module.training and not module._freeze_bn:      # BatchNorm running statistics
-            bufs = dict(module.named_buffers())
-            for k, (rm, rv) in tr.tok.running.items():
-                for nm, src in ((".running_mean", rm), (".running_var", rv)):
-                    dst = bufs["visual_adapter." + k + nm]
-                    if dst.data_ptr() != src.data_ptr():
-                        dst.copy_(src)
-                bufs["visual_adapter." + k + ".num_batches_tracked"] += 1
+            module._sync_bn_buffers(tr)
         return feat.clone()        # the trainer's feature buffer is reused by the next forward
 
     @staticmethod

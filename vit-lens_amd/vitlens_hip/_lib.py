@@ -47,6 +47,7 @@ SIGNATURES = {
     "vl_resample_h_f32": [P, L, I, I, I, P, P, I, I, I, I, F, F, F, P, P],
     "vl_resample_v_f32_norm": [P, I, I, I, P, P, I, I, I, F, F, P, P],
     "vl_knn_group": [P, P, P, P, I, I, I, I, I, P],
+    "vl_ball_group": [P, P, P, P, P, I, I, I, I, F, I, I, P],
     "vl_group_max": [P, L, P, I, L, L, I, I, P],
     "vl_pad3_bf16": [P, P, L, I, P],
     "vl_bn_stats": [P, L, I, I, P, I, P, P, P, P, F, P],

@@ -207,6 +207,9 @@ class LensCfg:
     pc_group_size: int = 32
     pc_encoder_dims: int = 256
     pc_trans_dim: int = 384
+    pc_tokenizer: str = "pointbert"        # "pointbert" (FPS + kNN mini-PointNet) | "pnsa" (FPS + ball query set abstraction)
+    pc_radius: float = 0.2                 # ball-query radius of the pnsa tokenizer
+    pc_in_dim: int = 3                     # point feature channels of the pnsa tokenizer (its convs see 3 + pc_in_dim)
     use_orig_pos: bool = True
     disable_adapter_pos: bool = False
     eeg_chans: int = 128               # modal_eeg/models/EEG_tokenizer.py (PatchEmbed1D)
@@ -340,8 +343,12 @@ class LensEngine:
             self.conv_b = _dev(sd[a + "proj.bias"], device)
             self.adapter_pos = _dev(sd[a + "pos_emb"].detach().float() * (0.0 if lens.disable_adapter_pos else 1.0), device)
         elif lens.modality == "pc":
-            from .points import PointTokenizerEngine
-            self.points = PointTokenizerEngine(sd, a, lens, device, gemm_cfg=gemm_cfg)
+            if lens.pc_tokenizer == "pnsa":       # inference = the trainer class with the running BatchNorm statistics
+                from .points import PNSATokenizerTrainer
+                self.points = PNSATokenizerTrainer(sd, a, lens, device, gemm_cfg=gemm_cfg, bn_training=False)
+            else:
+                from .points import PointTokenizerEngine
+                self.points = PointTokenizerEngine(sd, a, lens, device, gemm_cfg=gemm_cfg)
         else:
             raise NotImplementedError(lens.modality)
         self.perceiver = None if lens.perceiver_identity else PerceiverEngine(sd, prefix + "perceiver.", lens, device, gemm_cfg)

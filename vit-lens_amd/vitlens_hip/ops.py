@@ -392,6 +392,21 @@ def knn_group(xyz, center_idx, k, Kp=64, want_idx=False):
     return patches, nidx
 
 
+def ball_group(xyz, feats, center_idx, radius, nsample, Kp=64, want_idx=False):
+    """Ball query + grouping of the `pnsa` tokenizer (pointnet_util.py:101-161).  xyz [B,N,3] f32, feats [B,N,D] f32 or
+    None, center_idx [B,S] int64 -> (patches bf16 [B*S*nsample, Kp] = (xyz_j - centre ++ feats_j, zero padded),
+    idx int32 [B,S,nsample] or None).  The radius is squared in double and rounded to f32, as `d > radius ** 2` does."""
+    import numpy as np
+    B, N, _ = xyz.shape
+    S = center_idx.shape[1]
+    D = 0 if feats is None else feats.shape[2]
+    idx = torch.empty(B, S, nsample, device=xyz.device, dtype=torch.int32) if want_idx else None
+    patches = torch.empty(B * S * nsample, Kp, device=xyz.device, dtype=torch.bfloat16)
+    check(_lib.vl_ball_group(_p(xyz.contiguous()), _p(feats.contiguous() if feats is not None else None), _p(center_idx.contiguous()),
+                             _p(idx), _p(patches), B, N, S, D, float(np.float32(float(radius) ** 2)), nsample, Kp, _stream()))
+    return patches, idx
+
+
 def group_max(x, M, out_dtype=torch.bfloat16):
     _chk2d(x, "x", torch.bfloat16)
     groups = x.shape[0] // M

@@ -228,3 +228,105 @@ class PointTokenizerTrainer:
         dh1 = ops.gemm(df, o["w2T"], None, cfg=c)
         dz1 = self._bn_bwd(dh1, z1, (m1, v1, t1), "encoder.first_conv.1")
         self._dw(a + "encoder.first_conv.0.weight", dz1, patches, cols=3); self._db(a + "encoder.first_conv.0.bias", dz1)
+
+
+class PNSATokenizerTrainer(PointTokenizerTrainer):
+    """The `pnsa` point tokenizer (PointNSATokenizer, open_clip/modal_3d/models/pointnet/pointnet_util.py:345-368) on the
+    HIP kernels, forward and backward: PointNetSetAbstraction (:184-227: FPS centres, ball query, centre-subtracted xyz ++
+    point features, three 1x1 Conv2d + BatchNorm2d + ReLU, max over the group) then `lift` = Conv1d over
+    [centre xyz ++ group feature] + LayerNorm.  forward(features [B,N,in_dim], xyz [B,N,3]) -> tokens bf16 [B*S, trans_dim]
+    (no positional term: the Sample holds "x" only).
+
+    One class serves inference and training: bn_training=False applies the running statistics and updates nothing.
+    FPS / ball query produce indices only, so the backward stops at the gathered rows."""
+
+    def __init__(self, sd, a: str, lens, device, grads=None, gemm_cfg=-1, bn_training=True, bn_sync=None, world_size=1):
+        self.a, self.lens, self.device, self.cfg, self.bn_training = a, lens, torch.device(device), gemm_cfg, bn_training
+        self.bn_sync, self.world = bn_sync, world_size
+        self.grads = {} if grads is None else grads
+        f32 = lambda k: sd[a + k].detach().float().to(device).contiguous().clone()
+        m = self.masters = {}
+        for i in range(3):
+            w = f32(f"sa.mlp_convs.{i}.weight")
+            m[a + f"sa.mlp_convs.{i}.weight"] = w.reshape(w.shape[0], -1).contiguous(); m[a + f"sa.mlp_convs.{i}.bias"] = f32(f"sa.mlp_convs.{i}.bias")
+            m[a + f"sa.mlp_bns.{i}.weight"] = f32(f"sa.mlp_bns.{i}.weight"); m[a + f"sa.mlp_bns.{i}.bias"] = f32(f"sa.mlp_bns.{i}.bias")
+        wl = f32("lift.0.weight")
+        m[a + "lift.0.weight"] = wl.reshape(wl.shape[0], -1).contiguous(); m[a + "lift.0.bias"] = f32("lift.0.bias")
+        m[a + "lift.2.weight"] = f32("lift.2.weight"); m[a + "lift.2.bias"] = f32("lift.2.bias")
+        self.running = {f"sa.mlp_bns.{i}": (f32(f"sa.mlp_bns.{i}.running_mean"), f32(f"sa.mlp_bns.{i}.running_var")) for i in range(3)}
+        self.in_ch = m[a + "sa.mlp_convs.0.weight"].shape[1]               # 3 + in_dim
+        self.op = {}
+        self.refresh_operands()
+        self.ctx = None
+
+    @staticmethod
+    def _pad64(n):
+        return (n + 63) // 64 * 64
+
+    def refresh_operands(self):
+        a, m, o = self.a, self.masters, self.op
+
+        def padk(w):
+            out = torch.zeros(w.shape[0], self._pad64(w.shape[1]), device=w.device, dtype=BF)
+            out[:, :w.shape[1]] = w.to(BF)
+            return out
+        for i in range(3):
+            w = m[a + f"sa.mlp_convs.{i}.weight"]
+            o[f"w{i}"] = padk(w)
+            if i:
+                o[f"w{i}T"] = w.t().to(BF).contiguous()
+        wl = m[a + "lift.0.weight"]
+        o["wl"] = padk(wl)
+        o["wlT_feat"] = wl[:, 3:].t().to(BF).contiguous()                    # [C', trans]: dX of the group-feature columns only
+
+    def forward(self, features: torch.Tensor, xyz: torch.Tensor = None, fps_start=None) -> torch.Tensor:
+        if xyz is None:
+            raise ValueError("the pnsa tokenizer needs the point coordinates: visual(features, xyz=xyz) (pointnet_util.py:362-363)")
+        L, a, m, o, c = self.lens, self.a, self.masters, self.op, self.cfg
+        S, ns = L.pc_num_group, L.pc_group_size
+        xyz = xyz.to(self.device).contiguous().float()
+        feats = features.to(self.device).contiguous().float()
+        if fps_start is None:       # farthest_point_sample draws its first centre at random (pointnet_util.py:91)
+            fps_start = torch.randint(0, xyz.shape[1], (xyz.shape[0],), device=self.device, dtype=torch.long)
+        cidx, centers = ops.fps(xyz, fps_start.to(self.device), S)
+        patches, bidx = ops.ball_group(xyz, feats, cidx, L.pc_radius, ns, Kp=o["w0"].shape[1], want_idx=True)
+        x, zs, stats = patches, [], []
+        for i in range(3):
+            z = ops.gemm(x, o[f"w{i}"], m[a + f"sa.mlp_convs.{i}.bias"], cfg=c)
+            h, st = self._bn(z, f"sa.mlp_bns.{i}")
+            zs.append((x, z, h)); stats.append(st)
+            x = h
+        feat = ops.group_max(x, ns)                                           # [B*S, C']
+        Kl = o["wl"].shape[1]
+        lift_in = torch.zeros(feat.shape[0], Kl, device=self.device, dtype=BF)
+        lift_in[:, :3] = centers.reshape(-1, 3)
+        lift_in[:, 3:3 + feat.shape[1]] = feat
+        y = ops.gemm(lift_in, o["wl"], m[a + "lift.0.bias"], cfg=c)           # Conv1d(C' + 3 -> trans)
+        R, Tr = y.shape
+        mean = torch.empty(R, device=self.device, dtype=torch.float32); rstd = torch.empty_like(mean)
+        tok = torch.empty(R, Tr, device=self.device, dtype=BF)
+        ops.layernorm(y, m[a + "lift.2.weight"], m[a + "lift.2.bias"], tok, R, Tr, mean=mean, rstd=rstd)
+        self.ctx = (zs, stats, feat, lift_in, y, mean, rstd)
+        self.last_idx = (cidx, bidx)
+        return tok
+
+    def backward(self, dctx: torch.Tensor):
+        """dctx f32|bf16 [B*S, trans_dim] = gradient w.r.t. the returned tokens."""
+        L, a, m, o, c = self.lens, self.a, self.masters, self.op, self.cfg
+        ns = L.pc_group_size
+        zs, stats, feat, lift_in, y, mean, rstd = self.ctx
+        R, Tr = y.shape
+        dtok = dctx.contiguous()
+        ops.layernorm_bwd_params(dtok, y, mean, rstd, self.grad_buffer(a + "lift.2.weight"), self.grad_buffer(a + "lift.2.bias"), R, Tr)
+        dy = torch.empty(R, Tr, device=self.device, dtype=BF)
+        ops.layernorm_bwd(dtok, y, mean, rstd, m[a + "lift.2.weight"], R, Tr, dx=dy)
+        self._dw(a + "lift.0.weight", dy, lift_in, cols=m[a + "lift.0.weight"].shape[1]); self._db(a + "lift.0.bias", dy)
+        dfeat = ops.gemm(dy, o["wlT_feat"], None, cfg=c)                      # [B*S, C']
+        dh = ops.group_max_bwd(zs[2][2], dfeat, ns)
+        for i in (2, 1, 0):
+            x, z, _ = zs[i]
+            dz = self._bn_bwd(dh, z, stats[i], f"sa.mlp_bns.{i}")
+            self._dw(a + f"sa.mlp_convs.{i}.weight", dz, x, cols=self.in_ch if i == 0 else None)
+            self._db(a + f"sa.mlp_convs.{i}.bias", dz)
+            if i:
+                dh = ops.gemm(dz, o[f"w{i}T"], None, cfg=c)

@@ -631,9 +631,10 @@ class PCLensTrainer:
     def grads(self):
         return self.tower.grads
 
-    def forward(self, pts: torch.Tensor, fps_start=None) -> torch.Tensor:
+    def forward(self, pts: torch.Tensor, fps_start=None, **kw) -> torch.Tensor:
+        """pts [B,N,3] (PointBERT tokenizer) or point features [B,N,in_dim] with xyz=[B,N,3] (pnsa tokenizer)."""
         B = pts.shape[0]
-        ctx = self.tok.forward(pts, fps_start)                    # tokens + pos, bf16 [B*G, C]
+        ctx = self.tok.forward(pts, fps_start=fps_start, **kw)    # tokens (+ pos), bf16 [B*G, C]
         return self.tower.forward(self.perc.forward(ctx, B), B)
 
     def backward(self, dfeat: torch.Tensor):
