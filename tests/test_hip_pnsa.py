@@ -97,9 +97,64 @@ def test_pnsa_tokenizer_vs_reference_golden():
             wn = float(torch.tensor(z[k[:-4] + "weight"]).norm())
             assert float(g.norm()) < 2e-2 * wn, k
         else:
-            assert relerr(g, want) < 6e-2, (k, relerr(g, want))
+            # the set-abstraction gradients pass through the group max over bf16 activations: a few arg-max picks differ from
+            # the fp32 reference's (as for PointBERT, tests/test_hip_api.py:_pc_tol); the tight check of exactly these
+            # gradients is test_pnsa_backward_given_forward_routing below
+            tol = 0.30 if "sa." in k else 6e-2
+            assert relerr(g, want) < tol, (k, relerr(g, want))
         n += 1
     assert n == 16
+
+
+def _pnsa_routed(sd, a, x0, centers, ns, idx, gates, training):
+    """The oracle's pnsa arithmetic (vitlens_oracle.pnsa_tokens) on GIVEN grouped rows, with the group max taken at the
+    given arg-max rows and, optionally, the ReLUs replaced by given 0/1 gates."""
+    x = x0
+    for i in range(3):
+        w = sd[f"{a}sa.mlp_convs.{i}.weight"][:, :, 0, 0]
+        y = O.batch_norm_rows(x @ w.t() + sd[f"{a}sa.mlp_convs.{i}.bias"], sd, f"{a}sa.mlp_bns.{i}.", training)
+        x = y * gates[i] if gates is not None else torch.relu(y)
+    BS = x.shape[0] // ns
+    feat = x.view(BS, ns, -1).gather(1, idx[:, None, :]).squeeze(1)
+    y = torch.cat([centers, feat], -1) @ sd[a + "lift.0.weight"][:, :, 0].t() + sd[a + "lift.0.bias"]
+    return O.layer_norm(y, sd[a + "lift.2.weight"], sd[a + "lift.2.bias"])
+
+
+@pytest.mark.parametrize("bn_train", [False, True])
+def test_pnsa_backward_given_forward_routing(bn_train):
+    """All 16 parameter gradients at the 6e-2 bound of every other trainable tensor, with the two discrete decisions of the
+    forward taken out of the comparison (as tests/test_hip_train.py does for PointBERT): the arg-max rows of the group max
+    and - with train-mode BatchNorm, whose batch statistics of bf16 activations move pre-activations across zero - the
+    ReLU gates are read from the HIP forward, and the oracle's autograd is evaluated with them on the kernel's own rows."""
+    from vitlens_hip.points import PNSATokenizerTrainer
+    z, cfg = _case()
+    a = "a."
+    sd = {a + k[3:]: torch.tensor(z[k]) for k in z.files if k.startswith("sd/")}
+    xyz, feats, start = torch.tensor(z["in/xyz"]).cuda(), torch.tensor(z["in/features"]).cuda(), torch.tensor(z["in/fps_start"]).cuda()
+    ns, nin = cfg["group_size"], 3 + cfg["in_dim"]
+    tr = PNSATokenizerTrainer(sd, a, _lens(cfg), "cuda", bn_training=bn_train)
+    out = tr.forward(feats, xyz=xyz, fps_start=start)
+    zs, stats, feat, lift_in = tr.ctx[:4]
+    x0 = zs[0][0][:, :nin].float().cpu()
+    gates = [(h.float() > 0).float().cpu() for _, _, h in zs] if bn_train else None
+    h2 = zs[2][2].float().cpu()
+    idx = h2.view(-1, ns, h2.shape[1]).argmax(dim=1)                 # first maximum, as group_max_bwd_kernel
+    centers = lift_in[:, :3].float().cpu()
+    sdr = {k: (v.clone().requires_grad_(True) if (v.dtype.is_floating_point and "running" not in k) else v) for k, v in sd.items()}
+    ref = _pnsa_routed(sdr, a, x0, centers, ns, idx, gates, bn_train)
+    assert relerr(out, ref.detach()) < 2e-2, relerr(out, ref.detach())
+    g = torch.Generator().manual_seed(21)
+    dctx = torch.randn(ref.shape, generator=g)
+    ref.backward(dctx)
+    tr.backward(dctx.cuda())
+    errs = {}
+    for name, gr in tr.grads.items():
+        if bn_train and "mlp_convs" in name and name.endswith(".bias"):
+            continue                                   # identically zero in front of a train-mode BatchNorm
+        errs[name[len(a):]] = round(relerr(gr, sdr[name].grad.reshape(gr.shape)), 4)
+    print(sorted(errs.items()))
+    bad = {k: v for k, v in errs.items() if v >= 6e-2}
+    assert len(errs) >= 13 and not bad, bad
 
 
 def _oc():

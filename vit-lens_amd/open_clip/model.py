@@ -239,7 +239,7 @@ class VisionTransformer(nn.Module):
                 mods[str(i)] = mods["1"]
         self.image_mean = self.image_std = None
         self._engine = None
-        self._engine_key = None
+        self._engine_key, self._engine_vers = None, None
         self._trainer_obj, self._trainer_key, self._gen = None, None, 0
         self._freeze_bn = False
         self._bn_sync = None          # (communicator, world size) once set_bn_sync(True) was called in a multi-rank job
@@ -345,11 +345,15 @@ class VisionTransformer(nn.Module):
         return tower, lens
 
     def engine(self):
+        """The tower's executor on the HIP kernels.  Built ONCE per (device, train/eval mode); when parameters changed since
+        the last call (an optimizer step, load_state_dict) only their device operands are re-derived, in place - the
+        frozen ViT-L weights are cast to bf16 once, and the trainer bound to this engine keeps its activation buffers."""
         from vitlens_hip import engine as E
         dev = self.class_embedding.device
         if dev.type != "cuda":
             raise RuntimeError("the ViT-Lens towers run on the MI355X kernels only: move the model to a GPU")
-        key = (str(dev), tuple(p._version for p in self.parameters()), self.training)
+        key = (str(dev), self.training)
+        vers = {n: p._version for n, p in self.named_parameters()}
         if self._engine is None or key != self._engine_key:
             sd = {("t." + k): v for k, v in self.state_dict().items()}
             tower, lens = self._cfgs()
@@ -357,7 +361,18 @@ class VisionTransformer(nn.Module):
                 self._engine = E.VitEngine(sd, "t.", tower, dev)
             else:
                 self._engine = E.LensEngine(sd, "t.", tower, lens, dev)
-            self._engine_key = key
+            self._engine_key, self._engine_vers = key, vers
+        elif vers != self._engine_vers:
+            changed = [n for n, v in vers.items() if self._engine_vers.get(n) != v]
+            sd = {("t." + k): v for k, v in self.state_dict().items()}
+            if isinstance(self._engine, E.VitEngine):
+                self._engine.update_params(sd, changed)
+            else:
+                self._engine.update_params(sd, "t.", changed)
+            if self._trainer_obj is not None and self._trainer_key is not None and self._trainer_key[0] == id(self._engine):
+                from vitlens_hip.train import refresh_trainer
+                refresh_trainer(self._trainer_obj, sd, changed)
+            self._engine_vers = vers
         return self._engine
 
     # -------------------------------------------------------------------------------------- training (autograd)

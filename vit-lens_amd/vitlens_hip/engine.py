@@ -63,12 +63,27 @@ def prep_block(sd: Dict[str, torch.Tensor], p: str, device) -> Dict[str, torch.T
 
 
 def conv_weight_as_gemm(w: torch.Tensor, device, dtype=torch.bfloat16) -> torch.Tensor:
-    """Conv2d weight [O,C,kh,kw] -> [O, Kp] (K = C*kh*kw zero-padded to a multiple of 64), bf16 operand or f32 master."""
+    """Conv2d weight [O,C,kh,kw] -> [O, Kp] (K = C*kh*kw zero-padded to a multiple of 64), bf16 operand or f32 master.
+    Built where the weight lives (no host round trip for a parameter that is already on the GPU)."""
     O = w.shape[0]
     K = w[0].numel()
-    out = torch.zeros(O, _pad64(K), dtype=torch.float32)
-    out[:, :K] = w.detach().reshape(O, K).float().cpu()
+    out = torch.zeros(O, _pad64(K), dtype=torch.float32, device=w.device)
+    out[:, :K] = w.detach().reshape(O, K).float()
     return out.to(device=device, dtype=dtype).contiguous()
+
+
+def copy_tree(dst, src):
+    """dst <- src, in place, for every tensor of two identically shaped nests of dict / list / tuple.  The engines are
+    updated through this after an optimizer step: object identities (and with them the trainers' activation buffers and
+    every tensor another object holds a reference to) survive, only the trainable operands are re-derived."""
+    if torch.is_tensor(dst):
+        dst.copy_(src)
+    elif isinstance(dst, dict):
+        for k in dst:
+            copy_tree(dst[k], src[k])
+    else:
+        for d, s_ in zip(dst, src):
+            copy_tree(d, s_)
 
 
 class _Workspace:
@@ -118,6 +133,24 @@ class VitEngine:
         if prefix + "conv1.weight" in sd:
             self.conv_w = conv_weight_as_gemm(sd[prefix + "conv1.weight"], device)
         self._ws = {}
+
+    def update_params(self, sd, names):
+        """Re-derive, in place, the device operands of the parameters `names` (relative to this tower's prefix) from `sd`."""
+        p, dev = self.prefix, self.device
+        top = {n for n in names if not n.startswith("transformer.resblocks.")}
+        if "class_embedding" in top:
+            self.cls.copy_(sd[p + "class_embedding"])
+        if "positional_embedding" in top:
+            self.pos.copy_(sd[p + "positional_embedding"])
+        for nm, pair in (("ln_pre", self.ln_pre), ("ln_post", self.ln_post)):
+            if nm + ".weight" in top or nm + ".bias" in top:
+                pair[0].copy_(sd[p + nm + ".weight"]); pair[1].copy_(sd[p + nm + ".bias"])
+        if "proj" in top:
+            self.projT.copy_(sd[p + "proj"].t())
+        if "conv1.weight" in top and self.conv_w is not None:
+            self.conv_w.copy_(conv_weight_as_gemm(sd[p + "conv1.weight"], dev))
+        for l in sorted({int(n.split(".")[2]) for n in names if n.startswith("transformer.resblocks.")}):
+            copy_tree(self.blocks[l], prep_block(sd, f"{p}transformer.resblocks.{l}.", dev))
 
     def workspace(self, B, L):
         key = (B, L)
@@ -270,6 +303,12 @@ class PerceiverEngine:
             self.layers.append(lay)
         self._ws = {}
 
+    def update_params(self, sd, prefix: str):
+        """All Perceiver operands re-derived from `sd`, in place (the Perceiver is trainable as a whole in every recipe)."""
+        fresh = PerceiverEngine(sd, prefix, self.cfg, self.device, self.gemm_cfg)
+        self.latents.copy_(fresh.latents)
+        copy_tree(self.layers, fresh.layers)
+
     def _workspace(self, B, Tc):
         key = (B, Tc)
         if key in self._ws:
@@ -352,6 +391,28 @@ class LensEngine:
         else:
             raise NotImplementedError(lens.modality)
         self.perceiver = None if lens.perceiver_identity else PerceiverEngine(sd, prefix + "perceiver.", lens, device, gemm_cfg)
+
+    def update_params(self, sd, prefix: str, names):
+        """In-place refresh after the parameters `names` (relative to `prefix`) changed, e.g. by an optimizer step."""
+        L, a = self.lens, prefix + "visual_adapter."
+        self.vit.update_params(sd, [n for n in names if not n.startswith(("visual_adapter.", "perceiver."))])
+        if any(n.startswith("visual_adapter.") for n in names):
+            scale = 0.0 if L.disable_adapter_pos else 1.0
+            if L.modality in ("depth", "audio"):
+                self.conv_w.copy_(conv_weight_as_gemm(sd[a + "conv1.weight"], self.device))
+                self.adapter_pos.copy_(sd[a + "pos_emb"].detach().float() * scale)
+            elif L.modality == "eeg":
+                self.conv_w.copy_(conv_weight_as_gemm(sd[a + "proj.weight"].unsqueeze(2), self.device))
+                self.conv_b.copy_(sd[a + "proj.bias"])
+                self.adapter_pos.copy_(sd[a + "pos_emb"].detach().float() * scale)
+            elif L.modality == "pc":
+                if L.pc_tokenizer == "pnsa":
+                    self.points.load_params(sd)
+                else:
+                    from .points import PointTokenizerEngine
+                    self.points = PointTokenizerEngine(sd, a, L, self.device, gemm_cfg=self.gemm_cfg)
+        if self.perceiver is not None and any(n.startswith("perceiver.") for n in names):
+            self.perceiver.update_params(sd, prefix + "perceiver.")
 
     def tokens(self, x: torch.Tensor):
         """-> (tokens [B*T, C] bf16, pos table [T, C] f32 or per-sample pos [B*T, C], B)."""

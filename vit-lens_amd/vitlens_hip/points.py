@@ -26,11 +26,12 @@ def _padk(w, K=64):
 class PointTokenizerEngine:
     def __init__(self, sd, a: str, lens, device, gemm_cfg=-1, bn_training=False):
         if bn_training:
-            raise NotImplementedError("train-mode BatchNorm statistics for the point-cloud Lens (SURVEY §7 hard parts)")
+            raise NotImplementedError("the inference engine folds the running statistics; train-mode BatchNorm = PointTokenizerTrainer")
         self.lens, self.device, self.cfg = lens, torch.device(device), gemm_cfg
         f = lambda k: sd[a + k].detach().float().cpu()
-        w1, b1 = _fold_bn(f("encoder.first_conv.0.weight")[:, :, 0], f("encoder.first_conv.0.bias"), {k: v.cpu() for k, v in sd.items()}, a + "encoder.first_conv.1.")
-        w3, b3 = _fold_bn(f("encoder.second_conv.0.weight")[:, :, 0], f("encoder.second_conv.0.bias"), {k: v.cpu() for k, v in sd.items()}, a + "encoder.second_conv.1.")
+        bn_sd = {k: v.detach().cpu() for k, v in sd.items() if k.startswith((a + "encoder.first_conv.1.", a + "encoder.second_conv.1."))}
+        w1, b1 = _fold_bn(f("encoder.first_conv.0.weight")[:, :, 0], f("encoder.first_conv.0.bias"), bn_sd, a + "encoder.first_conv.1.")
+        w3, b3 = _fold_bn(f("encoder.second_conv.0.weight")[:, :, 0], f("encoder.second_conv.0.bias"), bn_sd, a + "encoder.second_conv.1.")
         half = w3.shape[1] // 2
         d = lambda t, dt=BF: t.to(device=device, dtype=dt).contiguous()
         self.w1, self.b1 = d(_padk(w1)), d(b1, torch.float32)
@@ -97,6 +98,14 @@ class PointTokenizerTrainer:
         self.op = {}
         self.refresh_operands()
         self.ctx = None
+
+    def load_params(self, sd):
+        """Masters and running statistics re-read from `sd` (reference names and shapes), in place; operands re-derived."""
+        for name, m in self.masters.items():
+            m.copy_(sd[name].detach().reshape(m.shape))
+        for k, (rm, rv) in self.running.items():
+            rm.copy_(sd[self.a + k + ".running_mean"]); rv.copy_(sd[self.a + k + ".running_var"])
+        self.refresh_operands()
 
     # bf16 GEMM operands (forward: W, backward: W^T) derived from the f32 masters
     def refresh_operands(self):

@@ -76,6 +76,14 @@ class TowerTrainer:
         self.grads: Dict[str, torch.Tensor] = {}
         self.ctx = None
 
+    def refresh_derived(self, blocks=(), proj=False):
+        """The engine's weights of `blocks` (and proj) were updated in place: redo their transposes."""
+        for l in blocks:
+            for k in ("in_w", "out_w", "fc_w", "proj_w"):
+                self.wT[l][k].copy_(self.eng.blocks[l][k].t())
+        if proj:
+            self.proj.copy_(self.eng.projT.t())
+
     # ------------------------------------------------------------------------------------------ helpers
     def saved(self, B, L):
         key = (B, L)
@@ -359,6 +367,19 @@ class PerceiverTrainer:
             self.wT.append(d)
         self._st = {}
 
+    def refresh_derived(self):
+        """The Perceiver engine's operands were updated in place: redo the transposes."""
+        for li, lay in enumerate(self.pe.layers):
+            if li >= 2 and lay is self.pe.layers[1]:
+                continue
+            d = self.wT[li]
+            d["x"]["q"].copy_(lay["x_attn"]["q_w"].t()); d["x"]["kv"].copy_(lay["x_attn"]["kv_w"].t())
+            d["x"]["out"].copy_(lay["x_attn"]["to_out_w"].t())
+            d["xff"]["w0"].copy_(lay["x_ff"]["w0"].t()); d["xff"]["w2"].copy_(lay["x_ff"]["w2"].t())
+            for ds, sl in zip(d["selfs"], lay["selfs"]):
+                ds["qkv"].copy_(sl["attn"]["qkv_w"].t()); ds["out"].copy_(sl["attn"]["to_out_w"].t())
+                ds["w0"].copy_(sl["ff"]["w0"].t()); ds["w2"].copy_(sl["ff"]["w2"].t())
+
     def grad_buffer(self, name, shape):
         g = self.grads.get(name)
         if g is None:
@@ -639,3 +660,18 @@ class PCLensTrainer:
 
     def backward(self, dfeat: torch.Tensor):
         self.tok.backward(self.perc.backward(self.tower.backward(dfeat)))
+
+
+def refresh_trainer(tr, sd, names):
+    """After the engine under trainer `tr` was updated in place for the parameters `names` (relative to the tower prefix):
+    refresh what the trainer derived from them - transposed weights, the point tokenizer's masters - keeping the trainer
+    and its activation buffers (a rebuild re-allocates tens of GB at ViT-L size)."""
+    tower = getattr(tr, "tower", None)
+    if tower is not None:
+        tower.refresh_derived({int(n.split(".")[2]) for n in names if n.startswith("transformer.resblocks.")}, "proj" in names)
+    perc = getattr(tr, "perc", None)
+    if perc is not None and any(n.startswith("perceiver.") for n in names):
+        perc.refresh_derived()
+    tok = getattr(tr, "tok", None)
+    if tok is not None and any(n.startswith("visual_adapter.") for n in names):
+        tok.load_params(sd)
