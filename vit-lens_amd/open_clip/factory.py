@@ -113,6 +113,7 @@ def tri_create_model(model_name: str, pretrained: Optional[str] = None, precisio
         v["visual_arch"] = getattr(args, "visual_arch", "perceiver_vit")
         v["exp_args"] = args
     model = TriCLIP(**cfg)
+    model.set_precision(precision)
     model.to(device=torch.device(device))
     if pretrained:
         if not os.path.exists(pretrained):

@@ -1,39 +1,26 @@
-"""Mean average precision accumulator (reference: open_clip/metrics/map.py:12-53): logits and multi-hot targets are
-collected per batch, gathered across ranks, squashed with a sigmoid and scored per class with scikit-learn's
-`average_precision_score` on the host, exactly as the reference does (AudioSet-style evaluation)."""
+"""Mean average precision accumulator (protocol and result keys of the reference's open_clip/metrics/map.py:12-53, the
+AudioSet-style multi-label evaluation): scores and multi-hot targets of every batch are collected, gathered across ranks,
+and each class is scored on the host by scikit-learn's `average_precision_score` over sigmoid(score)."""
 import numpy as np
 import torch
-import torch.distributed as dist
 
 from .base_metric import BaseMetric
-from ..utils import all_gather
 
 
 class MAP(BaseMetric):
-    def __init__(self):
-        super().__init__()
-
     def initialize(self):
-        self.logits, self.targets, self.ids = [], [], []
+        self._reset()
 
     def compute(self, ids, logits, targets):
-        self.ids.append(ids); self.logits.append(logits.float()); self.targets.append(targets.float())
+        self._push(ids=ids, score=logits.float(), target=targets.float())
 
     def merge_results(self, output_predict=False):
         from sklearn.metrics import average_precision_score
-        ids, preds, targets = torch.cat(self.ids, 0), torch.cat(self.logits, 0), torch.cat(self.targets, 0)
-        if dist.is_available() and dist.is_initialized():
-            ids, preds, targets = all_gather(ids), all_gather(preds), all_gather(targets)
-        preds = torch.sigmoid(preds).cpu().numpy()
-        if targets.ndim != preds.ndim:
-            if targets.size(0) == 1:
-                targets = targets.squeeze(0)
-            if targets.size(1) == 1:
-                targets = targets.squeeze(1)
-        targets = targets.cpu().numpy()
-        predict_results = {}
-        if output_predict:
-            for idx, pred in zip(ids.cpu().tolist(), preds.tolist()):
-                predict_results[idx] = pred
-        return {"map": np.mean(average_precision_score(targets, preds, average=None)), "map_cnt": len(targets),
-                "predict_results": predict_results}
+        ids, score, target = self._collected("ids"), self._collected("score"), self._collected("target")
+        prob = torch.sigmoid(score).cpu().numpy()
+        while target.dim() > prob.ndim:            # a stray singleton axis from the collate function
+            target = target.squeeze(0) if target.size(0) == 1 else target.squeeze(1)
+        truth = target.cpu().numpy()
+        per_class = average_precision_score(truth, prob, average=None)
+        return {"map": np.mean(per_class), "map_cnt": len(truth),
+                "predict_results": self._prediction_table(ids, prob.tolist(), output_predict)}

@@ -238,6 +238,7 @@ class VisionTransformer(nn.Module):
             for i in range(2, len(mods)):
                 mods[str(i)] = mods["1"]
         self.image_mean = self.image_std = None
+        self.res_dtype = torch.float32          # residual-stream dtype of the HIP towers; TriCLIP.set_precision maps `precision` to it
         self._engine = None
         self._engine_key, self._engine_vers = None, None
         self._trainer_obj, self._trainer_key, self._gen = None, None, 0
@@ -352,15 +353,15 @@ class VisionTransformer(nn.Module):
         dev = self.class_embedding.device
         if dev.type != "cuda":
             raise RuntimeError("the ViT-Lens towers run on the MI355X kernels only: move the model to a GPU")
-        key = (str(dev), self.training)
+        key = (str(dev), self.training, self.res_dtype)
         vers = {n: p._version for n, p in self.named_parameters()}
         if self._engine is None or key != self._engine_key:
             sd = {("t." + k): v for k, v in self.state_dict().items()}
             tower, lens = self._cfgs()
             if lens is None:
-                self._engine = E.VitEngine(sd, "t.", tower, dev)
+                self._engine = E.VitEngine(sd, "t.", tower, dev, res_dtype=self.res_dtype)
             else:
-                self._engine = E.LensEngine(sd, "t.", tower, lens, dev)
+                self._engine = E.LensEngine(sd, "t.", tower, lens, dev, res_dtype=self.res_dtype)
             self._engine_key, self._engine_vers = key, vers
         elif vers != self._engine_vers:
             changed = [n for n, v in vers.items() if self._engine_vers.get(n) != v]
@@ -560,6 +561,16 @@ class TriCLIP(nn.Module):
         self.register_buffer("attn_mask", mask, persistent=False)
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
         self._text_engine, self._text_key = None, None
+        self._res_dtype = torch.float32
+
+    def set_precision(self, precision: str):
+        """`precision` of tri_create_model (factory.py:164): the GEMMs always run bf16 x bf16 -> f32 (what the reference's
+        amp_bf16 autocast computes); "fp32" keeps the residual stream and its gradient in f32 (more precise than the
+        reference's autocast), "amp" / "amp_bf16" / "bf16" carry them in bf16 exactly as autocast does."""
+        dt = torch.float32 if precision == "fp32" else torch.bfloat16
+        self._res_dtype = self.image.res_dtype = self.visual.res_dtype = dt
+        self._text_engine = None
+        return self
 
     # ---- lock recipes (model.py:448-502) -------------------------------------------------------
     def lock_image_tower(self, unlocked_groups=0, freeze_bn_stats=False, unlock_cls=False, unlock_pos_emb=False):
@@ -587,14 +598,16 @@ class TriCLIP(nn.Module):
         dev = self.positional_embedding.device
         if dev.type != "cuda":
             raise RuntimeError("the ViT-Lens towers run on the MI355X kernels only: move the model to a GPU")
-        names = [n for n, _ in self.named_parameters() if not n.startswith(("image.", "visual."))]
-        key = (str(dev), tuple(dict(self.named_parameters())[n]._version for n in names))
+        # (logit_scale is not a text-tower operand: it changes every step and must not invalidate the frozen tower's engine)
+        prm = dict(self.named_parameters())
+        names = [n for n in prm if not n.startswith(("image.", "visual.")) and n != "logit_scale"]
+        key = (str(dev), self._res_dtype, tuple(prm[n]._version for n in names))
         if self._text_engine is None or key != self._text_key:
             sd = {k: v for k, v in self.state_dict().items() if not k.startswith(("image.", "visual."))}
             t = self.text_cfg
             self._text_engine = E.TextEngine(sd, E.TextCfg(context_length=t.context_length, vocab_size=t.vocab_size,
                                                            width=t.width, heads=t.heads, layers=t.layers,
-                                                           embed_dim=self.text_projection.shape[1]), dev)
+                                                           embed_dim=self.text_projection.shape[1]), dev, res_dtype=self._res_dtype)
             self._text_key = key
         return self._text_engine
 
