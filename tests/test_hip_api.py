@@ -219,6 +219,45 @@ def test_engine_and_trainer_survive_optimizer_steps(modality):
     assert worst < 1e-6, worst
 
 
+@pytest.mark.parametrize("modality", ["depth", "audio"])
+def test_grad_checkpointing_recomputes_the_same_gradients(modality):
+    """model.set_grad_checkpointing(True) (Transformer.forward, transformer.py:366-368): the trainer keeps only the block
+    inputs and re-runs each block's forward in front of its backward.  Same kernels on the same inputs: every gradient is
+    BIT-identical to the run that stored all activations, and the activation store is smaller."""
+    oc = _oc()
+    sd, ins, outs, grads, meta = split(load_npz(f"tiny_{modality}.npz"))
+    args = SimpleNamespace(**meta["args"])
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "tiny-lens.json"), "w") as f:
+            json.dump(meta["model_cfg"], f)
+        oc.add_model_config(td)
+        model = oc.tri_create_model("tiny-lens", None, precision="fp32", device="cuda", output_dict=True, args=args)
+    model.load_state_dict(sd, strict=False)
+    model.eval(); model.lock_image_tower(); model.lock_text_tower()
+    loss_fn = oc.create_loss(SimpleNamespace(local_loss=False, gather_with_grad=False, rank=0, world_size=1, horovod=False, n_tower=3,
+                                             use_dual_loss=False, cache_dir=None))
+    image, text, vx = ins["image"].cuda(), ins["text"].cuda(), ins["visual_x"].cuda()
+    res = []
+    for ckpt in (False, True):
+        model.set_grad_checkpointing(ckpt)
+        for p in model.parameters():
+            p.grad = None
+        loss = loss_fn(**model(image=image, text=text, visual_x=vx))
+        loss.backward()
+        tr = model.visual._trainer_obj
+        assert tr.tower.checkpoint is ckpt
+        S = next(iter(tr.tower._saved.values()))
+        nbytes = sum(t.numel() * t.element_size() for t in {id(t): t for t in S.X + S.qkv + S.a + S.u + S.lse}.values())
+        res.append((float(loss), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, nbytes))
+    assert res[0][0] == res[1][0]
+    assert set(res[0][1]) == set(res[1][1]) and len(res[0][1]) >= 20
+    assert all(torch.equal(res[0][1][k], res[1][1][k]) for k in res[0][1])
+    assert res[1][2] < 0.75 * res[0][2], (res[0][2], res[1][2])            # (two layers in the tiny tower; 24 at ViT-L: 11x)
+    ref = grads["visual.transformer.resblocks.0.mlp.c_fc.weight"]
+    g = res[1][1]["visual.transformer.resblocks.0.mlp.c_fc.weight"].float().cpu()
+    assert float((g - ref).norm() / ref.norm()) < 6e-2
+
+
 @pytest.mark.parametrize("groups,from_head", [(2, False), (1, False), (2, True)])
 def test_grouped_unlock_gradients(groups, from_head):
     """LiT-style grouped unlock (VisionTransformer.lock, transformer.py:564-597: [stem] + blocks + [last block, ln_post] +

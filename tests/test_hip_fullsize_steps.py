@@ -5,7 +5,11 @@ backward (first / last unlocked block, adapter, Perceiver, logit_scale) - plus p
 invariance of loss / gradients under the micro-batch split (different GEMM dispatch, same mathematics).
 
 Round 1 had these only at width 64; the tail-row residual bug (NaN loss at b = 256) was found by bench.py, not by a test.
-Tolerances: operands are bf16 through 24 blocks; gradients are compared by relative L2 (<= 8e-2) AND cosine (>= 0.995)."""
+Tolerances (round 3): per recipe, from the measured values (gpurun_out/r03_errs, the worst tensor of each run) plus ~50 %:
+  C3 f32 residual stream: rel. L2 2.7e-2 / cosine 0.99963 measured -> 4e-2 / 0.999;   C3 bf16 stream: 6.2e-2 / 0.99807 -> 9e-2 / 0.997;
+  C4: 2.3e-2 / 0.99978 -> 4e-2 / 0.999;   C5: 1.07e-1 / 0.99424 on EVERY tensor (the kNN / max-pool routing of the bf16
+  forward differs from the fp32 oracle's in a few groups, which shifts all downstream activations) -> 1.4e-1 / 0.992.
+  d loss / d logit_scale: relative, 3 % (measured 0.3 - 1.2 %); its well-conditioned check is the correlated-features test."""
 import math
 
 import pytest
@@ -70,8 +74,8 @@ def _check(step, ref_loss, ref_grads, loss, names, tol=8e-2, tag=None, cos_min=0
         assert g is not None, k
         e, c = relerr(g, ref), cosine(g, ref)
         errs[k] = [round(e, 5), round(c, 6)] if k != "logit_scale" else [float(g), float(ref)]
-        if k == "logit_scale":          # a scalar: difference of two nearly cancelling sums at random init -> absolute bound
-            if abs(float(g) - float(ref)) > 2e-3 + 0.1 * abs(float(ref)):       # (relative bound: the correlated-features test below)
+        if k == "logit_scale":          # a scalar; at random init a difference of nearly cancelling sums (|g| ~ 0.02 - 0.12)
+            if abs(float(g) - float(ref)) > 3e-2 * abs(float(ref)) + 2e-4:
                 bad[k] = (float(g), float(ref))
         elif e > (tol[k] if isinstance(tol, dict) else tol) or c < cos_min:
             bad[k] = (round(e, 4), round(c, 5))
@@ -102,8 +106,9 @@ def test_c3_depth_step_vitl_vs_oracle_autograd():
         st = ST.TriModalDepthStep(sd, E.TowerCfg(), E.TextCfg(), "cuda", micro_batch=2, unlock_first_n=4,
                                   train_res_dtype=res_dtype, frozen_res_dtype=res_dtype)
         loss = st.forward_backward(img.cuda(), txt.cuda(), dep.cuda())
-        _check(st, ref_loss, ref_grads, loss, names, tol=8e-2 if res_dtype == torch.float32 else 1.2e-1,
-               tag="c3_" + ("f32" if res_dtype == torch.float32 else "bf16"))
+        f32 = res_dtype == torch.float32
+        _check(st, ref_loss, ref_grads, loss, names, tol=4e-2 if f32 else 9e-2, cos_min=0.999 if f32 else 0.997,
+               tag="c3_" + ("f32" if f32 else "bf16"))
         del st
         torch.cuda.empty_cache()
 
@@ -137,9 +142,9 @@ def test_c3_logit_scale_gradient_at_a_non_degenerate_loss():
     loss = st.forward_backward(img.cuda(), txt.cuda(), dep.cuda())
     gs, rs = float(st.grads["logit_scale"]), float(ref_grads["logit_scale"])
     _record("c3_logit_scale", {"loss": [float(loss), ref_loss], "logit_scale": [gs, rs]})
-    assert ref_loss < math.log(B) + 0.5 * math.log(B), ref_loss          # the image<->depth pair is (nearly) solved
+    assert ref_loss < 2 * math.log(B) - 0.3, ref_loss          # clearly below the 2 ln B of uncorrelated features
     assert abs(float(loss) - ref_loss) < 3e-2
-    assert abs(rs) > 1e-2 and abs(gs - rs) < 5e-2 * abs(rs), (gs, rs)
+    assert abs(rs) > 0.1 and abs(gs - rs) < 1e-2 * abs(rs), (gs, rs)          # measured: -0.32931 vs -0.32937
 
 
 def test_c4_audio_step_vitl_vs_oracle_autograd():
@@ -165,7 +170,7 @@ def test_c4_audio_step_vitl_vs_oracle_autograd():
     st = ST.DualAudioStep(sd, E.TowerCfg(), E.TextCfg(), lc, "cuda", micro_batch=2)
     loss = st.forward_backward(aud.cuda(), txt.cuda())
     st.grads.update(st.trainers[0].perc.reference_named_grads())
-    _check(st, ref_loss, ref_grads, loss, names, tag="c4")
+    _check(st, ref_loss, ref_grads, loss, names, tol=4e-2, cos_min=0.999, tag="c4")
 
 
 def test_c5_pc_step_vitl_vs_oracle_autograd():
@@ -192,7 +197,7 @@ def test_c5_pc_step_vitl_vs_oracle_autograd():
     st = ST.TriModalPCStep(sd, E.TowerCfg(), E.TextCfg(), lc, "cuda", micro_batch=2, bn_training=False)
     loss = st.forward_backward(img.cuda(), txt.cuda(), pts.cuda(), start.cuda())
     st.grads.update(st.trainers[0].perc.reference_named_grads())
-    _check(st, ref_loss, ref_grads, loss, names, tol=1.2e-1, tag="c5")
+    _check(st, ref_loss, ref_grads, loss, names, tol=1.4e-1, cos_min=0.992, tag="c5")
 
 
 @pytest.mark.parametrize("res_dtype", [torch.bfloat16])

@@ -299,7 +299,9 @@ class VisionTransformer(nn.Module):
             p.requires_grad = True
 
     def set_grad_checkpointing(self, enable=True):
-        self.grad_checkpointing = enable
+        """Activation recompute for the transformer blocks (Transformer.forward, open_clip/transformer.py:366-368): the
+        trainer keeps only each block's input and re-runs the block's forward right before its backward."""
+        self.grad_checkpointing = bool(enable)
 
     def keep_last_layers(self, n_keep: int):
         """`model.visual.transformer.resblocks = resblocks[-n_keep:]` of --skip-trans-first-n-layers (factory.py:347-360):
@@ -382,7 +384,7 @@ class VisionTransformer(nn.Module):
         blocks = tuple(sorted({int(n.split(".")[2]) for n in req if n.startswith("transformer.resblocks.")}))
         return (blocks, "class_embedding" in req, "positional_embedding" in req, any(n.startswith("ln_pre.") for n in req),
                 any(n.startswith("ln_post.") for n in req), "proj" in req, "conv1.weight" in req,
-                self.training and not self._freeze_bn, self._bn_sync is not None)
+                self.training and not self._freeze_bn, self._bn_sync is not None, bool(getattr(self, "grad_checkpointing", False)))
 
     def _trainer(self):
         """Forward-with-saved-activations / backward executor for the current lock recipe (vitlens_hip.train), bound to
@@ -392,8 +394,9 @@ class VisionTransformer(nn.Module):
         flags = self._train_flags()
         key = (id(eng), flags)
         if self._trainer_obj is None or key != self._trainer_key:
-            blocks, cls, pos, lpre, lpost, proj, conv, bn_train, _ = flags
-            kw = dict(train_blocks=blocks, train_cls=cls, train_pos=pos, train_ln_pre=lpre, train_ln_post=lpost, train_proj=proj)
+            blocks, cls, pos, lpre, lpost, proj, conv, bn_train, _, ckpt = flags
+            kw = dict(train_blocks=blocks, train_cls=cls, train_pos=pos, train_ln_pre=lpre, train_ln_post=lpost, train_proj=proj,
+                      checkpoint=ckpt)
             if self.modality in ("image", "tactile"):
                 tr = T.ImageTowerTrainer(eng, kw, train_conv=conv)
             elif self.modality == "depth" and self.perceiver_identity:

@@ -257,8 +257,10 @@ class TriModalDepthStep(_StepState):
     def __init__(self, sd: Dict[str, torch.Tensor], tower: TowerCfg, text: TextCfg, device, micro_batch: int = 256,
                  unlock_first_n: int = 4, lr: float = 5e-4, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2,
                  rank: int = 0, world_size: int = 1, gemm_cfg: int = -1, comm=None, frozen_res_dtype=torch.float32,
-                 local_loss: bool = False, gather_with_grad: bool = False, train_res_dtype=torch.float32):
+                 local_loss: bool = False, gather_with_grad: bool = False, train_res_dtype=torch.float32,
+                 grad_checkpointing: bool = False):
         self.dev, self.mb, self.rank, self.world = torch.device(device), micro_batch, rank, world_size
+        self.grad_checkpointing = bool(grad_checkpointing)      # block recompute in the trainable tower (transformer.py:366-368)
         self.comm = comm or TorchComm()
         self.local_loss, self.gather_with_grad = local_loss, gather_with_grad
         self._base_sd = {k: v.detach() for k, v in sd.items()}
@@ -298,7 +300,7 @@ class TriModalDepthStep(_StepState):
     # -------------------------------------------------------------------------------------------
     def _trainer(self, i):
         while len(self.trainers) <= i:
-            t = DepthLensTrainer(self.lens, unlock_first_n=self.unlock_first_n)
+            t = DepthLensTrainer(self.lens, tower_kw=dict(train_blocks=range(self.unlock_first_n), checkpoint=self.grad_checkpointing))
             if self.trainers:                      # share weight transposes + gradient buffers across micro-batches
                 t.tower.wT = self.trainers[0].tower.wT
                 t.tower.proj = self.trainers[0].tower.proj

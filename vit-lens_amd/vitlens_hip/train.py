@@ -22,7 +22,10 @@ BF = torch.bfloat16
 class _Saved:
     """Per-(B, L) activation store: residual-stream snapshots and attention operands of every block."""
 
-    def __init__(self, B, L, D, H, hidden, layers, device, res_dtype=torch.float32, keep_blocks=()):
+    def __init__(self, B, L, D, H, hidden, layers, device, res_dtype=torch.float32, keep_blocks=(), checkpoint=False):
+        """checkpoint=True (set_grad_checkpointing, transformer.py:366-368): only the block INPUTS are kept per layer; every
+        other per-layer buffer is ONE tensor shared by all layers (the lists below repeat the same object), refilled by
+        re-running a block's forward right before its backward.  ViT-L at 256 samples: 3.4 GB instead of 36 GB."""
         dh = D // H
         T = B * L
         Lp = (L + 7) // 8 * 8
@@ -30,22 +33,36 @@ class _Saved:
         bf = lambda *s: torch.empty(*s, device=device, dtype=BF)
         self.Lp = Lp
         xres = f32 if res_dtype == torch.float32 else bf
-        self.X = [xres(T, D) for _ in range(2 * layers + 1)]          # X[2l]=block input, X[2l+1]=after attention
-        self.stats = [[f32(T) for _ in range(4)] for _ in range(layers)]   # mean1, rstd1, mean2, rstd2
+
+        def per_layer(make):
+            if not checkpoint:
+                return [make() for _ in range(layers)]
+            one = make()
+            return [one] * layers
+        mids = per_layer(lambda: xres(T, D))
+        self.X = [None] * (2 * layers + 1)                            # X[2l]=block input, X[2l+1]=after attention
+        for l in range(layers):
+            self.X[2 * l] = xres(T, D); self.X[2 * l + 1] = mids[l]
+        self.X[2 * layers] = xres(T, D)
+        self.stats = per_layer(lambda: [f32(T) for _ in range(4)])       # mean1, rstd1, mean2, rstd2
         # the packed in-projection output of every block; the attention kernels read q / k / v out of it in place
-        self.qkv = [bf(T, 3 * D) for _ in range(layers)]
+        self.qkv = per_layer(lambda: bf(T, 3 * D))
         hv = lambda m, i=0: ops.heads_view(m, B, L, H, dh, i * D)
         self.q = [hv(m, 0) for m in self.qkv]; self.k = [hv(m, 1) for m in self.qkv]; self.v = [hv(m, 2) for m in self.qkv]
-        self.a = [bf(T, D) for _ in range(layers)]
+        self.a = per_layer(lambda: bf(T, D))
         self.av = [hv(m) for m in self.a]
-        self.lse = [f32(B, H, L) for _ in range(layers)]
-        self.u = [bf(T, hidden) for _ in range(layers)]
+        self.lse = per_layer(lambda: f32(B, H, L))
+        self.u = per_layer(lambda: bf(T, hidden))
         # temporaries shared by all blocks
         self.h = bf(T, D); self.hid = bf(T, hidden)
         # trainable blocks keep their GEMM inputs (LN outputs, GELU output) for the weight gradients: 1.3 GB per block and
         # micro-batch at b = 256 instead of two LayerNorm passes and one GELU pass in the backward (HBM is 288 GB)
-        self.h1 = {l: bf(T, D) for l in keep_blocks}; self.h2 = {l: bf(T, D) for l in keep_blocks}
-        self.hidk = {l: bf(T, hidden) for l in keep_blocks}
+        if checkpoint and keep_blocks:
+            k1, k2, k3 = bf(T, D), bf(T, D), bf(T, hidden)
+            self.h1 = {l: k1 for l in keep_blocks}; self.h2 = {l: k2 for l in keep_blocks}; self.hidk = {l: k3 for l in keep_blocks}
+        else:
+            self.h1 = {l: bf(T, D) for l in keep_blocks}; self.h2 = {l: bf(T, D) for l in keep_blocks}
+            self.hidk = {l: bf(T, hidden) for l in keep_blocks}
         self.xpre = f32(T, D); self.pre_stats = [f32(T), f32(T)]
         self.post_stats = [f32(B), f32(B)]
         self.pooled = bf(B, D)
@@ -60,8 +77,9 @@ class _Saved:
 
 class TowerTrainer:
     def __init__(self, eng: VitEngine, train_blocks: Iterable[int] = (), train_cls=False, train_pos=False,
-                 param_prefix: str = "visual.", train_ln_pre=False, train_ln_post=False, train_proj=False):
+                 param_prefix: str = "visual.", train_ln_pre=False, train_ln_post=False, train_proj=False, checkpoint=False):
         self.eng, self.prefix = eng, param_prefix
+        self.checkpoint = bool(checkpoint)          # activation recompute per block (Transformer.forward, transformer.py:366-368)
         self.train_blocks = sorted(set(train_blocks))
         self.train_cls, self.train_pos = train_cls, train_pos
         # the stem / head pieces of the grouped (LiT) unlock, VisionTransformer.lock open_clip/transformer.py:564-597
@@ -89,7 +107,7 @@ class TowerTrainer:
         key = (B, L)
         if key not in self._saved:
             self._saved[key] = _Saved(B, L, self.D, self.H, self.hidden, self.layers, self.eng.device, self.eng.res_dtype,
-                                      keep_blocks=tuple(self.train_blocks))
+                                      keep_blocks=tuple(self.train_blocks), checkpoint=self.checkpoint)
         return self._saved[key]
 
     def grad_buffer(self, name, like):
@@ -115,22 +133,34 @@ class TowerTrainer:
         res_epi = ops.EPI_RES_F32 if e.res_dtype == torch.float32 else ops.EPI_RES_BF16
         ops.assemble_ln_pre(tokens, e.cls, e.pos, pos2, e.ln_pre[0], e.ln_pre[1], S.X[0], B, T, D,
                             xpre=S.xpre, mean=S.pre_stats[0], rstd=S.pre_stats[1])
-        for l, w in enumerate(e.blocks):
-            m1, r1, m2, r2 = S.stats[l]
-            h1, h2, hid = S.h1.get(l, S.h), S.h2.get(l, S.h), S.hidk.get(l, S.hid)
-            ops.layernorm(S.X[2 * l], w["ln1_w"], w["ln1_b"], h1, B * L, D, mean=m1, rstd=r1)
-            ops.gemm(h1, w["in_w"], w["in_b"], out=S.qkv[l], epi=ops.EPI_BF16, cfg=cfg)
-            ops.attn_fwd(S.q[l], S.k[l], S.v[l], S.a[l], lse=S.lse[l], qscale=dh ** -0.5 * ops.LOG2E)
-            ops.gemm(S.a[l], w["out_w"], w["out_b"], out=S.X[2 * l + 1], res=S.X[2 * l], epi=res_epi, cfg=cfg)
-            ops.layernorm(S.X[2 * l + 1], w["ln2_w"], w["ln2_b"], h2, B * L, D, mean=m2, rstd=r2)
-            ops.gemm(h2, w["fc_w"], w["fc_b"], out=hid, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg, out2=S.u[l])
-            ops.gemm(hid, w["proj_w"], w["proj_b"], out=S.X[2 * l + 2], res=S.X[2 * l + 1], epi=res_epi, cfg=cfg)
+        for l in range(self.layers):
+            self._block_forward(S, l, B, L)
         xl = S.X[2 * self.layers]
         ops.layernorm(xl, e.ln_post[0], e.ln_post[1], S.pooled, B, D, x_row_stride=L * D,
                       mean=S.post_stats[0], rstd=S.post_stats[1])
         feat = ops.gemm(S.pooled, e.projT, None, epi=ops.EPI_F32, cfg=cfg)
         self.ctx = (B, L, tokens, pos2 is not None)
         return feat
+
+    def _block_forward(self, S, l, B, L, write_out=True):
+        """One ResidualAttentionBlock forward (transformer.py:254-272) into the saved-activation slots of layer l.  With
+        write_out=False (the recompute in front of a block's backward) the block output X[2l+2] - already there from the
+        forward pass and not needed by the backward of block l - is not recomputed: the last GEMM is skipped."""
+        e, D, H = self.eng, self.D, self.H
+        dh = D // H
+        cfg = e.gemm_cfg
+        res_epi = ops.EPI_RES_F32 if e.res_dtype == torch.float32 else ops.EPI_RES_BF16
+        w = e.blocks[l]
+        m1, r1, m2, r2 = S.stats[l]
+        h1, h2, hid = S.h1.get(l, S.h), S.h2.get(l, S.h), S.hidk.get(l, S.hid)
+        ops.layernorm(S.X[2 * l], w["ln1_w"], w["ln1_b"], h1, B * L, D, mean=m1, rstd=r1)
+        ops.gemm(h1, w["in_w"], w["in_b"], out=S.qkv[l], epi=ops.EPI_BF16, cfg=cfg)
+        ops.attn_fwd(S.q[l], S.k[l], S.v[l], S.a[l], lse=S.lse[l], qscale=dh ** -0.5 * ops.LOG2E)
+        ops.gemm(S.a[l], w["out_w"], w["out_b"], out=S.X[2 * l + 1], res=S.X[2 * l], epi=res_epi, cfg=cfg)
+        ops.layernorm(S.X[2 * l + 1], w["ln2_w"], w["ln2_b"], h2, B * L, D, mean=m2, rstd=r2)
+        ops.gemm(h2, w["fc_w"], w["fc_b"], out=hid, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg, out2=S.u[l])
+        if write_out:
+            ops.gemm(hid, w["proj_w"], w["proj_b"], out=S.X[2 * l + 2], res=S.X[2 * l + 1], epi=res_epi, cfg=cfg)
 
     # ------------------------------------------------------------------------------------------ backward
     def _dw(self, name, dy, x, rows, bias_name=None):
@@ -175,6 +205,8 @@ class TowerTrainer:
         if f32_stream:
             ops.cast_bf16(S.dx, out=S.dxb)
         for l in reversed(range(self.layers)):
+            if self.checkpoint:          # refill the shared per-layer buffers with block l's activations
+                self._block_forward(S, l, B, L, write_out=False)
             w, wT = e.blocks[l], self.wT[l]
             m1, r1, m2, r2 = S.stats[l]
             trainable = l in self.train_blocks
