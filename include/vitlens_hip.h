@@ -193,6 +193,15 @@ int vl_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dO
 /* ---- point-cloud tokenizer (PointBERT grouping) ---- */
 /* farthest point sampling: xyz [B,N,3] f32, start [B] (the reference draws it with torch.randint, misc.py:60);
  * idx [B,G] int64 (bit-exact vs misc.fps), centers [B,G,3] optional. */
+/* ---- audio front end (csrc/vl_audio.hip) ----
+ * Kaldi-compatible log-mel filterbank = torchaudio.compliance.kaldi.fbank(htk_compat, 16 kHz, hanning window, 128 bins,
+ * no dither, 25 ms / 10 ms frames, snip_edges) + zero-padding / truncation to target_len rows + Normalize(mean, std), i.e.
+ * AudioASTProcessorEval.convert2fbank + transform (open_clip/modal_audio/processors/at_processor.py:839-873).
+ * wave [batch, n_samples] f32 (row stride wave_stride), window [win] f32, banks [nmel, nfft/2+1] f32 (host-built, device
+ * resident), out [batch, target_len, nmel] f32.  Parity unpinned: torchaudio is not available to check against. */
+int vl_kaldi_fbank(const float* wave, long wave_stride, int batch, long n_samples, const float* window, const float* banks,
+                   float* out, int target_len, int win, int shift, int nfft, int nmel, float preemph, float mean, float std,
+                   hipStream_t stream);
 int vl_fps(const float* xyz, const int64_t* start, int64_t* idx, float* centers, int B, int N, int G, hipStream_t stream);
 /* pc_norm after a gather (modal_3d/processors/pc_processor.py:32-38, PCProcessorEval :60-88): out [B,G,C] f32 =
  * (pts[b, idx[b,g], :] - centroid) / max distance from the centroid over the G selected points; idx NULL = all N points. */

@@ -303,6 +303,16 @@ class VisionTransformer(nn.Module):
         trainer keeps only each block's input and re-runs the block's forward right before its backward."""
         self.grad_checkpointing = bool(enable)
 
+    def drop_output_projection(self):
+        """`backbone.proj = None` (VitLens-OpenShape/src/models/clip_bind.py:38-41): the tower returns ln_post(cls) at
+        transformer width (transformer.py:783-784 `if self.proj is not None`); a wrapper applies its own projection."""
+        if "proj" in self._parameters:
+            del self._parameters["proj"]
+        self.proj = None
+        self.embed_dim = self.cfg.width
+        self._engine = self._engine_key = None
+        self._trainer_obj = self._trainer_key = None
+
     def keep_last_layers(self, n_keep: int):
         """`model.visual.transformer.resblocks = resblocks[-n_keep:]` of --skip-trans-first-n-layers (factory.py:347-360):
         the first blocks are dropped AFTER the checkpoint is loaded and the kept ones are renumbered from 0, as slicing

@@ -39,6 +39,7 @@ SIGNATURES = {
     "vl_ce_grad": [P, L, I, I, I, P, P, F, F, P, L, P, L, F, P, P, P],
     "vl_ce_grad_ws_floats": [I, I, L, L],
     "vl_gemm_bf16_ex": [P, P, P, P, P, P, I, I, I, I, I, I, F, I, I, I, I, P],
+    "vl_kaldi_fbank": [P, L, I, L, P, P, P, I, I, I, I, I, F, F, F, P],
     "vl_fps": [P, P, P, P, I, I, I, P],
     "vl_pc_gather_normalize": [P, P, P, I, I, I, I, P],
     "vl_resample_h_u8": [P, L, I, I, I, I, P, P, I, I, I, P, P],

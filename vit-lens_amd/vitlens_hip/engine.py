@@ -127,7 +127,9 @@ class VitEngine:
         self.T = self.pos.shape[0] - 1
         self.ln_pre = (_dev(sd[prefix + "ln_pre.weight"], device), _dev(sd[prefix + "ln_pre.bias"], device))
         self.ln_post = (_dev(sd[prefix + "ln_post.weight"], device), _dev(sd[prefix + "ln_post.bias"], device))
-        self.projT = _dev(sd[prefix + "proj"].t(), device, torch.bfloat16)          # [E, D]
+        # [E, D]; None = the tower has no output projection (`if self.proj is not None`, transformer.py:783-784;
+        # CLIPBindWrap drops it when the feature width differs, VitLens-OpenShape/src/models/clip_bind.py:35-47)
+        self.projT = _dev(sd[prefix + "proj"].t(), device, torch.bfloat16) if prefix + "proj" in sd else None
         self.blocks = [prep_block(sd, f"{prefix}transformer.resblocks.{i}.", device) for i in range(cfg.layers)]
         self.conv_w = None
         if prefix + "conv1.weight" in sd:
@@ -145,7 +147,7 @@ class VitEngine:
         for nm, pair in (("ln_pre", self.ln_pre), ("ln_post", self.ln_post)):
             if nm + ".weight" in top or nm + ".bias" in top:
                 pair[0].copy_(sd[p + nm + ".weight"]); pair[1].copy_(sd[p + nm + ".bias"])
-        if "proj" in top:
+        if "proj" in top and self.projT is not None:
             self.projT.copy_(sd[p + "proj"].t())
         if "conv1.weight" in top and self.conv_w is not None:
             self.conv_w.copy_(conv_weight_as_gemm(sd[p + "conv1.weight"], dev))
@@ -176,7 +178,11 @@ class VitEngine:
         ops.assemble_ln_pre(tokens, self.cls, pos, pos2, self.ln_pre[0], self.ln_pre[1], ws.x, B, T, D)
         run_blocks(self.blocks, ws, B, L, D, cfg.heads, causal=False, cfg=self.gemm_cfg)
         pooled = torch.empty(B, D, device=self.device, dtype=torch.bfloat16)
+        if self.projT is None:
+            pooled = torch.empty(B, D, device=self.device, dtype=torch.float32)
         ops.layernorm(ws.x, self.ln_post[0], self.ln_post[1], pooled, B, D, x_row_stride=L * D)
+        if self.projT is None:
+            return pooled
         return ops.gemm(pooled, self.projT, None, epi=ops.EPI_F32, cfg=self.gemm_cfg)
 
     def encode_image(self, image: torch.Tensor, normalize: bool = False) -> torch.Tensor:

@@ -89,7 +89,8 @@ class TowerTrainer:
         dev = eng.device
         # transposed bf16 weights for the dX GEMMs (C = dY . W  ==  NT GEMM against W^T)
         self.wT = [{k: w[k].t().contiguous() for k in ("in_w", "out_w", "fc_w", "proj_w")} for w in eng.blocks]
-        self.proj = eng.projT.t().contiguous()            # [D, E]: the NT "W" operand of dpooled = dfeat . proj^T
+        # [D, E]: the NT "W" operand of dpooled = dfeat . proj^T (None: a tower without output projection)
+        self.proj = eng.projT.t().contiguous() if eng.projT is not None else None
         self._saved = {}
         self.grads: Dict[str, torch.Tensor] = {}
         self.ctx = None
@@ -99,7 +100,7 @@ class TowerTrainer:
         for l in blocks:
             for k in ("in_w", "out_w", "fc_w", "proj_w"):
                 self.wT[l][k].copy_(self.eng.blocks[l][k].t())
-        if proj:
+        if proj and self.proj is not None:
             self.proj.copy_(self.eng.projT.t())
 
     # ------------------------------------------------------------------------------------------ helpers
@@ -138,7 +139,10 @@ class TowerTrainer:
         xl = S.X[2 * self.layers]
         ops.layernorm(xl, e.ln_post[0], e.ln_post[1], S.pooled, B, D, x_row_stride=L * D,
                       mean=S.post_stats[0], rstd=S.post_stats[1])
-        feat = ops.gemm(S.pooled, e.projT, None, epi=ops.EPI_F32, cfg=cfg)
+        if e.projT is None:          # features = ln_post(cls) itself (bf16 activation, returned as f32)
+            feat = S.pooled.float()
+        else:
+            feat = ops.gemm(S.pooled, e.projT, None, epi=ops.EPI_F32, cfg=cfg)
         self.ctx = (B, L, tokens, pos2 is not None)
         return feat
 
@@ -187,8 +191,8 @@ class TowerTrainer:
         P = self.prefix
         # feat = pooled @ proj ; pooled = ln_post(x[:, 0])
         dfb = ops.cast_bf16(dfeat.contiguous())
-        dpooled = ops.gemm(dfb, self.proj, None, epi=ops.EPI_BF16, cfg=cfg)   # [B, D]
-        if self.train_proj:          # feat = pooled @ proj  ->  dproj[D, E] += pooled^T dfeat
+        dpooled = dfb if self.proj is None else ops.gemm(dfb, self.proj, None, epi=ops.EPI_BF16, cfg=cfg)   # [B, D]
+        if self.train_proj and self.proj is not None:          # feat = pooled @ proj  ->  dproj[D, E] += pooled^T dfeat
             bp = (B + 63) // 64 * 64
             ops.gemm_dw(ops.transpose_to_bf16(S.pooled, ldo=bp), ops.transpose_to_bf16(dfb, ldo=bp),
                         self.grad_buffer(P + "proj", torch.empty(D, dfeat.shape[1])), cfg=cfg)
