@@ -141,14 +141,19 @@ class AudioProcessor(BaseProcessor):
             return None
         outs = []
         for a in wrap_list(audio_items):
-            if _is_path(a):
-                raise NotImplementedError("waveform files need torchaudio's kaldi fbank front end, which is not available "
-                                          "here: pass [n_clip, 512, 128] log-mel spectrogram tensors instead")
+            if _is_path(a) or (torch.is_tensor(a) and a.dim() <= 2 and a.shape[-1] != self.mel_bins):
+                # a .wav path or a raw waveform [n] / [1, n]: clips + Kaldi log-mel filterbank on the GPU (at_processor.py:823-903)
+                from open_clip.modal_audio.processors.at_processor import AudioASTProcessorEval
+                proc = AudioASTProcessorEval(sampling_rate=self.sampling_rate, clip_duration=self.clip_duration, n_clip=self.n_clip,
+                                             target_length=self.target_length, mel_bins=self.mel_bins,
+                                             device=device if str(device) != "cpu" else "cuda")
+                outs.append(proc(a))
+                continue
             a = torch.as_tensor(a, dtype=torch.float32)
             if a.shape[-2:] != (self.target_length, self.mel_bins):
                 raise ValueError(f"expected [.., {self.target_length}, {self.mel_bins}] spectrograms, got {tuple(a.shape)}")
             outs.append(a)
-        return torch.stack(outs, dim=0).to(device)
+        return torch.stack([o.to(device) for o in outs], dim=0)
 
 
 class TactileProcessor(BaseProcessor):
