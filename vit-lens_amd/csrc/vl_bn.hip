@@ -134,6 +134,38 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict_
   *(u32x4*)(out + r * ldo + c) = o;
 }
 
+// Column-stationary form of the same arithmetic (C/8 a divisor of 256): a thread keeps the coefficients of its 8 channels in
+// registers and walks down the rows (round 3: the thread-per-element form re-read 4-6 per-channel parameters per element
+// through L1 - 48 loads for 32 bytes of payload - and ran at an eighth of the HBM rate: 6.7 ms per call on the C5 step's
+// [2.1 M, 512] activations, profiles/r03_bench_c5_kernel_stats.csv).
+__global__ void __launch_bounds__(256) bn_apply_rows_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ mean,
+                                                            const float* __restrict__ var, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, int relu, bf16_t* __restrict__ out,
+                                                            long ldo, long R, int C) {
+  const int tpr = C >> 3, rpb = 256 / tpr;
+  const int c = (threadIdx.x % tpr) * 8;
+  float s[8], mu[8], b[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = gamma[c + e] * __builtin_amdgcn_rsqf(var[c + e] + eps); mu[e] = mean[c + e]; b[e] = beta[c + e]; }
+  for (long r = (long)blockIdx.x * rpb + threadIdx.x / tpr; r < R; r += (long)gridDim.x * rpb) {
+    const u32x4 v = *(const u32x4*)(x + r * ldx + c);
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float y[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float xv = bf2f((bf16_t)(h ? (v[k] >> 16) : (v[k] & 0xffff)));
+        float t = fmaf(xv - mu[2 * k + h], s[2 * k + h], b[2 * k + h]);
+        if (relu) t = fmaxf(t, 0.f);
+        y[h] = t;
+      }
+      o[k] = pack2bf(y[0], y[1]);
+    }
+    *(u32x4*)(out + r * ldo + c) = o;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ backward
 struct BnBwdP {
   const bf16_t* dy; long lddy; const bf16_t* x; long ldx;
@@ -223,6 +255,38 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnBwdP p) {
   *(u32x4*)(p.dx + r * p.lddx + c) = o;
 }
 
+// column-stationary form (see bn_apply_rows_kernel)
+__global__ void __launch_bounds__(256) bn_bwd_apply_rows_kernel(const BnBwdP p) {
+  const int tpr = p.C >> 3, rpb = 256 / tpr;
+  const int c = (threadIdx.x % tpr) * 8;
+  const float inv_n = p.total ? 1.0f / (float)*p.total : 1.0f;
+  float rs[8], mu[8], g[8], b[8], f1[8], f2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    rs[e] = __builtin_amdgcn_rsqf(p.var[c + e] + p.eps); mu[e] = p.mean[c + e]; g[e] = p.gamma[c + e]; b[e] = p.beta[c + e];
+    f1[e] = p.fin[c + e] * inv_n; f2[e] = p.fin[p.C + c + e] * inv_n;
+  }
+  for (long r = (long)blockIdx.x * rpb + threadIdx.x / tpr; r < p.R; r += (long)gridDim.x * rpb) {
+    const u32x4 xv = *(const u32x4*)(p.x + r * p.ldx + c);
+    const u32x4 dv = *(const u32x4*)(p.dy + r * p.lddy + c);
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float y[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = 2 * k + h;
+        const float xh = (bf2f((bf16_t)(h ? (xv[k] >> 16) : (xv[k] & 0xffff))) - mu[e]) * rs[e];
+        float d = bf2f((bf16_t)(h ? (dv[k] >> 16) : (dv[k] & 0xffff)));
+        if (p.relu && fmaf(xh, g[e], b[e]) <= 0.f) d = 0.f;
+        y[h] = g[e] * rs[e] * (d - f1[e] - xh * f2[e]);
+      }
+      o[k] = pack2bf(y[0], y[1]);
+    }
+    *(u32x4*)(p.dx + r * p.lddx + c) = o;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ group ops
 // thread per (group, column pair); lanes run along columns so every row access is coalesced
 __global__ void __launch_bounds__(256) group_max_bwd_kernel(const bf16_t* __restrict__ f, long ldf, const bf16_t* __restrict__ dg, long lddg,
@@ -269,6 +333,16 @@ __global__ void __launch_bounds__(256) group_sum_kernel(const bf16_t* __restrict
 }
 
 inline unsigned grid1(long n) { return (unsigned)((n + 255) / 256); }
+// the column-stationary apply kernels: C/8 threads per row must tile a 256-thread block
+inline bool rows_form_ok(int C) { const int tpr = C >> 3; return tpr >= 1 && tpr <= 256 && 256 % tpr == 0; }
+inline unsigned rows_grid(long R, int C) {
+  const long rpb = 256 / (C >> 3), blocks = (R + rpb - 1) / rpb;
+  return (unsigned)(blocks < 4096 ? blocks : 4096);          // 16 blocks per CU, each walking down the rows
+}
+inline void launch_bwd_apply(const BnBwdP& p, hipStream_t stream) {
+  if (rows_form_ok(p.C)) hipLaunchKernelGGL(bn_bwd_apply_rows_kernel, dim3(rows_grid(p.R, p.C)), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid1((long)p.R * (p.C >> 3))), dim3(256), 0, stream, p);
+}
 
 inline bool ws_shape_ok(int R, int nchunk) { return nchunk >= 1 && nchunk <= 65535 && R >= 1; }
 
@@ -288,8 +362,12 @@ extern "C" int vl_bn_stats(const void* x, long ldx, int R, int C, float* ws, int
 extern "C" int vl_bn_apply(const void* x, long ldx, const float* mean, const float* var, const float* gamma, const float* beta,
                            float eps, int relu, void* out, long ldo, long R, int C, hipStream_t stream) {
   if (R <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (ldo & 7)) return vl_set_error("vl_bn_apply: C, ldx, ldo must be multiples of 8");
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid1(R * (C >> 3))), dim3(256), 0, stream, (const bf16_t*)x, ldx, mean, var, gamma, beta, eps,
-                     relu, (bf16_t*)out, ldo, R, C);
+  if (rows_form_ok(C))
+    hipLaunchKernelGGL(bn_apply_rows_kernel, dim3(rows_grid(R, C)), dim3(256), 0, stream, (const bf16_t*)x, ldx, mean, var, gamma, beta,
+                       eps, relu, (bf16_t*)out, ldo, R, C);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid1(R * (C >> 3))), dim3(256), 0, stream, (const bf16_t*)x, ldx, mean, var, gamma, beta, eps,
+                       relu, (bf16_t*)out, ldo, R, C);
   VL_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -303,7 +381,7 @@ extern "C" int vl_bn_bwd(const void* dy, long lddy, const void* x, long ldx, con
            (R + nchunk - 1) / nchunk, dgamma, dbeta, (bf16_t*)dx, lddx, R, C, ws + (long)nchunk * 2 * C, nullptr, nullptr};
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((C + 127) / 128, nchunk), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, p);
-  if (dx) hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid1((long)R * (C >> 3))), dim3(256), 0, stream, p);
+  if (dx) launch_bwd_apply(p, stream);
   VL_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -346,7 +424,7 @@ extern "C" int vl_bn_bwd_apply(const void* dy, long lddy, const void* x, long ld
     return vl_set_error("vl_bn_bwd_apply: C and strides must be multiples of 8; sums, total and dx required");
   BnBwdP p{(const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean, var, gamma, beta, eps, relu, 1, nullptr, 0, 0, nullptr, nullptr,
            (bf16_t*)dx, lddx, R, C, sums, total, nullptr};
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid1((long)R * (C >> 3))), dim3(256), 0, stream, p);
+  launch_bwd_apply(p, stream);
   VL_HIP_OK(hipGetLastError());
   return 0;
 }

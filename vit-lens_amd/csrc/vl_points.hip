@@ -154,6 +154,87 @@ __global__ void __launch_bounds__(256) knn_group_kernel(const float* xyz, const 
   }
 }
 
+// Register form of knn_group_kernel for N = 64 * NPL points (round 3): a lane keeps its NPL sortable keys in VGPRs instead of
+// LDS, and the per-bit counts of the radix select are wave ballots + scalar popcounts (no LDS, no cross-lane shuffles; the
+// LDS form ran one 128 KB workgroup per CU and took 5.9 ms for 128 x 512 centres of 8192 points,
+// profiles/r03_bench_c5_kernel_stats.csv).  Same arithmetic, same selection order, same outputs.
+// wave-wide integer sum on the VALU: quad swaps, half-row / row mirrors (DPP), then the four rows through v_readlane
+__device__ __forceinline__ int wave_sum_int(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true); v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true); v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);
+  return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+}
+
+template <int NPL>
+__global__ void __launch_bounds__(256) knn_group_reg_kernel(const float* xyz, const int64_t* cidx, int G, int k, int* nidx,
+                                                            bf16_t* patches, int Kp) {
+  constexpr int N = NPL * 64;
+  const int lane = threadIdx.x & 63;
+  const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);        // global centre index b*G + g
+  const int b = (int)(w / G);
+  const float* P = xyz + (size_t)b * N * 3;
+  const int ci = (int)cidx[w];
+  const float cx = P[ci * 3], cy = P[ci * 3 + 1], cz = P[ci * 3 + 2];
+  float cc;
+  {
+#pragma clang fp contract(off)
+    cc = (cx * cx + cy * cy) + cz * cz;
+  }
+  auto dist_key = [&](int i) {
+    // no implicit contraction: the key is computed twice (radix select, selection pass) and must come out identical
+#pragma clang fp contract(off)
+    const float x = P[i * 3], y = P[i * 3 + 1], z = P[i * 3 + 2];
+    const float dot = __builtin_fmaf(cz, z, __builtin_fmaf(cy, y, cx * x));
+    const float pp = (x * x + y * y) + z * z;
+    return sort_key((-2.0f * dot + cc) + pp);                    // dist = -2ab; dist += |a|^2; dist += |b|^2
+  };
+  unsigned int key[NPL];
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    key[j] = dist_key(lane + j * 64);
+    if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);      // at most 16 points' loads in flight: the keys need the registers
+  }
+  // largest T with count(key < T) < k  ==  k-th smallest key
+  unsigned int T = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned int trial = T | (1u << bit);
+    int c = 0;                                               // per-lane count (compare + add-with-carry), one wave sum per bit
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) c += key[j] < trial;
+    if (wave_sum_int(c) < k) T = trial;
+  }
+  int nl = 0;
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) nl += key[j] < T;
+  int need_eq = k - wave_sum_int(nl);                        // ties at the k-th distance: lowest indices first
+  int base = 0;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // selection in index order: a ROLLED loop that recomputes each key from the (cache-resident) cloud - the same arithmetic,
+  // hence the same bits - instead of 128 unrolled ballot groups on the register array (which spilled 178 SGPRs)
+  for (int j = 0; j < NPL; ++j) {
+    const int i = lane + j * 64;
+    const unsigned int kj = dist_key(i);
+    const bool less = kj < T;
+    const bool eq = kj == T;
+    const unsigned long long bl = __ballot(less), be = __ballot(eq);
+    if ((bl | be) == 0ull) continue;                         // (wave-uniform) nothing of this slice is selected
+    const int eq_rank = __popcll(be & lt_mask);
+    const bool take_eq = eq && eq_rank < need_eq;
+    const unsigned long long bt = bl | __ballot(take_eq);
+    if (less || take_eq) {
+      const int slot = base + __popcll(bt & lt_mask);
+      if (nidx) nidx[w * k + slot] = i;
+      if (patches) {
+        bf16_t* o = patches + ((size_t)w * k + slot) * Kp;
+        o[0] = f2bf(__fsub_rn(P[i * 3], cx)); o[1] = f2bf(__fsub_rn(P[i * 3 + 1], cy)); o[2] = f2bf(__fsub_rn(P[i * 3 + 2], cz));
+        for (int e = 3; e < Kp; ++e) o[e] = 0;
+      }
+    }
+    base += __popcll(bt);
+    need_eq -= min(need_eq, __popcll(be));
+  }
+}
+
 // one wave per centre.  The distance is the reference's expression with the CPU's rounding (pinned on 10.24 M distances
 // against torch: the K = 3 matmul is an FMA chain x, y, z; the squared norms are plain sums; tests/test_oracle_pnsa.py).
 __global__ void __launch_bounds__(256) ball_group_kernel(const float* xyz, const float* feats, const int64_t* cidx, int N, int S,
@@ -302,6 +383,12 @@ extern "C" int vl_knn_group(const float* xyz, const int64_t* center_idx, int* ni
   if ((N & 63) || ((long)B * G) % 4) return vl_set_error("vl_knn_group: N must be a multiple of 64 and B*G of 4");
   if (patches && Kp < 3) return vl_set_error("vl_knn_group: Kp < 3");
   const dim3 grid((unsigned)(((long)B * G) / 4)), block(256);
+  switch (N) {       // keys in registers for the cloud sizes of the configs (8192: the Lens, 1024 / 2048: ablations, 256: the tests)
+#define VL_KNN_REG(NPLV) case NPLV * 64: hipLaunchKernelGGL(knn_group_reg_kernel<NPLV>, grid, block, 0, stream, xyz, center_idx, G, k, nidx, (bf16_t*)patches, Kp); VL_HIP_OK(hipGetLastError()); return 0;
+    VL_KNN_REG(4) VL_KNN_REG(16) VL_KNN_REG(32) VL_KNN_REG(128)
+#undef VL_KNN_REG
+    default: break;
+  }
   const size_t smem = (size_t)4 * N * sizeof(unsigned int);
   if (smem > 160 * 1024) return vl_set_error("vl_knn_group: at most 10240 points per cloud");
   static bool attr = false;
