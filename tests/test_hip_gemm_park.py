@@ -117,3 +117,37 @@ def test_auto_dispatch_width_1664(M):
     assert relerr(out2, res.float() + acc) < 4e-3
     if M % 256 == 0:
         assert torch.equal(out2, ops.gemm(a, w, bias, res=res, epi=ops.EPI_RES_BF16, cfg=10))
+
+
+@pytest.mark.parametrize("M,N,K", [(256 * 24, 2048, 1024), (256 * 5, 512, 512), (257 * 64, 1024, 512)])
+def test_geglu_and_dgeglu_epilogues_on_the_persistent_kernel(M, N, K):
+    """Perceiver feed-forward epilogues (perceiver.py:85-102) on the 256x256 persistent kernel (round 3; round 2 ran them on
+    the round-1 kernel at 600 TF/s): GEGLU = a * gelu(gate) over interleaved (a, gate) columns with the bf16 pre-activation
+    saved, DGEGLU = its backward from the saved pre-activation.  Against fp32 torch and against the round-1 kernel."""
+    ops = _ops()
+    a = rnd(M, K, seed=51).bfloat16().cuda(); w = rnd(N, K, seed=52, scale=K ** -0.5).bfloat16().cuda()
+    bias = rnd(N, seed=53).cuda()
+    acc = a.float() @ w.float().t() + bias
+    cfg = 8 if M % 256 == 0 else -1
+    hs = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    out = ops.gemm(a, w, bias, epi=ops.EPI_GEGLU, cfg=cfg, out2=hs)
+    assert out.shape == (M, N // 2) and bool(torch.isfinite(out).all())
+    assert relerr(hs, acc) < 4e-3
+    hf = hs.float()                                                           # the reference's autocast multiplies the bf16 halves
+    assert relerr(out, hf[:, 0::2] * torch.nn.functional.gelu(hf[:, 1::2])) < 4e-3
+    assert relerr(out, acc[:, 0::2] * torch.nn.functional.gelu(acc[:, 1::2])) < 8e-3
+    out_nosave = ops.gemm(a, w, bias, epi=ops.EPI_GEGLU, cfg=cfg)
+    assert torch.equal(out, out_nosave)
+    old = ops.gemm(a, w, bias, epi=ops.EPI_GEGLU, cfg=5)
+    assert relerr(out, old) < 8e-3
+    # backward: dy [M, N/2 ... here a fresh GEMM of width N] against h [M, 2N]
+    h = rnd(M, 2 * N, seed=54, scale=1.2).bfloat16().cuda()
+    dh = torch.full((M, 2 * N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ops.gemm(a, w, None, out=dh, res=h, epi=ops.EPI_DGEGLU, cfg=cfg)
+    dy = (a.float() @ w.float().t())
+    hf = h.float().requires_grad_(True)
+    (hf[:, 0::2] * torch.nn.functional.gelu(hf[:, 1::2]) * dy).sum().backward()
+    assert bool(torch.isfinite(dh).all()) and relerr(dh, hf.grad) < 6e-3
+    old = torch.empty_like(dh)
+    ops.gemm(a, w, None, out=old, res=h, epi=ops.EPI_DGEGLU, cfg=5)
+    assert relerr(dh, old) < 6e-3

@@ -48,6 +48,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     gemm_nt_pk_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool HAS_AUX = (EPI == EPI_RES_BF16 || EPI == EPI_DGELU);   // second operand of the output's shape
+  // GEGLU (Perceiver feed-forward, perceiver.py:85-102): rows of W interleaved (a_j, gate_j) -> out[M, N/2] = a * gelu(gate),
+  // optionally the bf16 pre-activation [M, N] to out2 (row stride 2 * ldo).  DGEGLU (its backward): acc = dy[M, N], res =
+  // the saved pre-activation h[M, 2N]: out[M, 2N] = (dy * gelu(g), dy * a * gelu'(g)) interleaved (ldo = row stride of h / out).
+  constexpr bool IS_GEGLU = (EPI == EPI_GEGLU), IS_DGEGLU = (EPI == EPI_DGEGLU);
   constexpr int NW = 8, NTL = 2, WTN = 64;   // 2 (M) x 4 (N) waves of 128 x 64
   constexpr int NU = 4;                      // 1 KB DMA units per operand per wave per k-step
   constexpr int NCH = 16;                    // output chunks per wave: chunk = 8 rows x 128 bytes = one store instruction
@@ -231,6 +235,24 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       const float* const bsrc = has_bias ? pe.bias : (const float*)pe.W;
       // destination of this lane's chunks
       unsigned char* const out_base = (unsigned char*)pe.out + ((size_t)mrow0 * pe.ldo + ncol0) * 2 + lo_out;
+      // GEGLU / DGEGLU lane offsets (other strides than the plain outputs)
+      [[maybe_unused]] const unsigned lo_half = (unsigned)((prow * pe.ldo + (lane & 7) * 4) * 2);        // GEGLU out: 4 values per lane
+      [[maybe_unused]] const unsigned lo_pre = (unsigned)((prow * 2 * pe.ldo + pcol) * 2);               // GEGLU out2: stride 2 * ldo
+      [[maybe_unused]] const unsigned lo_h = (unsigned)((prow * pe.ldo + (lane & 7) * 16) * 2);           // DGEGLU h / out: 16 values per lane
+      [[maybe_unused]] u32x4 hx[2][8];                                                                  // DGEGLU: h of row block i (double buffered)
+      [[maybe_unused]] const unsigned char* const hsrc = (const unsigned char*)pe.res + ((size_t)mrow0 * pe.ldo + 2 * ncol0) * 2 + lo_h;
+      [[maybe_unused]] auto load_h = [&](auto BI, auto II) {
+        constexpr int bi = decltype(BI)::value, ii = decltype(II)::value;
+        if constexpr (IS_DGEGLU && ii < 4) {
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) {
+            const unsigned char* src = hsrc + (size_t)((ii * 32 + pass * 8) * ldo2);
+            hx[bi][pass * 2] = *(const u32x4*)src;
+            hx[bi][pass * 2 + 1] = *(const u32x4*)(src + 16);
+          }
+        }
+      };
+      if constexpr (IS_DGEGLU) load_h(IC<0>{}, IC<0>{});
       if constexpr (EPI == EPI_F32) {
         // fp32 partial product of a k-slice: 32x32 blocks through the slab, 16-byte stores (8 lanes per 128-byte line)
         float* const fout = (float*)pe.out + (size_t)cur_sp * pe.split_stride + (size_t)mrow0 * pe.ldo + ncol0;
@@ -252,9 +274,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
           }
         }
-      } else
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      } else {
+      auto row_block = [&](auto II) {
+        constexpr int i = decltype(II)::value;
+        if constexpr (IS_DGEGLU) load_h(IC<(i + 1) & 1>{}, IC<i + 1>{});        // h of the next row block, under this block's work
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
 #pragma unroll
@@ -283,7 +306,37 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
           u32x4 w = *(const u32x4*)(slab + r * 128 + (((lane & 7) ^ (r & 7)) << 4));
           [[maybe_unused]] u32x4 rr;
           if constexpr (HAS_AUX) rr = aux[i * 4 + pass];
-          if constexpr (EPI == EPI_BF16 && ACT == 3) {
+          if constexpr (IS_GEGLU) {
+            // w = 4 (a, gate) pairs of the bf16 pre-activation (the reference's autocast multiplies the bf16 halves too)
+            const size_t rowoff = (size_t)(mrow0 + i * 32 + pass * 8);
+            if (pe.out2)
+              __builtin_nontemporal_store(w, (u32x4*)((unsigned char*)pe.out2 + (rowoff * 2 * pe.ldo + ncol0) * 2 + lo_pre));
+            u32x2 o;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+              o[e] = pack2bf(bf2f((bf16_t)(w[2 * e] & 0xffff)) * gelu_erf(bf2f((bf16_t)(w[2 * e] >> 16))),
+                             bf2f((bf16_t)(w[2 * e + 1] & 0xffff)) * gelu_erf(bf2f((bf16_t)(w[2 * e + 1] >> 16))));
+            __builtin_nontemporal_store(o, (u32x2*)((unsigned char*)pe.out + (rowoff * pe.ldo + (ncol0 >> 1)) * 2 + lo_half));
+            continue;
+          } else if constexpr (IS_DGEGLU) {
+            // w = dy of 8 hidden columns (bf16); hx = their 8 (a, gate) pairs -> 8 (d a, d gate) pairs
+            u32x4 o2[2];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              const unsigned hv = hx[i & 1][pass * 2 + (c >> 2)][c & 3];
+              const float dy = bf2f((bf16_t)((c & 1) ? (w[c >> 1] >> 16) : (w[c >> 1] & 0xffff)));
+              const float a = bf2f((bf16_t)(hv & 0xffff)), g = bf2f((bf16_t)(hv >> 16));
+              const GeluParts gp = gelu_parts(g);
+              const float ge = fmaf(-(fabsf(g) * gp.q), gp.e, fmaxf(g, 0.0f));
+              const float step = (__builtin_bit_cast(int, g) >= 0) ? 1.0f : 0.0f;
+              const float gd = fmaf(gp.e, fmaf(0.3989422804014327f, g, -copysignf(gp.q, g)), step);
+              o2[c >> 2][c & 3] = pack2bf(dy * ge, dy * a * gd);
+            }
+            unsigned char* dst = (unsigned char*)pe.out + ((size_t)(mrow0 + i * 32 + pass * 8) * pe.ldo + 2 * ncol0) * 2 + lo_h;
+            __builtin_nontemporal_store(o2[0], (u32x4*)dst);
+            __builtin_nontemporal_store(o2[1], (u32x4*)(dst + 16));
+            continue;
+          } else if constexpr (EPI == EPI_BF16 && ACT == 3) {
             __builtin_nontemporal_store(w, (u32x4*)((unsigned char*)pe.out2 + ((size_t)(mrow0 + i * 32 + pass * 8) * pe.ldo + ncol0) * 2 + lo_out));
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -303,6 +356,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
           }
           __builtin_nontemporal_store(w, (u32x4*)(out_base + (size_t)((i * 32 + pass * 8) * ldo2)));
         }
+      };
+      row_block(IC<0>{}); row_block(IC<1>{}); row_block(IC<2>{}); row_block(IC<3>{});
       }
       zero_acc();
       if (ti + 1 < my_tiles) { tile_origin(ti + 1, cur_m0, cur_n0, cur_sp); ldfrag(smem + par * PK_STAGE, 0, 0); }
@@ -333,7 +388,9 @@ bool vl_gemm_park_supported(int epi, const void* params) {
     if (p.ksplit_len < 2 || nk % p.ksplit_len) return false;
     return !((((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.out) & 15));
   }
-  if (!(epi == EPI_BF16 || epi == EPI_RES_BF16 || epi == EPI_DGELU)) return false;
+  if (!(epi == EPI_BF16 || epi == EPI_RES_BF16 || epi == EPI_DGELU || epi == EPI_GEGLU || epi == EPI_DGEGLU)) return false;
+  if (epi == EPI_GEGLU && p.act != 0) return false;
+  if (epi == EPI_DGEGLU && (p.bias || !p.res)) return false;
   // whole tiles; the DMA prologue issues two k-steps of tile 0 up front
   if ((p.M & 255) || (p.N & 255) || (p.K & 63) || p.K < 512 || p.M <= 0 || p.N <= 0) return false;
   if (p.res_div != 1) return false;
@@ -354,6 +411,8 @@ int vl_gemm_park_launch(int epi, const void* params, int ncu, hipStream_t s) {
       return p.act == 2 ? (int)launch_pk<EPI_BF16, 2>(p, ncu, s) : (int)launch_pk<EPI_BF16, 0>(p, ncu, s);
     case EPI_RES_BF16: return (int)launch_pk<EPI_RES_BF16, 0>(p, ncu, s);
     case EPI_DGELU: return (int)launch_pk<EPI_DGELU, 0>(p, ncu, s);
+    case EPI_GEGLU: return (int)launch_pk<EPI_GEGLU, 0>(p, ncu, s);
+    case EPI_DGEGLU: return (int)launch_pk<EPI_DGEGLU, 0>(p, ncu, s);
     case EPI_F32: return (int)launch_pk<EPI_F32, 0>(p, ncu, s);
     default: return (int)hipErrorInvalidValue;
   }
