@@ -151,3 +151,31 @@ def test_geglu_and_dgeglu_epilogues_on_the_persistent_kernel(M, N, K):
     old = torch.empty_like(dh)
     ops.gemm(a, w, None, out=old, res=h, epi=ops.EPI_DGEGLU, cfg=5)
     assert relerr(dh, old) < 6e-3
+
+
+def test_many_tiles_no_sporadic_epilogue_faults(pcfg):
+    """Round-3 finding (profiles/r03_pk_fma_fault.log): a compiler-chosen v_pk_fma_f32 form in the epilogue dropped the
+    accumulator in the last 16 lanes of a wave a few times per launch - only with many tiles per workgroup, at different
+    places in every run, invisible to a single small case.  16 tiles per workgroup, every element checked, four launches of
+    each epilogue family; results must also be bit-identical from launch to launch."""
+    ops = _ops()
+    M, N, K = 65536, 4096, 1024
+    a = rnd(M, K, seed=61).bfloat16().cuda(); w = rnd(N, K, seed=62, scale=K ** -0.5).bfloat16().cuda()
+    bias = rnd(N, seed=63).cuda()
+    acc = a.float() @ w.float().t() + bias
+    res = rnd(M, N, seed=64).bfloat16().cuda()
+
+    def bad(out, ref):
+        return int(((out.float() - ref).abs() > ref.abs() * 2.0 ** -6 + 2e-2).sum())
+    first = {}
+    for rep in range(4):
+        outs = {"plain": ops.gemm(a, w, bias, epi=ops.EPI_BF16, cfg=pcfg),
+                "gelu": ops.gemm(a, w, bias, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=pcfg),
+                "res": ops.gemm(a, w, bias, res=res, epi=ops.EPI_RES_BF16, cfg=pcfg)}
+        refs = {"plain": acc, "gelu": torch.nn.functional.gelu(acc), "res": res.float() + acc}
+        for k, o in outs.items():
+            assert bad(o, refs[k]) == 0, (k, rep, bad(o, refs[k]))
+            if rep == 0:
+                first[k] = o.clone()
+            else:
+                assert torch.equal(o, first[k]), (k, rep)

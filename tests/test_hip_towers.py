@@ -157,3 +157,27 @@ def test_bench_geometry_tail_rows_match_small_batch(res_dtype):
     assert relerr(full[:4], first) < tol, relerr(full[:4], first)
     cs = torch.nn.functional.cosine_similarity(full[-4:].float(), small.float(), dim=-1)
     assert float((1 - cs).max()) < 1e-4
+
+
+def test_vit_bigG_14_image_tower_full_geometry():
+    """ViT-bigG-14 at its real size (model_configs/ViT-bigG-14.json: width 1664 = 13 x 128, 48 layers, 16 heads of 104, MLP 8192,
+    embed 1280; the OpenShape flavour's backbone), seeded random weights: features of 4 images against the
+    oracle, then a batch of 64 (M = 16 448 token rows: N = 1664 / 4992 reach the persistent 256x128-tile kernel, the head
+    dim runs zero-padded to 128) against the small-batch run of the same images."""
+    from vitlens_hip import engine
+    spec = O.TowerSpec(width=1664, layers=48, heads=16, mlp_ratio=4.9231, patch=14, image_size=224, embed_dim=1280)
+    g = torch.Generator().manual_seed(3)
+    sd = O.init_tower(spec, g, "image.")
+    image = torch.randn(64, 3, 224, 224, generator=g)
+    torch.set_num_threads(max(1, min(64, torch.get_num_threads())))
+    ref = O.encode_image(sd, image[:4], spec, normalize=True)
+    eng = engine.VitEngine(sd, "image.", engine.TowerCfg(width=1664, layers=48, heads=16, mlp_ratio=4.9231, embed_dim=1280), "cuda",
+                           res_dtype=torch.float32)
+    small = eng.encode_image(image[:4].cuda(), normalize=True).float().cpu()
+    assert small.shape == (4, 1280)
+    assert float((small @ small.t() - ref @ ref.t()).abs().max()) < 1e-3
+    assert float((1 - torch.nn.functional.cosine_similarity(small, ref, dim=-1)).max()) < 1e-3
+    big = eng.encode_image(image.cuda(), normalize=True).float().cpu()
+    assert bool(torch.isfinite(big).all())
+    assert float((1 - torch.nn.functional.cosine_similarity(big[:4], small, dim=-1)).max()) < 2e-4
+    assert float((big @ big.t())[:4, :4].sub(ref @ ref.t()).abs().max()) < 1e-3

@@ -39,6 +39,23 @@ struct GemmP {
   int pp_delay;
 };
 
+// acc * alpha + bias as four plain v_fma_f32.  Left to the compiler, the vector expression becomes v_pk_fma_f32, and in
+// one of the two operand orders hipcc picks (accumulator pair as src0, the (ldo, alpha) pair as src1 with op_sel:[0,1,0])
+// the LOW half of the result came out as if the accumulator were zero in lanes 48-63, on the last row block of a tile, a
+// few times per launch (100-2000 of 268 M elements; the other order, which round 2 happened to get, never did).  Found in
+// round 3 by tests/test_hip_gemm_park.py after an unrelated refactor flipped the operand order; evidence and the bisection
+// in profiles/r03_pk_fma_fault.log.  Plain FMAs were clean in every run and cost two more VALU issues per eight values.
+__device__ __forceinline__ f32x4 scale_bias(f32x4 v, float alpha, f32x4 b) {
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float t;
+    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(v[e]), "v"(alpha), "v"(b[e]));
+    r[e] = t;
+  }
+  return r;
+}
+
 template <int BM, int BN>
 struct Smem {
   static constexpr int A_BYTES = BM * 128;

@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               f32x4 v = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
-              *(f32x4*)(slab + fr * 128 + (((q * 2 + fg) ^ wsw) << 4)) = v * pe.alpha;
+              *(f32x4*)(slab + fr * 128 + (((q * 2 + fg) ^ wsw) << 4)) = scale_bias(v, pe.alpha, f32x4{0.f, 0.f, 0.f, 0.f});
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             f32x4 bv = *(const f32x4*)(bsrc + n);
 #pragma unroll
             for (int e = 0; e < 4; ++e) bv[e] = has_bias ? bv[e] : 0.f;
-            v = v * pe.alpha + bv;
+            v = scale_bias(v, pe.alpha, bv);
             if constexpr (EPI == EPI_BF16 && ACT == 1) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
