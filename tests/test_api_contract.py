@@ -139,7 +139,7 @@ def test_vitlens_checkpoint_roundtrip_and_reference_format(monkeypatch, tmp_path
                 a.vitlens["text"].positional_embedding.shape[1] and "visual" in k]
     torch.manual_seed(1)
     b = _tiny_vitlens(monkeypatch, mods)
-    assert not torch.equal(a.vitlens["depth"].visual.class_embedding, b.vitlens["depth"].visual.class_embedding)
+    assert not torch.equal(a.vitlens["depth"].class_embedding, b.vitlens["depth"].class_embedding)
     missing, unexpected = b.load_checkpoint(path)
     assert not missing and not unexpected
     sa, sb = a.state_dict(), b.state_dict()
@@ -164,7 +164,7 @@ def test_vitlens_checkpoint_roundtrip_and_reference_format(monkeypatch, tmp_path
     c = _tiny_vitlens(monkeypatch, ["image", "text", "depth"])
     missing, unexpected = c.load_checkpoint(path)
     assert not missing and not unexpected
-    assert torch.equal(c.vitlens["depth"].visual.visual_adapter.conv1.weight, sd["visual.visual_adapter.conv1.weight"])
+    assert torch.equal(c.vitlens["depth"].visual_adapter.conv1.weight, sd["visual.visual_adapter.conv1.weight"])
     assert torch.equal(c.vitlens["image"].image.conv1.weight, sd["image.conv1.weight"])
     assert torch.equal(c.vitlens["text"].token_embedding.weight, sd["token_embedding.weight"])
     # training checkpoint -> one modality (load_modality_from_pt_ckpt)
@@ -172,7 +172,7 @@ def test_vitlens_checkpoint_roundtrip_and_reference_format(monkeypatch, tmp_path
     torch.manual_seed(2)
     d = _tiny_vitlens(monkeypatch, ["depth"])
     d.load_modality_from_pt_ckpt("depth", path)
-    assert torch.equal(d.vitlens["depth"].visual.positional_embedding, sd["visual.positional_embedding"])
+    assert torch.equal(d.vitlens["depth"].positional_embedding, sd["visual.positional_embedding"])
 
 
 def test_list_models_natural_order_and_pos_embed_resize():

@@ -296,9 +296,10 @@ def test_grouped_unlock_gradients(groups, from_head):
             assert p.grad is None, n
 
 
-def test_forward_without_no_grad_refuses_an_untrainable_tower():
-    """A tower whose parameters require grad but whose backward is not implemented must not silently produce graph-less
-    features (round-1 finding): the text tower raises; under no_grad / after lock_text_tower it runs."""
+def test_forward_without_no_grad_says_the_text_tower_is_inference_only():
+    """A tower whose parameters require grad but whose backward is not implemented must not SILENTLY produce graph-less
+    features (round-1 finding), and a freshly created model must still encode text (round-2 advice): the text tower warns
+    once and returns detached features; under no_grad / after lock_text_tower it is silent."""
     oc = _oc()
     case = load_npz("tiny_depth.npz")
     sd, ins, outs, grads, meta = split(case)
@@ -307,13 +308,18 @@ def test_forward_without_no_grad_refuses_an_untrainable_tower():
             json.dump(meta["model_cfg"], f)
         oc.add_model_config(td)
         model = oc.tri_create_model("tiny-lens", None, device="cuda", output_dict=True, args=SimpleNamespace(**meta["args"]))
-    with pytest.raises(NotImplementedError):
+    import warnings
+    with pytest.warns(UserWarning, match="inference-only"):
+        f0 = model.encode_text(ins["text"].cuda())
+    assert not f0.requires_grad
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                     # said once; silent under no_grad and after locking
         model.encode_text(ins["text"].cuda())
-    with torch.no_grad():
-        model.encode_text(ins["text"].cuda())
-    model.lock_text_tower()
-    f = model.encode_text(ins["text"].cuda())
-    assert not f.requires_grad
+        with torch.no_grad():
+            model.encode_text(ins["text"].cuda())
+        model.lock_text_tower()
+        f = model.encode_text(ins["text"].cuda())
+    assert not f.requires_grad and torch.equal(f, f0)
 
 
 def test_skip_trans_first_n_layers_through_factory():
@@ -366,7 +372,8 @@ def test_vitlens_encode_api_at_full_size():
     ref = O.encode_image(sd, image, O.TowerSpec(), normalize=True)
     cs = torch.nn.functional.cosine_similarity(out[ModalityType.IMAGE].float().cpu(), ref, dim=-1)
     assert float((1 - cs).max()) < 1e-3
-    sdd = {k: v.detach().float().cpu() for k, v in vl.vitlens[ModalityType.DEPTH].state_dict().items()}
+    assert not hasattr(vl.vitlens[ModalityType.DEPTH], "image")          # only the modality's visual tower is kept (vitlens.py:100-107)
+    sdd = {"visual." + k: v.detach().float().cpu() for k, v in vl.vitlens[ModalityType.DEPTH].state_dict().items()}
     refd = O.encode_visual(sdd, depth, O.TowerSpec(), O.LensSpec(modality="depth", perceiver_identity=True), normalize=True)
     cs = torch.nn.functional.cosine_similarity(out[ModalityType.DEPTH].float().cpu(), refd, dim=-1)
     assert float((1 - cs).max()) < 1e-3

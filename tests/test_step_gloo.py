@@ -159,7 +159,7 @@ def _worker(rank, world, port, recipe, local_loss, gwg, ret):
             st.masters[f"visual.transformer.resblocks.{l}.mlp.c_fc.weight"] = torch.zeros(3, 5)
         st.masters["visual.W"] = Wv.clone()
         st.bf16_targets, st.trainers, st.flat_grad, st.grads = {}, [], None, {}
-        st._pending, st._reduced_upto = [], None
+        st._pending, st._reduced_upto, st._reduce_done = [], None, False
         st.opt = TR.AdamW(st.masters, lr=1e-2)
         st._trainer = lambda i: st.trainers[i] if i < len(st.trainers) else (st.trainers.append(
             _LinearTower(st.masters["visual.W"], st.grads, "visual.W", nblk)) or st.trainers[i])
@@ -179,8 +179,15 @@ def _worker(rank, world, port, recipe, local_loss, gwg, ret):
         st._refresh_operands = lambda: None
         loss = st.forward_backward(mine["vis"], mine["txt"])
         k = 2
-    grads_local = {n: v.clone() for n, v in st.grads.items()}
+    # between forward_backward and optimizer_step the buffer is mixed (block buckets summed, the rest rank-local):
+    # `finish_reduce()` / `reduced_grads()` is the accessor that makes it one state; idempotent (counted below: every
+    # element is reduced exactly once although it is called twice and optimizer_step calls it again)
+    st.finish_reduce()
+    summed = {n: v.clone() for n, v in st.reduced_grads().items()}
     st.optimizer_step()
+    for n, v in summed.items():
+        if not torch.equal(v, st.grads[n]):
+            errs.append(f"optimizer_step reduced {n} again after finish_reduce()")
     # ---- collective sequence ----
     ops_seen = [e[0] for e in comm.log]
     if ops_seen.count("all_gather") != 1 or comm.log[[e[0] for e in comm.log].index("all_gather")][1] != (b, k * E_DIM):

@@ -34,8 +34,13 @@ class ViTLens(nn.Module):
                     base = tri_create_model(cfg.model, None, device=self._dev, args=cfg)
                 self.vitlens[m] = base
             elif m in (ModalityType.DEPTH, ModalityType.AUDIO, ModalityType.PC, ModalityType.TACTILE, ModalityType.EEG):
+                # only the modality's `visual` tower is kept, as in the reference (`self.vitlens.add_module(modality,
+                # model.visual); del model`, vitlens.py:100-107): the model's own image / text towers would be 1.7 GB of unused,
+                # randomly initialised fp32 parameters per modality
                 cfg = fetch_model_cfg(modality=m, model_option=model_var)
-                self.vitlens[m] = tri_create_model(cfg.model, None, device=self._dev, args=cfg)
+                full = tri_create_model(cfg.model, None, device="cpu", args=cfg)
+                self.vitlens[m] = full.visual.to(self._dev)
+                del full
             else:
                 raise NotImplementedError(f"modality {m!r} is outside the hot path (SURVEY §8)")
         if load_from_ckpt is not None:
@@ -57,7 +62,7 @@ class ViTLens(nn.Module):
             return model.image, None
         if m == ModalityType.TEXT:
             return model, lambda k: k.startswith(self._TEXT_KEYS) or k in ("positional_embedding", "text_projection")
-        return model.visual, None
+        return model, None            # the modality's visual tower itself
 
     def state_dict(self, *args, **kwargs):
         out = {}
@@ -107,7 +112,7 @@ class ViTLens(nn.Module):
         sd = ckpt.get("state_dict", ckpt)
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
         sd = {k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}
-        return self.vitlens[modality].visual.load_state_dict(sd, strict=False)
+        return self.vitlens[modality].load_state_dict(sd, strict=False)
 
     def export_checkpoint(self, save_path="model_release/vitlens.pt"):
         torch.save(dict(model_var=self.model_var, modality_loaded=self.modality_loaded, state_dict=self.state_dict()), save_path)
@@ -139,10 +144,10 @@ class ViTLens(nn.Module):
                 f = model.encode_image(x.to(self._dev), normalize=False)
             elif self.reduce_list(m) and x.ndim == 4:
                 B, S = x.shape[:2]
-                f = model.encode_visual(x.reshape(B * S, *x.shape[2:]).to(self._dev), normalize=False)
+                f = model(x.reshape(B * S, *x.shape[2:]).to(self._dev))
                 f = f.reshape(B, S, -1).mean(dim=1).contiguous()
             else:
-                f = model.encode_visual(x.to(self._dev), normalize=False)
+                f = model(x.to(self._dev))
             if normalize:
                 from vitlens_hip import ops
                 f = ops.l2_normalize(f.contiguous().float())

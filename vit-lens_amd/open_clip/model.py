@@ -639,12 +639,17 @@ class TriCLIP(nn.Module):
         return _normalize(features) if normalize else features
 
     def encode_text(self, text, normalize: bool = False):
-        if torch.is_grad_enabled():
+        if torch.is_grad_enabled() and not getattr(self, "_warned_text_frozen", False):
             names = [n for n, p in self.named_parameters() if p.requires_grad and not n.startswith(("image.", "visual."))
                      and n != "logit_scale"]
             if names:
-                raise NotImplementedError("training the text tower is not implemented on the HIP path (every ViT-Lens recipe "
-                                          f"locks it, TRAIN_INFERENCE.md); parameters with requires_grad: {names[:3]}...")
+                # every ViT-Lens recipe locks the text tower (TRAIN_INFERENCE.md); a model built without `--lock-text` still
+                # has requires_grad set on it.  The HIP text tower is inference-only: features come back detached, said once.
+                import warnings
+                warnings.warn("the HIP text tower is inference-only: text features carry no gradient although "
+                              f"{len(names)} text parameters have requires_grad=True ({names[0]}, ...); lock the text tower "
+                              "(lock_text_tower()) to silence this", stacklevel=2)
+                self._warned_text_frozen = True
         features = self._text().encode_text(text.to(self.positional_embedding.device))
         return _normalize(features) if normalize else features
 

@@ -295,7 +295,7 @@ class TriModalDepthStep(_StepState):
         self.opt = AdamW(self.masters, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.flat_grad = None
         self.grads: Dict[str, torch.Tensor] = {}
-        self._pending, self._reduced_upto = [], None
+        self._pending, self._reduced_upto, self._reduce_done = [], None, False
 
     # -------------------------------------------------------------------------------------------
     def _trainer(self, i):
@@ -335,21 +335,40 @@ class TriModalDepthStep(_StepState):
         self.optimizer_step()
         return loss
 
+    def finish_reduce(self):
+        """Bring `flat_grad` / `grads` to ONE state: the sum over ranks of every gradient, all collectives complete.
+
+        Between `forward_backward()` and this call the buffer is MIXED: the unlocked blocks' buckets were all-reduced
+        during the last micro-batch's backward (possibly still in flight on the collective's stream) while logit_scale
+        and the adapter - produced last - are still rank-local.  Anything that reads or rescales the gradients in
+        between (clipping, norm logging, accumulation over several forward_backward calls) calls this first;
+        `optimizer_step()` does.  Idempotent; a no-op on one rank.  The values are SUMS: the 1/world of DDP's mean is
+        applied inside the optimizer step (`grad_scale`)."""
+        if self.world == 1 or self._reduce_done:
+            return
+        for h in self._pending:
+            h.wait()
+        self._pending = []
+        if self._reduced_upto is None:
+            self.comm.all_reduce_sum(self.flat_grad)
+        else:
+            lo, hi = self._rest_ranges()
+            for a, b in ((0, lo), (hi, self.flat_grad.numel())):
+                if b > a:
+                    self.comm.all_reduce_sum(self.flat_grad[a:b])
+        self._reduced_upto = None
+        self._reduce_done = True
+
+    def reduced_grads(self):
+        """The gradients by master name after `finish_reduce()` (sums over ranks)."""
+        self.finish_reduce()
+        return self.grads
+
     def optimizer_step(self):
         if self.world > 1:
             # DDP semantics: mean of per-rank gradients.  Block buckets were started during the last micro-batch's backward
             # (reverse layer order); what is left - logit_scale and the adapter, produced last - goes in one more call.
-            for h in self._pending:
-                h.wait()
-            self._pending = []
-            if self._reduced_upto is None:
-                self.comm.all_reduce_sum(self.flat_grad)
-            else:
-                lo, hi = self._rest_ranges()
-                for a, b in ((0, lo), (hi, self.flat_grad.numel())):
-                    if b > a:
-                        self.comm.all_reduce_sum(self.flat_grad[a:b])
-            self._reduced_upto = None
+            self.finish_reduce()
             self.opt.step(self.grads, grad_scale=1.0 / self.world)
         else:
             self.opt.step(self.grads)
@@ -386,7 +405,7 @@ class TriModalDepthStep(_StepState):
             self._alloc_flat_grads()
         for h in self._pending:          # (a forward_backward without optimizer_step: finish what was started)
             h.wait()
-        self._pending, self._reduced_upto = [], None
+        self._pending, self._reduced_upto, self._reduce_done = [], None, False
         self.flat_grad.zero_()
         E = self.image.cfg.embed_dim
         fi = torch.empty(B, E, device=self.dev); ft = torch.empty(B, E, device=self.dev)
@@ -435,6 +454,7 @@ class _PerceiverLensStep(_StepState):
         self.masters: Dict[str, torch.Tensor] = {"logit_scale": self.logit_scale}
         self.refresh = []        # (master name, forward bf16 tensor, key path of the transposed copy in trainer.perc.wT)
         self.flat_grad, self.grads = None, {}
+        self._reduce_done = False
 
     def _collect_perceiver(self, sd):
         pe, P = self.lens.perceiver, "visual.perceiver."
@@ -501,6 +521,7 @@ class _PerceiverLensStep(_StepState):
             for i in range(nmb):
                 self._trainer(i)
             self._alloc_flat_grads()
+        self._reduce_done = False
         self.flat_grad.zero_()
         return mb, nmb
 
@@ -517,9 +538,21 @@ class _PerceiverLensStep(_StepState):
     def _refresh_operands(self):
         self._refresh_perceiver()
 
+    def finish_reduce(self):
+        """Sum `flat_grad` over ranks (one collective, once per forward_backward).  Until this has run the gradients are
+        rank-local; clipping / logging / accumulation code calls it (or `reduced_grads()`) before touching them.  The 1/world
+        of DDP's mean is applied in the optimizer step."""
+        if self.world > 1 and not self._reduce_done:
+            self.comm.all_reduce_sum(self.flat_grad)
+            self._reduce_done = True
+
+    def reduced_grads(self):
+        self.finish_reduce()
+        return self.grads
+
     def optimizer_step(self):
         if self.world > 1:
-            self.comm.all_reduce_sum(self.flat_grad)
+            self.finish_reduce()
             self.opt.step(self.grads, grad_scale=1.0 / self.world)
         else:
             self.opt.step(self.grads)
