@@ -21,7 +21,11 @@ def read_wav(path):
     import wave
 
     import numpy as np
-    with wave.open(path, "rb") as f:
+    if not str(path).lower().endswith((".wav", ".wave")):
+        # the reference decodes through torchaudio's backends (at_processor.py:226-244); this image has no flac / mp3 decoder
+        raise NotImplementedError(f"{path}: only PCM .wav is decoded here - convert the recording, or pass the waveform / "
+                                  "the [clips, 512, 128] fbank tensor")
+    with wave.open(str(path), "rb") as f:
         sr, ch, width, n = f.getframerate(), f.getnchannels(), f.getsampwidth(), f.getnframes()
         raw = f.readframes(n)
     if width == 2:
