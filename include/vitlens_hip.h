@@ -37,11 +37,14 @@ typedef struct ihipStream_t* hipStream_t;
 #define VL_EPI_RES_F32 2  /* out f32 [M,N]   = res f32 + alpha*acc + bias (in place ok)  */
 #define VL_EPI_RES_BF16 3 /* out bf16[M,N]   = res bf16 + alpha*acc + bias               */
 #define VL_EPI_GEGLU 5    /* out bf16[M,N/2] = a*gelu(gate), W rows interleaved (a,gate) */
-#define VL_EPI_DGELU 6    /* out bf16[M,N]   = alpha*acc * gelu'(res bf16[M,N])  (dX through GELU) */
+#define VL_EPI_DGELU 6    /* out bf16[M,N]   = alpha*acc * gelu'(res bf16[M,N])  (dX through GELU); with act =
+                           * VL_ACT_GELU_DSAVE res IS gelu' (left by the forward): the epilogue is one multiplication */
 #define VL_EPI_DGEGLU 7   /* acc = dy[M,N]; res = h bf16[M,2N] interleaved (a,g); out bf16[M,2N] = d h  (dX through GEGLU) */
 #define VL_ACT_NONE 0
 #define VL_ACT_GELU 1     /* exact-erf GELU (nn.GELU default)                            */
 #define VL_ACT_RELU 2
+#define VL_ACT_GELU_DSAVE 4 /* forward of a TRAINED MLP: out = gelu(pre), out2 (required) = gelu'(pre), both of the bf16-rounded
+                             * pre-activation; pair it with VL_EPI_DGELU + the same act in the backward               */
 
 /* dtype tags for mixed-dtype entry points */
 #define VL_F32 0

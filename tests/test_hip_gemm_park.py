@@ -86,6 +86,39 @@ def test_p4_residual_and_dgelu(M, N, K, pcfg):
     assert torch.equal(out, ops.gemm(a, w, None, res=u, epi=ops.EPI_DGELU, cfg=5, out=torch.empty_like(out)))
 
 
+@pytest.mark.parametrize("cfg", [8, 10, 0, 1, 5, -1])
+def test_gelu_forward_leaves_its_derivative_for_the_dx_gemm(cfg):
+    """VL_ACT_GELU_DSAVE: the forward writes out = gelu(pre) and out2 = gelu'(pre) (both of the bf16-rounded pre-activation);
+    VL_EPI_DGELU launched with the same act multiplies by that tensor.  Against fp32 torch, against the separate
+    pre-activation + erf-in-the-backward pair, on every kernel family (persistent, ping-pong, plain tiles, tail rows)."""
+    ops = _ops()
+    M, N, K = (256 * 9 + (64 if cfg in (-1, 0, 1) else 0)), 1024, 512
+    a = rnd(M, K, seed=31).bfloat16().cuda(); w = rnd(N, K, seed=32, scale=2 * K ** -0.5).bfloat16().cuda()
+    bias = rnd(N, seed=33).cuda()
+    pre = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    y0 = ops.gemm(a, w, bias, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg, out2=pre)
+    d = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    y = ops.gemm(a, w, bias, epi=ops.EPI_BF16, act=ops.ACT_GELU_DSAVE, cfg=cfg, out2=d)
+    pf = pre.float().requires_grad_(True)
+    torch.nn.functional.gelu(pf).sum().backward()
+    # bf16 of an fp32-accurate gelu' (|err| <= 4e-7 before rounding): at most one bf16 ulp from torch's
+    assert bool(torch.isfinite(d).all())
+    assert bool(((d.float() - pf.grad).abs() <= pf.grad.abs() * 2.0 ** -8 + 1e-6).all())
+    if cfg in (8, 10, 5):                      # kernels whose GELU acts on the bf16-rounded pre-activation in both modes
+        assert torch.equal(y, y0)
+    else:                                      # plain-tile paths apply act=GELU to the fp32 value
+        assert relerr(y, y0) < 4e-3
+    # backward: (dy W) * gelu'
+    dy = rnd(M, K, seed=34).bfloat16().cuda(); wt = rnd(N, K, seed=35, scale=K ** -0.5).bfloat16().cuda()
+    acc = dy.float() @ wt.float().t()
+    got = ops.gemm(dy, wt, None, res=d, epi=ops.EPI_DGELU, act=ops.ACT_GELU_DSAVE, cfg=cfg, out=torch.empty_like(d))
+    assert relerr(got, acc * pf.grad) < 5e-3
+    old = ops.gemm(dy, wt, None, res=pre, epi=ops.EPI_DGELU, cfg=cfg, out=torch.empty_like(d))
+    assert relerr(got, old) < 4e-3            # one more bf16 rounding (of gelu') than the erf-in-the-backward form
+    with pytest.raises(ValueError):
+        ops.gemm(a, w, bias, epi=ops.EPI_BF16, act=ops.ACT_GELU_DSAVE, cfg=cfg)
+
+
 def test_p4_is_what_auto_dispatch_uses_at_bench_geometry():
     """cfg=-1 at M = 257*256: whole rounds on p4 + tail kernel; every row must be written (NaN-poisoned outputs)."""
     ops = _ops()

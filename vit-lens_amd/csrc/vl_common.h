@@ -58,13 +58,24 @@ __device__ __forceinline__ GeluParts gelu_parts(float x) {
   r.e = __builtin_amdgcn_exp2f(-(zs * zs));
   return r;
 }
-__device__ __forceinline__ float gelu_erf(float x) {
-  const GeluParts g = gelu_parts(x);
+__device__ __forceinline__ float gelu_from_parts(float x, const GeluParts g) {
   return fmaf(-(fabsf(x) * g.q), g.e, fmaxf(x, 0.0f));
 }
 // d/dx gelu(x) = Phi(x) + x*phi(x)
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-  const GeluParts g = gelu_parts(x);
+__device__ __forceinline__ float gelu_grad_from_parts(float x, const GeluParts g) {
   const float step = (__builtin_bit_cast(int, x) >= 0) ? 1.0f : 0.0f;           // by the sign BIT: consistent with copysign at +-0
   return fmaf(g.e, fmaf(0.3989422804014327f, x, -copysignf(g.q, x)), step);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_from_parts(x, gelu_parts(x)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) { return gelu_grad_from_parts(x, gelu_parts(x)); }
+// One packed pair of bf16 pre-activations -> packed bf16 (gelu, gelu'): the pair the forward of a TRAINED MLP leaves behind
+// (VL_ACT_GELU_DSAVE), so that the dX GEMM's epilogue is a multiplication instead of a second erf evaluation.
+__device__ __forceinline__ void gelu_and_grad_pk(unsigned int w, unsigned int& y, unsigned int& d) {
+  const float lo = bf2f((bf16_t)(w & 0xffff)), hi = bf2f((bf16_t)(w >> 16));
+  const GeluParts a = gelu_parts(lo), b = gelu_parts(hi);
+  y = pack2bf(gelu_from_parts(lo, a), gelu_from_parts(hi, b));
+  d = pack2bf(gelu_grad_from_parts(lo, a), gelu_grad_from_parts(hi, b));
+}
+__device__ __forceinline__ unsigned int mul_pk_bf16(unsigned int a, unsigned int b) {
+  return pack2bf(bf2f((bf16_t)(a & 0xffff)) * bf2f((bf16_t)(b & 0xffff)), bf2f((bf16_t)(a >> 16)) * bf2f((bf16_t)(b >> 16)));
 }

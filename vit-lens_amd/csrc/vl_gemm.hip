@@ -40,6 +40,15 @@ __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL
           for (int e = 0; e < 4; ++e) v[e] += bv[e];
         }
         if constexpr (EPI == EPI_BF16) {
+          if (p.act == 4) {          // GELU of the bf16-rounded pre-activation, out2 = gelu' of the same (bf16)
+            unsigned int y0, g0, y1, g1;
+            gelu_and_grad_pk(pack2bf(v[0], v[1]), y0, g0);
+            gelu_and_grad_pk(pack2bf(v[2], v[3]), y1, g1);
+            const u32x2 o = {y0, y1}, d = {g0, g1};
+            *(u32x2*)((bf16_t*)p.out2 + (size_t)m * p.ldo + n) = d;
+            *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
+            continue;
+          }
           if (p.act == 1) {
             if (p.out2) {
               u32x2 o2; o2[0] = pack2bf(v[0], v[1]); o2[1] = pack2bf(v[2], v[3]);
@@ -72,8 +81,11 @@ __device__ __forceinline__ void store_tile(const GemmP& p, f32x16 (&acc)[MT][NTL
           *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
         } else if constexpr (EPI == EPI_DGELU) {
           const u32x2 r = *(const u32x2*)((const bf16_t*)p.res + (size_t)m * p.ldo + n);
-          v[0] *= gelu_erf_grad(bf2f((bf16_t)(r[0] & 0xffff))); v[1] *= gelu_erf_grad(bf2f((bf16_t)(r[0] >> 16)));
-          v[2] *= gelu_erf_grad(bf2f((bf16_t)(r[1] & 0xffff))); v[3] *= gelu_erf_grad(bf2f((bf16_t)(r[1] >> 16)));
+          const bool saved = p.act == 4;          // res = gelu' itself (left by a VL_ACT_GELU_DSAVE forward)
+          const float r0 = bf2f((bf16_t)(r[0] & 0xffff)), r1 = bf2f((bf16_t)(r[0] >> 16));
+          const float r2 = bf2f((bf16_t)(r[1] & 0xffff)), r3 = bf2f((bf16_t)(r[1] >> 16));
+          v[0] *= saved ? r0 : gelu_erf_grad(r0); v[1] *= saved ? r1 : gelu_erf_grad(r1);
+          v[2] *= saved ? r2 : gelu_erf_grad(r2); v[3] *= saved ? r3 : gelu_erf_grad(r3);
           u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
           *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
         } else if constexpr (EPI == EPI_GEGLU) {
@@ -156,6 +168,11 @@ __device__ __forceinline__ void store_tile_lds16(const GemmP& p, f32x16 (&acc)[M
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             w[e] = pack2bf(gelu_erf(bf2f((bf16_t)(w[e] & 0xffff))), gelu_erf(bf2f((bf16_t)(w[e] >> 16))));
+        } else if (p.act == 4) {
+          u32x4 d;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { unsigned int y, g; gelu_and_grad_pk(w[e], y, g); w[e] = y; d[e] = g; }
+          *(u32x4*)((bf16_t*)p.out2 + (size_t)m * p.ldo + n8) = d;
         }
         *(u32x4*)((bf16_t*)p.out + (size_t)m * p.ldo + n8) = w;
       } else if constexpr (EPI == EPI_RES_BF16) {
@@ -170,10 +187,15 @@ __device__ __forceinline__ void store_tile_lds16(const GemmP& p, f32x16 (&acc)[M
         *(u32x4*)((bf16_t*)p.out + (size_t)m * p.ldo + n8) = w;
       } else if constexpr (EPI == EPI_DGELU) {
         const u32x4 rr = *(const u32x4*)((const bf16_t*)p.res + (size_t)m * p.ldo + n8);
+        if (p.act == 4) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          w[e] = pack2bf(bf2f((bf16_t)(w[e] & 0xffff)) * gelu_erf_grad(bf2f((bf16_t)(rr[e] & 0xffff))),
-                         bf2f((bf16_t)(w[e] >> 16)) * gelu_erf_grad(bf2f((bf16_t)(rr[e] >> 16))));
+          for (int e = 0; e < 4; ++e) w[e] = mul_pk_bf16(w[e], rr[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            w[e] = pack2bf(bf2f((bf16_t)(w[e] & 0xffff)) * gelu_erf_grad(bf2f((bf16_t)(rr[e] & 0xffff))),
+                           bf2f((bf16_t)(w[e] >> 16)) * gelu_erf_grad(bf2f((bf16_t)(rr[e] >> 16))));
+        }
         *(u32x4*)((bf16_t*)p.out + (size_t)m * p.ldo + n8) = w;
       }
     }
@@ -244,6 +266,15 @@ __device__ __forceinline__ void store_tile_lds(const GemmP& p, f32x16 (&acc)[MT]
           if (m >= p.M || !col_ok) continue;
           v = v * p.alpha + bv;
           if constexpr (EPI == EPI_BF16) {
+            if (p.act == 4) {
+              unsigned int y0, g0, y1, g1;
+              gelu_and_grad_pk(pack2bf(v[0], v[1]), y0, g0);
+              gelu_and_grad_pk(pack2bf(v[2], v[3]), y1, g1);
+              const u32x2 o = {y0, y1}, d = {g0, g1};
+              *(u32x2*)((bf16_t*)p.out2 + (size_t)m * p.ldo + n) = d;
+              *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
+              continue;
+            }
             if (p.act == 1) {
               if (p.out2) {
                 u32x2 o2; o2[0] = pack2bf(v[0], v[1]); o2[1] = pack2bf(v[2], v[3]);
@@ -274,8 +305,11 @@ __device__ __forceinline__ void store_tile_lds(const GemmP& p, f32x16 (&acc)[MT]
             *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
           } else if constexpr (EPI == EPI_DGELU) {
             const u32x2 rr = *(const u32x2*)((const bf16_t*)p.res + (size_t)m * p.ldo + n);
-            v[0] *= gelu_erf_grad(bf2f((bf16_t)(rr[0] & 0xffff))); v[1] *= gelu_erf_grad(bf2f((bf16_t)(rr[0] >> 16)));
-            v[2] *= gelu_erf_grad(bf2f((bf16_t)(rr[1] & 0xffff))); v[3] *= gelu_erf_grad(bf2f((bf16_t)(rr[1] >> 16)));
+            const bool saved = p.act == 4;
+            const float r0 = bf2f((bf16_t)(rr[0] & 0xffff)), r1 = bf2f((bf16_t)(rr[0] >> 16));
+            const float r2 = bf2f((bf16_t)(rr[1] & 0xffff)), r3 = bf2f((bf16_t)(rr[1] >> 16));
+            v[0] *= saved ? r0 : gelu_erf_grad(r0); v[1] *= saved ? r1 : gelu_erf_grad(r1);
+            v[2] *= saved ? r2 : gelu_erf_grad(r2); v[3] *= saved ? r3 : gelu_erf_grad(r3);
             u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
             *(u32x2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o;
           }
@@ -743,6 +777,8 @@ hipError_t dispatch(const GemmP& p0, int cfg, hipStream_t s) {
   if (cfg == 4 || cfg == 5) return launch_persist<EPI>(p, s);       // 4: historical alias
   if (cfg == 6) return launch_persist<EPI, 128>(p, s);              // 256x128 tiles (experiment)
   if (cfg == 9) return launch_tail<EPI>(p, s);
+  if (cfg == 11) return launch<64, 64, 2, 2, EPI, true>(p, s);      // few-row problems: one 64x64 tile per workgroup
+  if (cfg == 12) return launch<128, 64, 2, 2, EPI, true>(p, s);
   switch (cfg & 3) {
     case 0: return launch<256, 256, 2, 4, EPI, true>(p, s);
     case 1: return launch<128, 128, 2, 2, EPI, true>(p, s);
@@ -818,7 +854,9 @@ extern "C" int vl_gemm_bf16_ex(const void* A, const void* W, const float* bias, 
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.alpha = alpha; p.act = act; p.res_div = res_div;
   hipError_t e;
   switch (epi) {
-    case VL_EPI_BF16: e = run_gemm<EPI_BF16>(p, cfg, stream); break;
+    case VL_EPI_BF16:
+      VL_CHECK_ARG(act != VL_ACT_GELU_DSAVE || out2, "vl_gemm_bf16: VL_ACT_GELU_DSAVE needs out2 (the gelu' tensor)");
+      e = run_gemm<EPI_BF16>(p, cfg, stream); break;
     case VL_EPI_F32: e = run_gemm<EPI_F32>(p, cfg, stream); break;
     case VL_EPI_RES_F32: VL_CHECK_ARG(res, "vl_gemm_bf16: residual missing"); e = run_gemm<EPI_RES_F32>(p, cfg, stream); break;
     case VL_EPI_RES_BF16: VL_CHECK_ARG(res, "vl_gemm_bf16: residual missing"); e = run_gemm<EPI_RES_BF16>(p, cfg, stream); break;

@@ -284,6 +284,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               w[e] = pack2bf(gelu_erf(bf2f((bf16_t)(w[e] & 0xffff))), gelu_erf(bf2f((bf16_t)(w[e] >> 16))));
+          } else if constexpr (EPI == EPI_BF16 && ACT == 4) {
+            u32x4 d;                                              // out2 = gelu'(pre) for the dX GEMM of the backward
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { unsigned int y, g; gelu_and_grad_pk(w[e], y, g); w[e] = y; d[e] = g; }
+            __builtin_nontemporal_store(d, (u32x4*)((unsigned char*)pe.out2 + ((size_t)(mrow0 + i * 32 + pass * 8) * pe.ldo + ncol0) * 2 + lo_out));
           } else if constexpr (EPI == EPI_RES_BF16) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -291,6 +296,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
               const float hi = bf2f((bf16_t)(w[e] >> 16)) + bf2f((bf16_t)(rr[e] >> 16));
               w[e] = pack2bf(lo, hi);
             }
+          } else if constexpr (EPI == EPI_DGELU && ACT == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = mul_pk_bf16(w[e], rr[e]);     // aux = gelu' saved by the forward
           } else if constexpr (EPI == EPI_DGELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -337,7 +345,8 @@ bool vl_gemm_pp_supported(int epi, const void* params) {
   if (p.K < 128) return false;                  // the DMA prologue issues two steps of tile 0 up front
   if (p.res_div != 1) return false;
   if (epi == EPI_RES_BF16 && p.act != 0) return false;
-  if (epi == EPI_BF16 && p.out2 && p.act != 1) return false;
+  if (epi == EPI_BF16 && p.out2 && p.act != 1 && p.act != 4) return false;
+  if (epi == EPI_BF16 && p.act == 4 && !p.out2) return false;
   if (p.ldo & 7) return false;
   if (((uintptr_t)p.A | (uintptr_t)p.W) & 15) return false;
   if (((uintptr_t)p.out | (uintptr_t)p.res | (uintptr_t)p.out2) & 15) return false;
@@ -349,9 +358,10 @@ int vl_gemm_pp_launch(int epi, const void* params, int ncu, hipStream_t s) {
   switch (epi) {
     case EPI_BF16:
       if (p.act == 1) return p.out2 ? (int)launch_pp<EPI_BF16, 3>(p, ncu, s) : (int)launch_pp<EPI_BF16, 1>(p, ncu, s);
+      if (p.act == 4) return (int)launch_pp<EPI_BF16, 4>(p, ncu, s);
       return p.act == 2 ? (int)launch_pp<EPI_BF16, 2>(p, ncu, s) : (int)launch_pp<EPI_BF16, 0>(p, ncu, s);
     case EPI_RES_BF16: return (int)launch_pp<EPI_RES_BF16, 0>(p, ncu, s);
-    case EPI_DGELU: return (int)launch_pp<EPI_DGELU, 0>(p, ncu, s);
+    case EPI_DGELU: return p.act == 4 ? (int)launch_pp<EPI_DGELU, 4>(p, ncu, s) : (int)launch_pp<EPI_DGELU, 0>(p, ncu, s);
     case EPI_F32: return (int)launch_pp<EPI_F32, 0>(p, ncu, s);
     default: return (int)hipErrorInvalidValue;
   }

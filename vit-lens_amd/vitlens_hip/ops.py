@@ -9,6 +9,7 @@ from ._lib import load_library, check
 F32, BF16 = 0, 1
 EPI_BF16, EPI_F32, EPI_RES_F32, EPI_RES_BF16, EPI_GEGLU, EPI_DGELU, EPI_DGEGLU = 0, 1, 2, 3, 5, 6, 7
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+ACT_GELU_DSAVE = 4          # forward: out = gelu(pre), out2 = gelu'(pre);  with EPI_DGELU: res is that gelu' tensor
 LOG2E = 1.4426950408889634
 
 _lib = load_library()
@@ -42,7 +43,10 @@ def _chk2d(t, name, dtype=None):
 
 
 def gemm(a, w, bias=None, out=None, res=None, epi=EPI_BF16, act=ACT_NONE, alpha=1.0, cfg=-1, out2=None, res_div=1):
-    """out = epilogue(a @ w.T).  a [M,K] bf16, w [N,K] bf16.  out2: optional pre-activation copy (bf16)."""
+    """out = epilogue(a @ w.T).  a [M,K] bf16, w [N,K] bf16.  out2: optional pre-activation copy (bf16; with
+    act=ACT_GELU_DSAVE: gelu'(pre) instead, the operand of the backward's EPI_DGELU launched with the same act)."""
+    if act == ACT_GELU_DSAVE and epi == EPI_BF16 and out2 is None:
+        raise ValueError("gemm: ACT_GELU_DSAVE needs out2")
     _chk2d(a, "a", torch.bfloat16); _chk2d(w, "w", torch.bfloat16)
     M, K = a.shape
     N = w.shape[0]

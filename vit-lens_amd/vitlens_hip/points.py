@@ -183,7 +183,7 @@ class PointTokenizerTrainer:
         tok = ops.gemm(g2, o["wr"], m[a + "reduce_dim.bias"], cfg=c)
         c3 = ops.pad3(centers, self.KP)
         u = torch.empty(c3.shape[0], o["wp0"].shape[0], device=self.device, dtype=BF)
-        p1 = ops.gemm(c3, o["wp0"], m[a + "pos_embed.0.bias"], act=ops.ACT_GELU, cfg=c, out2=u)
+        p1 = ops.gemm(c3, o["wp0"], m[a + "pos_embed.0.bias"], act=ops.ACT_GELU_DSAVE, cfg=c, out2=u)
         out = torch.empty_like(tok)
         ops.gemm(p1, o["wp2"], m[a + "pos_embed.2.bias"], out=out, res=tok, epi=ops.EPI_RES_BF16, cfg=c)
         self.ctx = (patches, z1, s1[0], s1[1], h1, f, g, z3, s3[0], s3[1], h2, f2, g2, c3, u, p1, s1[2], s3[2])
@@ -213,7 +213,7 @@ class PointTokenizerTrainer:
         # positional MLP: pos = W2 gelu(W0 c + b0) + b2
         self._dw(a + "pos_embed.2.weight", dout, p1); self._db(a + "pos_embed.2.bias", dout)
         du = torch.empty_like(u)
-        ops.gemm(dout, o["wp2T"], None, out=du, res=u, epi=ops.EPI_DGELU, cfg=c)
+        ops.gemm(dout, o["wp2T"], None, out=du, res=u, epi=ops.EPI_DGELU, act=ops.ACT_GELU_DSAVE, cfg=c)
         self._dw(a + "pos_embed.0.weight", du, c3, cols=3); self._db(a + "pos_embed.0.bias", du)
         # token branch
         self._dw(a + "reduce_dim.weight", dout, g2); self._db(a + "reduce_dim.bias", dout)

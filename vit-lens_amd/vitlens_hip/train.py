@@ -162,7 +162,9 @@ class TowerTrainer:
         ops.attn_fwd(S.q[l], S.k[l], S.v[l], S.a[l], lse=S.lse[l], qscale=dh ** -0.5 * ops.LOG2E)
         ops.gemm(S.a[l], w["out_w"], w["out_b"], out=S.X[2 * l + 1], res=S.X[2 * l], epi=res_epi, cfg=cfg)
         ops.layernorm(S.X[2 * l + 1], w["ln2_w"], w["ln2_b"], h2, B * L, D, mean=m2, rstd=r2)
-        ops.gemm(h2, w["fc_w"], w["fc_b"], out=hid, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg, out2=S.u[l])
+        # S.u[l] = gelu'(fc output): all the backward needs of the pre-activation, evaluated next to gelu() from the same
+        # exp / rational pieces (+3 VALU per element here) - the dX GEMM's epilogue is then one multiplication
+        ops.gemm(h2, w["fc_w"], w["fc_b"], out=hid, epi=ops.EPI_BF16, act=ops.ACT_GELU_DSAVE, cfg=cfg, out2=S.u[l])
         if write_out:
             ops.gemm(hid, w["proj_w"], w["proj_b"], out=S.X[2 * l + 2], res=S.X[2 * l + 1], epi=res_epi, cfg=cfg)
 
@@ -216,7 +218,7 @@ class TowerTrainer:
             trainable = l in self.train_blocks
             bp = f"{P}transformer.resblocks.{l}."
             # ---- MLP branch: x2 = x1 + proj(gelu(fc(ln2(x1)))) ----
-            ops.gemm(S.dxb, wT["proj_w"], None, out=S.du, res=S.u[l], epi=ops.EPI_DGELU, cfg=cfg)       # du = (dx W_proj) * gelu'(u)
+            ops.gemm(S.dxb, wT["proj_w"], None, out=S.du, res=S.u[l], epi=ops.EPI_DGELU, act=ops.ACT_GELU_DSAVE, cfg=cfg)   # du = (dx W_proj) * gelu'(u)
             if trainable:
                 self._dw(bp + "mlp.c_proj.weight", S.dx, S.hidk[l], rows, bp + "mlp.c_proj.bias")
                 self._dw(bp + "mlp.c_fc.weight", S.du, S.h2[l], rows, bp + "mlp.c_fc.bias")
