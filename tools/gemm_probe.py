@@ -37,6 +37,10 @@ def main():
                 return lambda: ops.gemm(a, w, bias, out=out, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg)
             if label == "gelu+save":
                 return lambda: ops.gemm(a, w, bias, out=out, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg, out2=u2)
+            if label == "gelu+dsave":      # forward of a trained MLP: gelu and gelu' (VL_ACT_GELU_DSAVE)
+                return lambda: ops.gemm(a, w, bias, out=out, epi=ops.EPI_BF16, act=ops.ACT_GELU_DSAVE, cfg=cfg, out2=u2)
+            if label == "dgelu_saved":     # its dX GEMM: the epilogue multiplies by the saved gelu'
+                return lambda: ops.gemm(a, w, None, out=out, res=resb, epi=ops.EPI_DGELU, act=ops.ACT_GELU_DSAVE, cfg=cfg)
             if label == "res_bf16":
                 return lambda: ops.gemm(a, w, bias, out=resb, res=resb, epi=ops.EPI_RES_BF16, cfg=cfg)
             return lambda: ops.gemm(a, w, None, out=out, res=resb, epi=ops.EPI_DGELU, cfg=cfg)

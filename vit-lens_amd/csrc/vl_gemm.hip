@@ -825,7 +825,11 @@ static hipError_t run_gemm(const GemmP& p, int cfg, hipStream_t s) {
   // every other epilogue indexes res with the local row.
   if (p.res && EPI != EPI_RES_BF16) pr.res = (const unsigned char*)p.res + (size_t)rows_main * p.ldo * osz;
   if (p.out2) pr.out2 = (bf16_t*)p.out2 + (size_t)rows_main * p.ldo * (EPI == EPI_GEGLU ? 2 : 1);
-  return pr.M <= 512 ? launch_tail<EPI>(pr, s) : dispatch<EPI>(pr, 1, s);
+  if (pr.M > 512) return dispatch<EPI>(pr, 1, s);
+  // leftover rows: 64x64 LDS-DMA tiles when they fill most of the chip (N >= 3072 at 256 rows: 10-12 us against 15-20 us,
+  // profiles/r03b_tail_probe.log), otherwise the split-K 32x32 tail kernel (long K, few columns: 17 us against 28-32 us)
+  const long t64 = (long)((pr.M + 63) / 64) * ((pr.N + 63) / 64);
+  return t64 >= 192 ? dispatch<EPI>(pr, 11, s) : launch_tail<EPI>(pr, s);
 }
 
 #define VL_CHECK_ARG(c, msg) do { if (!(c)) return vl_set_error(msg); } while (0)
