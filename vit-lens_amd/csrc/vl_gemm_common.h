@@ -37,6 +37,7 @@ struct GemmP {
   // kernel tuning input set by the dispatcher (not part of the C ABI): start-up phase shift of the second workgroup of a
   // CU (vl_gemm_pp.hip, units of 4096 cycles)
   int pp_delay;
+  int mfma16;        // persistent kernel: main loop on v_mfma_f32_16x16x32_bf16 (tuning input, set by the dispatcher)
 };
 
 // acc * alpha + bias as four plain v_fma_f32.  Left to the compiler, the vector expression becomes v_pk_fma_f32, and in

@@ -42,8 +42,14 @@ using IC = std::integral_constant<int, I>;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-// ACT (EPI_BF16 only): 0 none, 1 GELU, 2 ReLU, 3 GELU with the pre-activation also written to out2 (saved for backward)
-template <int EPI, int ACT>
+// ACT (EPI_BF16 only): 0 none, 1 GELU, 2 ReLU, 3 GELU with the pre-activation also written to out2 (saved for backward),
+// 4 GELU with gelu'(pre-activation) written to out2.  EPI_DGELU: ACT 4 = the aux operand is that saved gelu'.
+// M16: the main loop on `v_mfma_f32_16x16x32_bf16` (32 MFMAs of 16 384 flop per 32-deep half k-step from 8 + 4 fragments)
+// instead of `v_mfma_f32_32x32x16_bf16` (8 of 32 768 flop per 16-deep substep from 4 + 2): the same LDS traffic and
+// accumulator registers, a quarter of the accumulator read-modify-write per flop.  The board is power-limited on real
+// data: a register-only loop of the 16x16x32 instruction sustains 2087 TF/s on random-normal operands
+// against 1862 TF/s for 32x32x16 (profiles/r03b_mfma_power_probe.log).
+template <int EPI, int ACT, bool M16>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
     gemm_nt_pk_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -103,29 +109,67 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
   // ---- fragments (two sets: the reads of substep s+1 are in flight under the MFMAs of substep s) ----
   const int fa_base = (wave_m * 128 + fr) * 128, fw_base = PK_ABYTES + (wave_n * WTN + fr) * 128;
-  bf16x8 af[2][4], wf[2][NTL];
-  auto ldfrag = [&](const unsigned char* stage, int kk, int c) {
+  bf16x8 af[2][4], wf[2][M16 ? 4 : NTL];
+  [[maybe_unused]] auto ldfrag = [&](const unsigned char* stage, int kk, int c) {
     const int off = ((kk * 2 + fg) ^ fsw) * 16;
 #pragma unroll
     for (int j = 0; j < NTL; ++j) wf[c][j] = *(const bf16x8*)(stage + fw_base + j * 4096 + off);
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[c][i] = *(const bf16x8*)(stage + fa_base + i * 4096 + off);
   };
-  f32x16 acc[4][NTL];
-  auto mma = [&](int c) {
+  [[maybe_unused]] f32x16 acc[M16 ? 1 : 4][M16 ? 1 : NTL];
+  [[maybe_unused]] auto mma = [&](int c) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < NTL; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][j], af[c][i], acc[i][j], 0, 0, 0);
+        acc[M16 ? 0 : i][M16 ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][j], af[c][i], acc[M16 ? 0 : i][M16 ? 0 : j], 0, 0, 0);
+  };
+  // ---- the same wave tile in 16x16 blocks: fragment = 16 rows x 32 k (lane: row lane&15, 8-wide k chunk lane>>4), A rows
+  // mh*64 + ia*16, W rows jb*16; accumulator block [ib][jb]: lane owns output row ib*16 + (lane&15) and the four columns
+  // jb*16 + (lane>>4)*4 .. +3.  Same XOR swizzle ((row>>1)&7 on the 16-byte chunk index; block bases are multiples of 16
+  // rows), conflict-free in the four 16-lane groups of ds_read_b128.
+  const int fr16 = lane & 15, fq = lane >> 4;
+  const int fsw16 = (fr16 >> 1) & 7;
+  const int fa16 = (wave_m * 128 + fr16) * 128, fw16 = PK_ABYTES + (wave_n * WTN + fr16) * 128;
+  [[maybe_unused]] f32x4 acc16[M16 ? 8 : 1][M16 ? 4 : 1];
+  [[maybe_unused]] auto ldA16 = [&](const unsigned char* stage, int h, int mh, int c) {
+    const int off = ((h * 4 + fq) ^ fsw16) * 16;
+#pragma unroll
+    for (int ia = 0; ia < 4; ++ia) af[c][ia] = *(const bf16x8*)(stage + fa16 + (mh * 4 + ia) * 2048 + off);
+  };
+  [[maybe_unused]] auto ldW16 = [&](const unsigned char* stage, int h, int c, auto J0, auto J1) {
+    const int off = ((h * 4 + fq) ^ fsw16) * 16;
+#pragma unroll
+    for (int jb = decltype(J0)::value; jb < decltype(J1)::value; ++jb) wf[c][M16 ? jb : 0] = *(const bf16x8*)(stage + fw16 + jb * 2048 + off);
+  };
+  [[maybe_unused]] auto mma16 = [&](auto MH, int ca, int cw) {
+    constexpr int mh = decltype(MH)::value;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+      for (int ia = 0; ia < 4; ++ia)
+        acc16[M16 ? mh * 4 + ia : 0][M16 ? jb : 0] =
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cw][M16 ? jb : 0], af[ca][ia], acc16[M16 ? mh * 4 + ia : 0][M16 ? jb : 0], 0, 0, 0);
+  };
+  auto first_frags = [&](const unsigned char* stage) {       // fragments of a stage's first phase
+    if constexpr (M16) { ldA16(stage, 0, 0, 0); ldW16(stage, 0, 0, IC<0>{}, IC<4>{}); }
+    else ldfrag(stage, 0, 0);
   };
   auto zero_acc = [&]() {
+    if constexpr (M16) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < NTL; ++j)
+        for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
   };
 
   // ---- epilogue operands ----
@@ -181,7 +225,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   dma_step(smem);
   dma_step(smem + PK_STAGE);                     // nk >= 8: still inside tile 0
   dma_wait_and_barrier();
-  ldfrag(smem, 0, 0);
+  first_frags(smem);
 
   int par = 0;                                   // stage buffer of the k-step being computed
   bool pendB = false;                            // group B: a DMA batch is due at the top of the next k-step
@@ -191,6 +235,23 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     unsigned char* oth = smem + (par ^ 1) * PK_STAGE;
     if (grpB && pendB) { dma_step(oth); pendB = false; }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (M16) {
+      // four phases of 16 MFMAs: (k half 0, rows 0-63) (0, 64-127) (1, 0-63) (1, 64-127); W fragments of a half stay for both
+      ldA16(cur, 0, 1, 1); ldW16(cur, 1, 1, IC<0>{}, IC<2>{});
+      mma16(IC<0>{}, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ldA16(cur, 1, 0, 0); ldW16(cur, 1, 1, IC<2>{}, IC<4>{});
+      mma16(IC<1>{}, 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ldA16(cur, 1, 1, 1);
+      mma16(IC<0>{}, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      dma_wait_and_barrier();
+      if (dti < my_tiles) { if (!grpB) dma_step(cur); else pendB = true; }
+      if constexpr (!last) first_frags(oth);
+      __builtin_amdgcn_sched_barrier(0);
+      mma16(IC<1>{}, 1, 1);
+    } else {
     ldfrag(cur, 1, 1);
     mma(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -206,6 +267,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     if constexpr (!last) ldfrag(oth, 0, 0);      // (at a tile boundary the fragments would sit in registers through the epilogue)
     __builtin_amdgcn_sched_barrier(0);
     mma(1);
+    }
     __builtin_amdgcn_sched_barrier(0);
     par ^= 1;
   };
@@ -260,10 +322,21 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
           for (int j = 0; j < NTL; ++j) {
+            if constexpr (M16) {
+#pragma unroll
+              for (int ibh = 0; ibh < 2; ++ibh)
+#pragma unroll
+                for (int jbh = 0; jbh < 2; ++jbh) {
+                  const int row = ibh * 16 + fr16;
+                  *(f32x4*)(slab + row * 128 + (((jbh * 4 + fq) ^ (row & 7)) << 4)) =
+                      scale_bias(acc16[M16 ? i * 2 + ibh : 0][M16 ? j * 2 + jbh : 0], pe.alpha, f32x4{0.f, 0.f, 0.f, 0.f});
+                }
+            } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              f32x4 v = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+              f32x4 v = {acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 0], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 1], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 2], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 3]};
               *(f32x4*)(slab + fr * 128 + (((q * 2 + fg) ^ wsw) << 4)) = scale_bias(v, pe.alpha, f32x4{0.f, 0.f, 0.f, 0.f});
+            }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -282,8 +355,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int j = 0; j < NTL; ++j) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int n = ncol0 + j * 32 + q * 8 + fg * 4;
-            f32x4 v = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+            // 32x32 blocks: (j, q) = column block, 8-column group; 16x16 blocks: (j, q) = (row half ibh, column block jb)
+            const int n = M16 ? ncol0 + q * 16 + fq * 4 : ncol0 + j * 32 + q * 8 + fg * 4;
+            f32x4 v;
+            if constexpr (M16) v = acc16[M16 ? i * 2 + j : 0][M16 ? q : 0];
+            else v = f32x4{acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 0], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 1], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 2], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 3]};
             f32x4 bv = *(const f32x4*)(bsrc + n);
 #pragma unroll
             for (int e = 0; e < 4; ++e) bv[e] = has_bias ? bv[e] : 0.f;
@@ -296,7 +372,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
               for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
             u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-            *(u32x2*)(wr + (((j * 4 + q) ^ wsw) << 4)) = o;
+            if constexpr (M16) {
+              const int row = j * 16 + fr16;
+              *(u32x2*)(slab + row * 128 + (((q * 2 + (fq >> 1)) ^ (row & 7)) << 4) + (fq & 1) * 8) = o;
+            } else {
+              *(u32x2*)(wr + (((j * 4 + q) ^ wsw) << 4)) = o;
+            }
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -368,14 +449,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       row_block(IC<0>{}); row_block(IC<1>{}); row_block(IC<2>{}); row_block(IC<3>{});
       }
       zero_acc();
-      if (ti + 1 < my_tiles) { tile_origin(ti + 1, cur_m0, cur_n0, cur_sp); ldfrag(smem + par * PK_STAGE, 0, 0); }
+      if (ti + 1 < my_tiles) { tile_origin(ti + 1, cur_m0, cur_n0, cur_sp); first_frags(smem + par * PK_STAGE); }
     }
   }
 }
 
-template <int EPI, int ACT>
-hipError_t launch_pk(const GemmP& p, int ncu, hipStream_t s) {
-  auto kern = gemm_nt_pk_kernel<EPI, ACT>;
+template <int EPI, int ACT, bool M16>
+hipError_t launch_pk_v(const GemmP& p, int ncu, hipStream_t s) {
+  auto kern = gemm_nt_pk_kernel<EPI, ACT, M16>;
   static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PK_LDS);   // thread-safe one-time init
   if (attr != hipSuccess) return attr;
   const int tiles = (p.M >> 8) * (p.N >> 8) * ((EPI == EPI_F32 && p.ksplit_len) ? (p.K >> 6) / p.ksplit_len : 1);
@@ -383,6 +464,11 @@ hipError_t launch_pk(const GemmP& p, int ncu, hipStream_t s) {
   if (tiles < G) G = (tiles + 7) & ~7;
   hipLaunchKernelGGL(kern, dim3(G), dim3(512), PK_LDS, s, p);
   return hipGetLastError();
+}
+
+template <int EPI, int ACT>
+hipError_t launch_pk(const GemmP& p, int ncu, hipStream_t s) {
+  return p.mfma16 ? launch_pk_v<EPI, ACT, true>(p, ncu, s) : launch_pk_v<EPI, ACT, false>(p, ncu, s);
 }
 
 }  // namespace
