@@ -735,19 +735,20 @@ namespace {
 
 // Kernel selection / tuning inputs of the persistent kernels.  Read once from the environment so that one build can be
 // A/B-measured on the GPU box (tools/kernel_bench.py, bench.py); the defaults are the measured best.
-struct GemmTune { int prefer_pp, pp_delay, mfma16; };
+struct GemmTune { int prefer_pp, pp_delay, mfma16, pk_gn; };
 inline int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }
 inline const GemmTune& gemm_tune() {
-  static const GemmTune t{env_int("VL_GEMM_PP", 0), env_int("VL_PP_DELAY", 4), env_int("VL_GEMM_MFMA16", 1)};
+  static const GemmTune t{env_int("VL_GEMM_PP", 0), env_int("VL_PP_DELAY", 4), env_int("VL_GEMM_MFMA16", 1), env_int("VL_GEMM_GN", 0)};
   return t;
 }
 inline GemmP tuned(const GemmP& p) {
   GemmP q = p;
   q.pp_delay = gemm_tune().pp_delay;
   q.mfma16 = gemm_tune().mfma16;
+  q.pk_gn = gemm_tune().pk_gn;
   return q;
 }
 

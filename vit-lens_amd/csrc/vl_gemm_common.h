@@ -37,6 +37,7 @@ struct GemmP {
   // kernel tuning input set by the dispatcher (not part of the C ABI): start-up phase shift of the second workgroup of a
   // CU (vl_gemm_pp.hip, units of 4096 cycles)
   int pp_delay;
+  int pk_gn;         // persistent kernel: N-tiles per group of the tile order (0 = the built-in 4)
   int mfma16;        // persistent kernel: main loop on v_mfma_f32_16x16x32_bf16 (tuning input, set by the dispatcher)
 };
 

@@ -87,10 +87,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     int v = ti * G + slot;
     sp = 0;
     if constexpr (EPI == EPI_F32) { sp = v / ntiles_mn; v -= sp * ntiles_mn; }
-    const int gsz = PK_GN * tiles_m;
+    const int GN = p.pk_gn > 0 ? p.pk_gn : PK_GN;
+    const int gsz = GN * tiles_m;
     const int gid = v / gsz, rem = v - gid * gsz;
-    const int first_n = gid * PK_GN;
-    const int gn = min(tiles_n - first_n, PK_GN);
+    const int first_n = gid * GN;
+    const int gn = min(tiles_n - first_n, GN);
     const int tm = rem / gn;
     m0 = tm << 8; n0 = (first_n + (rem - tm * gn)) << 8;
   };
