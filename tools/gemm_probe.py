@@ -13,7 +13,9 @@ from vitlens_hip import ops  # noqa: E402
 
 T = 256 * 256
 SHAPES = {"qkv": (T, 3072, 1024), "out": (T, 1024, 1024), "fc": (T, 4096, 1024), "proj": (T, 1024, 4096),
-          "sq8k": (8192, 8192, 8192), "dfc": (T, 1024, 4096), "dproj": (T, 4096, 1024)}
+          "sq8k": (8192, 8192, 8192), "dfc": (T, 1024, 4096), "dproj": (T, 4096, 1024),
+          # text tower (ViT-L/14 text: width 768, 77 tokens x 256 captions = 77 row tiles: no whole round of 256 workgroups)
+          "tqkv": (19712, 2304, 768), "tout": (19712, 768, 768), "tfc": (19712, 3072, 768), "tproj": (19712, 768, 3072)}
 
 
 def main():

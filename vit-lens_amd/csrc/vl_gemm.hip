@@ -804,7 +804,9 @@ static hipError_t run_gemm(const GemmP& p, int cfg, hipStream_t s) {
   if (cfg >= 0) return dispatch<EPI>(p, cfg, s);
   const int G = num_cus() & ~7;
   const int tiles_n = (p.N + 255) / 256, full_m = p.M / 256;
-  if ((long)full_m * tiles_n < G) return dispatch<EPI>(p, 1, s);
+  // fewer 256x256 tiles than 3/4 of the CUs: 128x128 tiles.  (Between 3/4 and one full round the persistent kernel's single
+  // uneven round wins: text tower out_proj / c_proj, 77 x 3 = 231 tiles, 30 / 86 us against 89 us on 128x128 tiles.)
+  if ((long)full_m * tiles_n < (G * 3) / 4) return dispatch<EPI>(p, 1, s);
   int step = G / gcd_i(G, tiles_n);
   int main_m = (full_m / step) * step;
   if ((p.N & 255) == 128) {       // 256x128 tiles on the ping-pong kernel (two workgroups per CU): whole rounds where the row
@@ -812,6 +814,9 @@ static hipError_t run_gemm(const GemmP& p, int cfg, hipStream_t s) {
     main_m = (full_m / step) * step;
     if (main_m == 0) main_m = full_m;
   }
+  // no whole round fits (e.g. the text tower's 77 row tiles x 9 or 12 column tiles): every full row tile on the persistent
+  // kernel with an uneven last round (launch_best_persist falls back to the round-1 kernel where the round-2 one does not apply)
+  if (main_m == 0) main_m = full_m;
   if (main_m == 0) return launch_persist<EPI>(p, s);
   const int rows_main = main_m * 256;
   GemmP pm = p; pm.M = rows_main;
