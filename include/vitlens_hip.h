@@ -74,6 +74,13 @@ int vl_gemm_bf16(const void* A, const void* W, const float* bias, void* out, con
  * Autograd counterpart of the dW of nn.Linear / 1x1 Conv1d in the trainable Lens. */
 int vl_gemm_splitk_accum_f32(const void* A, const void* W, float* out, int M, int N, int K, int lda, int ldw, long ldo,
                              float alpha, int splits, float* ws, hipStream_t stream);
+/* The same accumulate on TOKEN-MAJOR operands: out[M,N] f32 += alpha * At[K,M]^T . Bt[K,N], At = dY and Bt = X as the backward
+ * holds them (row = token, row strides lda >= M, ldb >= N, multiples of 8) - no transposed copies.  M % 256 == N % 256 == 0,
+ * K % 64 == 0, (K/64) % splits == 0 with >= 4 steps per slice; ws = splits*M*N floats.  Fragments come from gfx950's LDS
+ * transpose read (csrc/vl_gemm_tn.hip).  Replaces the dW of nn.Linear / in_proj / out_proj under loss.backward()
+ * (open_clip/transformer.py:215,226-234,252-272; training/train.py:212-216). */
+int vl_gemm_tn_splitk_accum_f32(const void* At, const void* Bt, float* out, int M, int N, int K, int lda, int ldb, long ldo,
+                                float alpha, int splits, float* ws, hipStream_t stream);
 /* vl_gemm_bf16 + `out2` (with VL_EPI_BF16/VL_ACT_GELU also stores the pre-activation, bf16, for the
  * backward) + `res_div` (VL_EPI_RES_BF16: residual row = m / res_div, i.e. one row broadcast over a group:
  * the PointNet concat([global, local]) conv of dvae.py:207-210 split into two GEMMs).

@@ -23,8 +23,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 python tools/traffic_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/r03_hbm_traffic_c3.json \
-  "gemm_nt_pk_kernel<3, 0>|65792,1024,4096|hi|3,0" "gemm_nt_pk_kernel<0, 1>|65792,4096,1024|hi|0,1" \
-  "gemm_nt_pk_kernel<0, 4>|65792,4096,1024|all|0,4" "gemm_nt_pk_kernel<6, 4>|65792,4096,1024|all|6,4"
+  "gemm_nt_pk_kernel<3, 0,|65792,1024,4096|hi|3,0" "gemm_nt_pk_kernel<0, 1,|65792,4096,1024|hi|0,1" \
+  "gemm_nt_pk_kernel<0, 4,|65792,4096,1024|all|0,4" "gemm_nt_pk_kernel<6, 4,|65792,4096,1024|all|6,4"
 find gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE -name "*.csv" -size +4M -delete
 for WL in c4 c5; do
   echo "== bench $WL =="

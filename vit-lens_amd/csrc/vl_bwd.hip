@@ -152,6 +152,42 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* a, long lda, float
   ws[(long)blockIdx.y * cols + j] = s;
 }
 
+// the same for bf16 inputs whose rows are 16-byte friendly: 8 columns per thread (one 16-byte load per row), four row lanes
+// per block with four loads each in flight, reduced through LDS.  (The one-column-per-thread kernel moves 128 bytes per wave
+// load: 1.6 TB/s on a [65 792, 4 096] gradient, 0.33 ms - more than both transposes of the path it now stands beside.)
+__global__ void __launch_bounds__(256) colsum8_bf16_kernel(const bf16_t* a, long lda, float* ws, int rows, int cols, int slab) {
+  __shared__ float sh[3][64][8];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int j = (blockIdx.x * 64 + cx) * 8;
+  const int r0 = blockIdx.y * slab, r1 = min(rows, r0 + slab);
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  auto add = [&](const u32x4 v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s[2 * e] += bf2f((bf16_t)(v[e] & 0xffff)); s[2 * e + 1] += bf2f((bf16_t)(v[e] >> 16)); }
+  };
+  if (j < cols) {
+    const bf16_t* ptr = a + j;
+    int r = r0 + ry;
+    for (; r + 12 < r1; r += 16) {
+      const u32x4 v0 = *(const u32x4*)(ptr + (long)r * lda), v1 = *(const u32x4*)(ptr + (long)(r + 4) * lda);
+      const u32x4 v2 = *(const u32x4*)(ptr + (long)(r + 8) * lda), v3 = *(const u32x4*)(ptr + (long)(r + 12) * lda);
+      add(v0); add(v1); add(v2); add(v3);
+    }
+    for (; r < r1; r += 4) add(*(const u32x4*)(ptr + (long)r * lda));
+  }
+  if (ry) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sh[ry - 1][cx][e] = s[e];
+  }
+  __syncthreads();
+  if (ry == 0 && j < cols) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ws[(long)blockIdx.y * cols + j + e] = (s[e] + sh[0][cx][e]) + (sh[1][cx][e] + sh[2][cx][e]);
+  }
+}
+
 __global__ void __launch_bounds__(256) gelu_kernel(const bf16_t* u, bf16_t* y, long n) {
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (long)gridDim.x * 256 * 8) {
     const u32x4 v = *(const u32x4*)(u + i);
@@ -281,7 +317,9 @@ extern "C" int vl_colsum(const void* a, int a_dtype, long lda, float* out, int r
   if (!ws) return vl_set_error("vl_colsum: workspace of vl_colreduce_ws_floats(rows, cols, 1) floats required");
   const int slab = kSlabRows, nslab = (rows + slab - 1) / slab;
   const dim3 g((cols + 255) / 256, nslab), b(256);
-  if (a_dtype == VL_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, g, b, 0, stream, (const bf16_t*)a, lda, ws, rows, cols, slab);
+  if (a_dtype == VL_BF16 && (cols & 7) == 0 && (lda & 7) == 0 && ((uintptr_t)a & 15) == 0)
+    hipLaunchKernelGGL(colsum8_bf16_kernel, dim3((cols + 511) / 512, nslab), b, 0, stream, (const bf16_t*)a, lda, ws, rows, cols, slab);
+  else if (a_dtype == VL_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, g, b, 0, stream, (const bf16_t*)a, lda, ws, rows, cols, slab);
   else hipLaunchKernelGGL(colsum_kernel<float>, g, b, 0, stream, (const float*)a, lda, ws, rows, cols, slab);
   hipLaunchKernelGGL(slab_finalize_kernel, dim3((cols + 63) / 64, 1), dim3(1024), 0, stream, ws, nslab, 1, cols, scale, out, out);
   VL_HIP_OK(hipGetLastError());

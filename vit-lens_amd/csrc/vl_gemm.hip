@@ -880,6 +880,33 @@ extern "C" int vl_gemm_bf16_ex(const void* A, const void* W, const float* bias, 
   return 0;
 }
 
+// vl_gemm_tn.hip: token-major operands (At [K, M], Bt [K, N]) through the LDS transpose read
+bool vl_gemm_tn_supported(const void* params);
+int vl_gemm_tn_launch(const void* params, int ncu, hipStream_t s);
+
+// out[M,N] (f32, row stride ldo) += alpha * At[K,M]^T . Bt[K,N]: the weight-gradient GEMM on the operands as the backward
+// holds them (row = token).  K is cut into `splits` equal slices of whole 64-token steps; partial products go to ws
+// (splits * M * N floats) and are summed in a fixed order.
+extern "C" int vl_gemm_tn_splitk_accum_f32(const void* At, const void* Bt, float* out, int M, int N, int K, int lda, int ldb,
+                                           long ldo, float alpha, int splits, float* ws, hipStream_t stream) {
+  VL_CHECK_ARG(M > 0 && N > 0 && K > 0, "vl_gemm_tn_splitk: empty problem");
+  VL_CHECK_ARG((M & 255) == 0 && (N & 255) == 0 && (K & 63) == 0, "vl_gemm_tn_splitk: M % 256, N % 256, K % 64 required");
+  VL_CHECK_ARG((lda & 7) == 0 && (ldb & 7) == 0 && (ldo & 3) == 0 && lda >= M && ldb >= N, "vl_gemm_tn_splitk: lda/ldb % 8, ldo % 4, lda >= M, ldb >= N required");
+  VL_CHECK_ARG(splits >= 1 && splits <= 1024 && ws, "vl_gemm_tn_splitk: 1 <= splits <= 1024 and a workspace of splits*M*N floats");
+  const int nk = K >> 6;
+  VL_CHECK_ARG(nk % splits == 0 && nk / splits >= 4, "vl_gemm_tn_splitk: K/64 must be a multiple of splits with >= 4 steps per slice");
+  GemmP p{};
+  p.A = (const bf16_t*)At; p.W = (const bf16_t*)Bt; p.out = ws; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldb; p.ldo = N;
+  p.alpha = alpha; p.res_div = 1; p.split_stride = (long)M * N; p.ksplit_len = nk / splits;
+  VL_CHECK_ARG(vl_gemm_tn_supported(&p), "vl_gemm_tn_splitk: operands must be 16-byte aligned and a slice below 2 GB");
+  hipError_t e = (hipError_t)vl_gemm_tn_launch(&p, num_cus(), stream);
+  if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)M * (N >> 2) + 255) / 256)), dim3(256), 0, stream, ws, splits, M, N, out, ldo);
+  e = hipGetLastError();
+  if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
+  return 0;
+}
+
 // out[M,N] (f32, row stride ldo) += alpha * A[M,K] . W[N,K]^T with the K range cut into `splits` slices computed by
 // separate workgroups (weight-gradient GEMMs: tiny M x N, K = number of tokens) and summed in a fixed order.
 extern "C" int vl_gemm_splitk_accum_f32(const void* A, const void* W, float* out, int M, int N, int K, int lda, int ldw,

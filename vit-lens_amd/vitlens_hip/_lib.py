@@ -22,6 +22,7 @@ SIGNATURES = {
     "vl_device_info": [I, C.c_char_p, I, C.POINTER(I), C.POINTER(I), C.POINTER(L)],
     "vl_gemm_bf16": [P, P, P, P, P, I, I, I, I, I, I, F, I, I, I, P],
     "vl_gemm_splitk_accum_f32": [P, P, P, I, I, I, I, I, L, F, I, P, P],
+    "vl_gemm_tn_splitk_accum_f32": [P, P, P, I, I, I, I, I, L, F, I, P, P],
     "vl_attn_fwd_bf16": [P, P, P, P, P, P, I, I, I, I, I, F, I, P],
     "vl_layernorm_fwd": [P, I, L, P, L, P, P, P, I, L, P, P, I, I, F, P],
     "vl_assemble_ln_pre": [P, I, P, P, P, P, P, P, I, P, P, P, I, I, I, F, P],

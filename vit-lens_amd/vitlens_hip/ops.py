@@ -116,6 +116,28 @@ def gemm_dw(dyt, xt, g, cfg=-1, alpha=1.0):
     return gemm(dyt, xt, None, out=g, res=g, epi=EPI_RES_F32, cfg=cfg, alpha=alpha)
 
 
+def gemm_dw_tn(dy, x, g, alpha=1.0):
+    """g[N_out, K_in] += dy^T x on the operands as the backward holds them (dy [R, N_out], x [R, K_in] bf16, row = token):
+    no transposed copies - the kernel stages token-major k-slabs and reads its fragments with the LDS transpose read.
+    Returns False (nothing launched) when the shape does not fit (whole 256x256 tiles, R % 64 == 0, enough work items)."""
+    if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or g.dtype != torch.float32 or dy.dim() != 2 or x.dim() != 2:
+        return False
+    R, M = dy.shape
+    N = x.shape[1]
+    if x.shape[0] != R or R % 64 or M % 256 or N % 256 or dy.stride(1) != 1 or x.stride(1) != 1 or g.stride(1) != 1:
+        return False
+    if dy.stride(0) % 8 or x.stride(0) % 8 or g.stride(0) % 4 or dy.data_ptr() % 16 or x.data_ptr() % 16 or tuple(g.shape) != (M, N):
+        return False
+    nk, t256 = R // 64, (M // 256) * (N // 256)
+    for splits in (1, 2, 4, 8, 16):
+        if nk % splits == 0 and t256 * splits >= 192 and nk // splits >= 16:
+            ws = torch.empty(splits * M * N, device=g.device, dtype=torch.float32)
+            check(_lib.vl_gemm_tn_splitk_accum_f32(_p(dy), _p(x), _p(g), M, N, R, dy.stride(0), x.stride(0), g.stride(0),
+                                                   float(alpha), splits, _p(ws), _stream()))
+            return True
+    return False
+
+
 def _bhld_strides(*views):
     """(batch, head, row) element strides of [B,H,L,dh] views (last stride 1) as a ctypes long array."""
     import ctypes

@@ -175,6 +175,10 @@ class TowerTrainer:
         g = self.grad_buffer(name, torch.empty(dy.shape[1], x.shape[1]))
         rp = (rows + 63) // 64 * 64
         gb = self.grad_buffer(bias_name, torch.empty(dy.shape[1])) if bias_name else None
+        if rows == dy.shape[0] == x.shape[0] and ops.gemm_dw_tn(dy, x, g):      # token-major operands: no transposed copies
+            if gb is not None:
+                ops.colsum(dy, gb)
+            return
         dyt = ops.transpose_colsum(dy, rp, colsum_out=gb)
         xt = ops.transpose_colsum(x, rp)
         ops.gemm_dw(dyt, xt, g, cfg=self.eng.gemm_cfg)
