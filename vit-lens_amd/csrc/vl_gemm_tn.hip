@@ -83,26 +83,40 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int fbase = (fq * 8 + (fi >> 2)) * 512 + (fi & 3) * 8;
   const int fx = fg << 5;                                                      // unit u of these rows sits at byte (u << 5) ^ fx of the row
   const int ua0 = (wave_m * 8) << 5, ub0 = (wave_n * 4) << 5;                  // (wave-uniform) first unit of this wave's rows / columns
-  bf16x8 af[2][4], wf[2][4];
-  auto tr2 = [&](const unsigned char* src) {          // 8 consecutive tokens of one column: two transpose reads, 4 token rows apart
-    Frag2 f;
-    f.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(src));
-    f.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(src + 2048));
-    return __builtin_bit_cast(bf16x8, f);
+  // The reads are inline assembly with hand-placed waits: hipcc puts an `s_waitcnt vmcnt(0)` in front of the transpose-read
+  // BUILTIN whenever an LDS-DMA is in flight (it cannot tell that the DMA writes the other stage) - that wait sat at the top
+  // of every k-step, serialising the DMA round trip with the MFMAs (1 047 vs 1 217 TF/s for the NT kernel on the same problem).
+  // Protocol: the reads of phase p+1 are issued at the start of phase p; phase p+1 begins with `s_waitcnt lgkmcnt(0)` tied
+  // ("+v") to the registers it is about to consume, so that no consumer (and no compiler-made copy) can move above the wait.
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+  s16x4 afr[2][4][2], wfr[2][4][2];                       // [buffer][fragment][tokens 0-3 | 4-7 of the lane's 8-token chunk]
+  auto tr_issue = [&](s16x4& lo, s16x4& hi, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048" : "=&v"(lo), "=&v"(hi) : "v"(addr));
   };
-  auto ldA = [&](const unsigned char* stage, int h, auto MH, int c) {
+  auto ldA = [&](unsigned stage, int h, auto MH, int c) {          // stage = LDS byte offset of the operand stage
     constexpr int mh = decltype(MH)::value;
     int fxx = fx;
     asm volatile("" : "+v"(fxx));        // keeps the 12 (x 2 stages) fragment addresses from being hoisted into registers (they spilled)
 #pragma unroll
-    for (int ia = 0; ia < 4; ++ia) af[c][ia] = tr2(stage + h * 16384 + fbase + ((ua0 + ((mh * 4 + ia) << 5)) ^ fxx));
+    for (int ia = 0; ia < 4; ++ia)
+      tr_issue(afr[c][ia][0], afr[c][ia][1], lds0 + stage + h * 16384 + fbase + ((ua0 + ((mh * 4 + ia) << 5)) ^ fxx));
   };
-  auto ldB = [&](const unsigned char* stage, int h, int c, auto J0, auto J1) {
+  auto ldB = [&](unsigned stage, int h, int c, auto J0, auto J1) {
     int fxx = fx;
     asm volatile("" : "+v"(fxx));
 #pragma unroll
-    for (int jb = decltype(J0)::value; jb < decltype(J1)::value; ++jb) wf[c][jb] = tr2(stage + TN_ABYTES + h * 16384 + fbase + ((ub0 + (jb << 5)) ^ fxx));
+    for (int jb = decltype(J0)::value; jb < decltype(J1)::value; ++jb)
+      tr_issue(wfr[c][jb][0], wfr[c][jb][1], lds0 + stage + TN_ABYTES + h * 16384 + fbase + ((ub0 + (jb << 5)) ^ fxx));
   };
+  auto waitA = [&](int c) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(afr[c][0][0]), "+v"(afr[c][0][1]), "+v"(afr[c][1][0]), "+v"(afr[c][1][1]),
+                 "+v"(afr[c][2][0]), "+v"(afr[c][2][1]), "+v"(afr[c][3][0]), "+v"(afr[c][3][1]));
+  };
+  auto waitB = [&](int c) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wfr[c][0][0]), "+v"(wfr[c][0][1]), "+v"(wfr[c][1][0]), "+v"(wfr[c][1][1]),
+                 "+v"(wfr[c][2][0]), "+v"(wfr[c][2][1]), "+v"(wfr[c][3][0]), "+v"(wfr[c][3][1]));
+  };
+  auto frag = [&](const s16x4 (&f)[2]) { return __builtin_bit_cast(bf16x8, Frag2{f[0], f[1]}); };
   f32x4 acc[8][4];
   auto mma = [&](auto MH, int ca, int cw) {
     constexpr int mh = decltype(MH)::value;
@@ -110,9 +124,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
       for (int ia = 0; ia < 4; ++ia)
-        acc[mh * 4 + ia][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cw][jb], af[ca][ia], acc[mh * 4 + ia][jb], 0, 0, 0);
+        acc[mh * 4 + ia][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(wfr[cw][jb]), frag(afr[ca][ia]), acc[mh * 4 + ia][jb], 0, 0, 0);
   };
-  auto first_frags = [&](const unsigned char* stage) { ldA(stage, 0, IC<0>{}, 0); ldB(stage, 0, 0, IC<0>{}, IC<4>{}); };
+  auto first_frags = [&](unsigned stage) { ldA(stage, 0, IC<0>{}, 0); ldB(stage, 0, 0, IC<0>{}, IC<4>{}); };
   auto zero_acc = [&]() {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -143,27 +157,30 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   dma_step(smem);
   dma_step(smem + TN_STAGE);                   // nk >= 4 (vl_gemm_tn_supported): still inside work item 0
   dma_wait_and_barrier();
-  first_frags(smem);
+  first_frags(0u);
 
   int par = 0;
   bool pendB = false;
   auto kstep = [&](auto LAST) {
     constexpr bool last = decltype(LAST)::value;
-    unsigned char* cur = smem + par * TN_STAGE;
-    unsigned char* oth = smem + (par ^ 1) * TN_STAGE;
-    if (grpB && pendB) { dma_step(oth); pendB = false; }
+    const unsigned cur = par * TN_STAGE, oth = (par ^ 1) * TN_STAGE;
+    if (grpB && pendB) { dma_step(smem + oth); pendB = false; }
     __builtin_amdgcn_sched_barrier(0);
+    waitA(0); waitB(0);                                   // first fragments of this stage (issued behind the previous barrier)
     ldA(cur, 0, IC<1>{}, 1); ldB(cur, 1, 1, IC<0>{}, IC<2>{});
     mma(IC<0>{}, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+    waitA(1);
     ldA(cur, 1, IC<0>{}, 0); ldB(cur, 1, 1, IC<2>{}, IC<4>{});
     mma(IC<1>{}, 1, 0);
     __builtin_amdgcn_sched_barrier(0);
+    waitA(0); waitB(1);
     ldA(cur, 1, IC<1>{}, 1);
     mma(IC<0>{}, 0, 1);
     __builtin_amdgcn_sched_barrier(0);
+    waitA(1);
     dma_wait_and_barrier();
-    if (dti < my_tiles) { if (!grpB) dma_step(cur); else pendB = true; }
+    if (dti < my_tiles) { if (!grpB) dma_step(smem + cur); else pendB = true; }
     if constexpr (!last) first_frags(oth);
     __builtin_amdgcn_sched_barrier(0);
     mma(IC<1>{}, 1, 1);
@@ -208,7 +225,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
       }
       zero_acc();
-      if (ti + 1 < my_tiles) { tile_origin(ti + 1, cur_m0, cur_n0, cur_sp); first_frags(smem + par * TN_STAGE); }
+      if (ti + 1 < my_tiles) { tile_origin(ti + 1, cur_m0, cur_n0, cur_sp); first_frags((unsigned)(par * TN_STAGE)); }
     }
   }
 }
