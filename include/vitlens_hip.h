@@ -76,7 +76,8 @@ int vl_gemm_splitk_accum_f32(const void* A, const void* W, float* out, int M, in
                              float alpha, int splits, float* ws, hipStream_t stream);
 /* The same accumulate on TOKEN-MAJOR operands: out[M,N] f32 += alpha * At[K,M]^T . Bt[K,N], At = dY and Bt = X as the backward
  * holds them (row = token, row strides lda >= M, ldb >= N, multiples of 8) - no transposed copies.  M % 256 == N % 256 == 0,
- * K % 64 == 0, (K/64) % splits == 0 with >= 4 steps per slice; ws = splits*M*N floats.  Fragments come from gfx950's LDS
+ * K % 64 == 0; the K/64 steps are cut into slices of ceil(K/64/splits) (the last one may be shorter; every slice >= 4 steps);
+ * ws = splits*M*N floats.  Fragments come from gfx950's LDS
  * transpose read (csrc/vl_gemm_tn.hip).  Replaces the dW of nn.Linear / in_proj / out_proj under loss.backward()
  * (open_clip/transformer.py:215,226-234,252-272; training/train.py:212-216). */
 int vl_gemm_tn_splitk_accum_f32(const void* At, const void* Bt, float* out, int M, int N, int K, int lda, int ldb, long ldo,

@@ -19,7 +19,9 @@ def relerr(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("R,M,N", [(4096, 1024, 4096), (4096, 4096, 1024), (8192, 3072, 1024), (257 * 256, 1024, 4096)])
+@pytest.mark.parametrize("R,M,N", [(4096, 1024, 4096), (4096, 4096, 1024), (8192, 3072, 1024), (257 * 256, 1024, 4096),
+                                   (64 * 70, 4096, 1024),        # 70 steps in 4 slices of 18, 18, 18, 16
+                                   (257 * 256, 1024, 1024)])     # out_proj at the C3 micro-batch: 16 tiles x 16 slices of 65 ... 53 steps
 def test_small_integers_are_bit_exact(R, M, N):
     ops = _ops()
     g = torch.Generator().manual_seed(R + M)

@@ -894,14 +894,15 @@ extern "C" int vl_gemm_tn_splitk_accum_f32(const void* At, const void* Bt, float
   VL_CHECK_ARG((lda & 7) == 0 && (ldb & 7) == 0 && (ldo & 3) == 0 && lda >= M && ldb >= N, "vl_gemm_tn_splitk: lda/ldb % 8, ldo % 4, lda >= M, ldb >= N required");
   VL_CHECK_ARG(splits >= 1 && splits <= 1024 && ws, "vl_gemm_tn_splitk: 1 <= splits <= 1024 and a workspace of splits*M*N floats");
   const int nk = K >> 6;
-  VL_CHECK_ARG(nk % splits == 0 && nk / splits >= 4, "vl_gemm_tn_splitk: K/64 must be a multiple of splits with >= 4 steps per slice");
+  const int len = (nk + splits - 1) / splits, eff = (nk + len - 1) / len;      // slices of `len` 64-token steps; the last one may be shorter
+  VL_CHECK_ARG(len >= 4 && nk - (eff - 1) * len >= 4, "vl_gemm_tn_splitk: every K slice needs >= 4 steps of 64");
   GemmP p{};
   p.A = (const bf16_t*)At; p.W = (const bf16_t*)Bt; p.out = ws; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldb; p.ldo = N;
-  p.alpha = alpha; p.res_div = 1; p.split_stride = (long)M * N; p.ksplit_len = nk / splits;
+  p.alpha = alpha; p.res_div = 1; p.split_stride = (long)M * N; p.ksplit_len = len;
   VL_CHECK_ARG(vl_gemm_tn_supported(&p), "vl_gemm_tn_splitk: operands must be 16-byte aligned and a slice below 2 GB");
   hipError_t e = (hipError_t)vl_gemm_tn_launch(&p, num_cus(), stream);
   if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)M * (N >> 2) + 255) / 256)), dim3(256), 0, stream, ws, splits, M, N, out, ldo);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)M * (N >> 2) + 255) / 256)), dim3(256), 0, stream, ws, eff, M, N, out, ldo);
   e = hipGetLastError();
   if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
   return 0;

@@ -39,9 +39,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = 8, WTN = 64, NU = 4, SLAB = 4096;
   const int tiles_n = p.N >> 8, tiles_m = p.M >> 8;
-  const int nk = p.ksplit_len;                    // k-steps (64 tokens) per work item
+  const int nk_len = p.ksplit_len, nk_tot = p.K >> 6;        // k-steps (64 tokens) per slice (the last slice may be shorter), in all
   const int ntiles_mn = tiles_m * tiles_n;
-  const int ntiles = ntiles_mn * ((p.K >> 6) / nk);
+  const int ntiles = ntiles_mn * ((nk_tot + nk_len - 1) / nk_len);
+  auto steps_of = [&](int sp) { return min(nk_len, nk_tot - sp * nk_len); };
   const int G = gridDim.x;
   const int slot = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
   if (slot >= ntiles) return;
@@ -71,7 +72,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int a_kstep = p.lda * 128, b_kstep = p.ldw * 128;                     // bytes between k-steps (64 token rows)
   __amdgpu_buffer_rsrc_t rsA, rsB;
   auto make_rsrc = [&](int m0, int n0, int sp, __amdgpu_buffer_rsrc_t& ra, __amdgpu_buffer_rsrc_t& rb) {
-    const size_t t0 = (size_t)sp * nk * 64;
+    const size_t t0 = (size_t)sp * nk_len * 64;
     ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + t0 * p.lda + m0), 0, 0x7ffffff0, 0x00020000);
     rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + t0 * p.ldw + n0), 0, 0x7ffffff0, 0x00020000);
   };
@@ -138,6 +139,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   tile_origin(0, cur_m0, cur_n0, cur_sp);
   make_rsrc(cur_m0, cur_n0, cur_sp, rsA, rsB);
   __amdgpu_buffer_rsrc_t rsA_n = rsA, rsB_n = rsB;
+  int nk = steps_of(cur_sp);                     // steps of the work item being computed
+  int nk_dma = nk, nk_dma_n = nk;                // ... of the work item the DMA is in / of the one after it
   int dti = 0, dkt = 0;
   auto dma_step = [&](unsigned char* stage) {
     const int ka = dkt * a_kstep, kb = dkt * b_kstep;
@@ -147,7 +150,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(stage + TN_ABYTES + (i * NW + wid) * 1024), 16, voffB, kb + i * b_unit, 0, 0);
     }
     ++dkt;
-    if (dkt == nk) { dkt = 0; ++dti; rsA = rsA_n; rsB = rsB_n; }
+    if (dkt == nk_dma) { dkt = 0; ++dti; rsA = rsA_n; rsB = rsB_n; nk_dma = nk_dma_n; }
   };
   auto dma_wait_and_barrier = [&]() {          // see vl_gemm_park.hip: hipcc does not wait for the builtin's LDS writes
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -194,6 +197,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       int nm0, nn0, nsp;
       tile_origin(ti + 1, nm0, nn0, nsp);
       make_rsrc(nm0, nn0, nsp, rsA_n, rsB_n);
+      nk_dma_n = steps_of(nsp);
     }
     for (int kt = 0; kt < nk - 1; ++kt) kstep(std::false_type{});
     kstep(std::true_type{});
@@ -225,7 +229,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
       }
       zero_acc();
-      if (ti + 1 < my_tiles) { tile_origin(ti + 1, cur_m0, cur_n0, cur_sp); first_frags((unsigned)(par * TN_STAGE)); }
+      if (ti + 1 < my_tiles) { tile_origin(ti + 1, cur_m0, cur_n0, cur_sp); nk = steps_of(cur_sp); first_frags((unsigned)(par * TN_STAGE)); }
     }
   }
 }
@@ -239,7 +243,9 @@ bool vl_gemm_tn_supported(const void* params) {
   if ((p.M & 255) || (p.N & 255) || (p.K & 63) || p.M <= 0 || p.N <= 0 || p.K <= 0) return false;
   if ((p.lda & 7) || (p.ldw & 7) || (p.ldo & 3)) return false;
   const int nk = p.K >> 6;
-  if (p.ksplit_len < 4 || nk % p.ksplit_len) return false;       // the DMA runs two k-steps ahead: it must not leave work item 0 in the prologue
+  if (p.ksplit_len < 4 || p.ksplit_len > nk) return false;
+  const int last = nk - ((nk + p.ksplit_len - 1) / p.ksplit_len - 1) * p.ksplit_len;
+  if (last < 4) return false;                                      // the DMA runs two k-steps ahead: it must not leave a work item in its prologue
   if ((long)p.ksplit_len * 128 * (p.lda > p.ldw ? p.lda : p.ldw) >= (1L << 31)) return false;      // scalar byte offsets of a slice
   return !((((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.out) & 15));
 }
@@ -249,7 +255,7 @@ int vl_gemm_tn_launch(const void* params, int ncu, hipStream_t s) {
   auto kern = gemm_tn_kernel;
   static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS);   // thread-safe one-time init
   if (attr != hipSuccess) return (int)attr;
-  const int tiles = (p.M >> 8) * (p.N >> 8) * ((p.K >> 6) / p.ksplit_len);
+  const int tiles = (p.M >> 8) * (p.N >> 8) * (((p.K >> 6) + p.ksplit_len - 1) / p.ksplit_len);
   int G = ncu & ~7;
   if (tiles < G) G = (tiles + 7) & ~7;
   hipLaunchKernelGGL(kern, dim3(G), dim3(512), TN_LDS, s, p);
