@@ -176,8 +176,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   // ---- epilogue operands ----
   // chunk ci (0..15) = rows (ci>>2)*32 + (ci&3)*8 + (lane>>3) of the wave's sub-tile, columns (lane&7)*8 .. +7
   [[maybe_unused]] u32x4 aux[NCH];
-  const int prow = lane >> 3, pcol = (lane & 7) * 8;
-  const unsigned lo_out = (unsigned)((prow * p.ldo + pcol) * 2);     // lane part of an output / aux address (row-major outputs)
+  // (the epilogue's lane constants are derived at the START OF EVERY EPILOGUE from a laundered copy of the lane index: computed
+  // here they would be hoisted above the k-loop, live through it beside 128 accumulators + 64 fragment registers, and spill)
+  int prow = 0, pcol = 0;
+  unsigned lo_out = 0;                                               // lane part of an output / aux address (row-major outputs)
   const int ldo2 = p.ldo * 2;
   auto chunk_row = [](int ci) { return (ci >> 2) * 32 + (ci & 3) * 8; };
   [[maybe_unused]] const unsigned char* aux_src = nullptr;      // &aux[tile row 0 of this wave][tile col 0 of this wave] (current tile)
@@ -286,6 +288,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       // ---------------- tile finished: arithmetic, LDS transpose, one burst of 16-byte non-temporal stores ----------------
       const GemmP pe = reload_params();
       const int mrow0 = cur_m0 + wave_m * 128, ncol0 = cur_n0 + wave_n * WTN;
+      int el = lane;
+      asm volatile("" : "+v"(el));
+      prow = el >> 3; pcol = (el & 7) * 8;
+      lo_out = (unsigned)((prow * pe.ldo + pcol) * 2);
+      [[maybe_unused]] const int fr = el & 31, fg = el >> 5, fr16 = el & 15, fq = el >> 4;      // shadow the main loop's copies
       if constexpr (HAS_AUX) {
         load_pair(IC<0>{}); load_pair(IC<1>{}); load_pair(IC<2>{}); load_pair(IC<3>{});
         load_pair(IC<4>{}); load_pair(IC<5>{}); load_pair(IC<6>{}); load_pair(IC<7>{});
@@ -299,9 +306,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       // destination of this lane's chunks
       unsigned char* const out_base = (unsigned char*)pe.out + ((size_t)mrow0 * pe.ldo + ncol0) * 2 + lo_out;
       // GEGLU / DGEGLU lane offsets (other strides than the plain outputs)
-      [[maybe_unused]] const unsigned lo_half = (unsigned)((prow * pe.ldo + (lane & 7) * 4) * 2);        // GEGLU out: 4 values per lane
+      [[maybe_unused]] const unsigned lo_half = (unsigned)((prow * pe.ldo + (el & 7) * 4) * 2);        // GEGLU out: 4 values per lane
       [[maybe_unused]] const unsigned lo_pre = (unsigned)((prow * 2 * pe.ldo + pcol) * 2);               // GEGLU out2: stride 2 * ldo
-      [[maybe_unused]] const unsigned lo_h = (unsigned)((prow * pe.ldo + (lane & 7) * 16) * 2);           // DGEGLU h / out: 16 values per lane
+      [[maybe_unused]] const unsigned lo_h = (unsigned)((prow * pe.ldo + (el & 7) * 16) * 2);           // DGEGLU h / out: 16 values per lane
       [[maybe_unused]] u32x4 hx[2][8];                                                                  // DGEGLU: h of row block i (double buffered)
       [[maybe_unused]] const unsigned char* const hsrc = (const unsigned char*)pe.res + ((size_t)mrow0 * pe.ldo + 2 * ncol0) * 2 + lo_h;
       [[maybe_unused]] auto load_h = [&](auto BI, auto II) {
@@ -343,8 +350,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
               const int r = pass * 8 + prow;
-              const f32x4 w = *(const f32x4*)(slab + r * 128 + (((lane & 7) ^ (r & 7)) << 4));
-              __builtin_nontemporal_store(w, (f32x4*)(fout + (size_t)(i * 32 + r) * pe.ldo + j * 32 + (lane & 7) * 4));
+              const f32x4 w = *(const f32x4*)(slab + r * 128 + (((el & 7) ^ (r & 7)) << 4));
+              __builtin_nontemporal_store(w, (f32x4*)(fout + (size_t)(i * 32 + r) * pe.ldo + j * 32 + (el & 7) * 4));
             }
           }
         }
@@ -385,7 +392,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
           const int r = pass * 8 + prow;
-          u32x4 w = *(const u32x4*)(slab + r * 128 + (((lane & 7) ^ (r & 7)) << 4));
+          u32x4 w = *(const u32x4*)(slab + r * 128 + (((el & 7) ^ (r & 7)) << 4));
           [[maybe_unused]] u32x4 rr;
           if constexpr (HAS_AUX) rr = aux[i * 4 + pass];
           if constexpr (IS_GEGLU) {
