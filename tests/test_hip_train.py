@@ -204,6 +204,25 @@ def test_layernorm_backward_bf16_streams(rows, D):
     assert relerr(dxf, xr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("rows,D", [(50, 1024), (777, 1024), (1030, 768), (263, 72), (41, 100)])
+def test_layernorm_param_gradients_bf16_streams(rows, D):
+    """dgamma / dbeta from bf16 dy and bf16 x (the 16-byte kernel for D % 8 == 0, the per-column one otherwise), row counts that
+    are no multiple of the row lanes or of the 256-row slabs, accumulating into existing values."""
+    from vitlens_hip import ops
+    g = torch.Generator().manual_seed(rows + D)
+    x = (torch.randn(rows, D, generator=g) * 2 + 0.5).bfloat16().cuda()
+    dy = torch.randn(rows, D, generator=g).bfloat16().cuda()
+    w = torch.ones(D, device="cuda"); b = torch.zeros(D, device="cuda")
+    y = torch.empty(rows, D, device="cuda", dtype=torch.bfloat16)
+    mean = torch.empty(rows, device="cuda"); rstd = torch.empty(rows, device="cuda")
+    ops.layernorm(x, w, b, y, rows, D, mean=mean, rstd=rstd)
+    dw = torch.full((D,), 2.0, device="cuda"); db = torch.full((D,), -1.0, device="cuda")
+    ops.layernorm_bwd_params(dy, x, mean, rstd, dw, db, rows, D)
+    xh = (x.double() - mean.double()[:, None]) * rstd.double()[:, None]
+    assert relerr(dw, 2.0 + (dy.double() * xh).sum(0)) < 1e-5
+    assert relerr(db, -1.0 + dy.double().sum(0)) < 1e-5
+
+
 def test_adamw_matches_torch():
     from vitlens_hip import train as TR
     g = torch.Generator().manual_seed(7)
