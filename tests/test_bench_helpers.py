@@ -49,3 +49,31 @@ def test_committed_hbm_traffic_summary_matches_the_dominant_gemm():
     alg_fc = 2 * (65792 * 1024 + 4096 * 1024 + 65792 * 4096)
     assert alg_fc <= fc <= 2.2 * alg_fc and fc_save > fc + 0.9 * 2 * 65792 * 4096               # + the gelu' tensor
     assert bench.hbm_traffic({"M": 1, "N": 2, "K": 3, "epi": 0, "act": 0}) is None
+
+
+def test_traffic_summary_tells_two_gemm_shapes_of_one_kernel_apart(tmp_path):
+    """tools/traffic_summary.py: one template instance (`gemm_nt_pk_kernel<3, 0, true>`) serves c_proj (K = 4096) and out_proj
+    (K = 1024); "hi" / "lo" keep the launches above / below the midpoint of the kernel's FETCH_SIZE range, the corrections are
+    the guide's (KiB -> bytes, gfx950 doubling of wide reads), and the first spec becomes the file's headline entry."""
+    import csv
+    import subprocess
+    import sys
+    name = "void (anonymous namespace)::gemm_nt_pk_kernel<3, 0, true>((anonymous namespace)::GemmP)"
+    for c, vals in (("FETCH_SIZE", [100, 101, 400, 401, 402]), ("WRITE_SIZE", [50, 50, 60, 60, 60])):
+        d = tmp_path / c
+        d.mkdir()
+        with open(d / "x_counter_collection.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Kernel_Name", "Counter_Name", "Counter_Value"])
+            for v in vals:
+                w.writerow([name, c, v])
+    out = tmp_path / "o.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "traffic_summary.py"), str(tmp_path / "FETCH_SIZE"),
+                        str(tmp_path / "WRITE_SIZE"), str(out), "gemm_nt_pk_kernel<3, 0,|1,2,3|hi|3,0", "gemm_nt_pk_kernel<3, 0,|1,2,4|lo"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    t = json.load(open(out))
+    assert t["shape"] == [1, 2, 3] and t["epi"] == 3 and t["act"] == 0 and t["launches_sampled"] == 3
+    assert t["traffic_bytes_per_launch"] == 401 * 1024 * 2 + 60 * 1024
+    lo = t["shapes"][1]
+    assert lo["shape"] == [1, 2, 4] and lo["launches_sampled"] == 2 and lo["traffic_bytes_per_launch"] == 100.5 * 1024 * 2 + 50 * 1024
