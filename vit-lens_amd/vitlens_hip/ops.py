@@ -128,15 +128,24 @@ def gemm_dw_tn(dy, x, g, alpha=1.0):
         return False
     if dy.stride(0) % 8 or x.stride(0) % 8 or g.stride(0) % 4 or dy.data_ptr() % 16 or x.data_ptr() % 16 or tuple(g.shape) != (M, N):
         return False
-    nk, t256 = R // 64, (M // 256) * (N // 256)
-    for splits in (1, 2, 4, 8, 16):          # slices of ceil(nk / splits) steps: the last one may be shorter
+    splits = tn_splits(R // 64, (M // 256) * (N // 256))
+    if not splits:
+        return False
+    ws = torch.empty(splits * M * N, device=g.device, dtype=torch.float32)
+    check(_lib.vl_gemm_tn_splitk_accum_f32(_p(dy), _p(x), _p(g), M, N, R, dy.stride(0), x.stride(0), g.stride(0),
+                                           float(alpha), splits, _p(ws), _stream()))
+    return True
+
+
+def tn_splits(nk: int, tiles: int) -> int:
+    """K slices for the token-major dW kernel: the smallest of 1, 2, 4, 8, 16 that gives >= 192 work items (tiles x slices) with
+    >= 16 steps of 64 tokens per slice; slices are ceil(nk / splits) steps long, the last one may be shorter but not below the
+    4 steps the kernel's DMA look-ahead needs (vl_gemm_tn_splitk_accum_f32 checks the same).  0 = the shape does not fit."""
+    for splits in (1, 2, 4, 8, 16):
         ln = -(-nk // splits)
-        if t256 * splits >= 192 and nk // splits >= 16 and nk - (-(-nk // ln) - 1) * ln >= 4:
-            ws = torch.empty(splits * M * N, device=g.device, dtype=torch.float32)
-            check(_lib.vl_gemm_tn_splitk_accum_f32(_p(dy), _p(x), _p(g), M, N, R, dy.stride(0), x.stride(0), g.stride(0),
-                                                   float(alpha), splits, _p(ws), _stream()))
-            return True
-    return False
+        if tiles * splits >= 192 and nk // splits >= 16 and nk - (-(-nk // ln) - 1) * ln >= 4:
+            return splits
+    return 0
 
 
 def _bhld_strides(*views):
