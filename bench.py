@@ -60,6 +60,10 @@ def parse():
                          "recipe, out = model(image, text, visual_x); loss(**out).backward(); torch.optim.AdamW.step(); clamp")
     ap.add_argument("--gemm-cfg", type=int, default=-1)
     ap.add_argument("--bn-sync", action="store_true", help="c5 with --gpus N: SyncBatchNorm in the point tokenizer (--use-bn-sync)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="--gpus 1 only: initialise a ONE-rank RCCL communicator and run the step's multi-rank code path on it "
+                         "(packed all-gather, bucketed async all-reduce; prints collective_ms_per_step) - the API / stream "
+                         "contract of the exchange exercised on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="CPU-baseline sample: images (c2, default 48) / triplets per step (c3, default 8)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="default: one thread per physical core of the host")
@@ -452,15 +456,21 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from vitlens_hip import engine, ops
     timer = GemmTimer(ops); timer.install(engine)
     comm = None
-    if world > 1:
+    if use_dist:
         from vitlens_hip import step as _vstep
         comm = TimedComm(_vstep.TorchComm())
     res_dtype = torch.float32 if a.res_dtype == "f32" else torch.bfloat16
@@ -469,11 +479,11 @@ def main():
     if a.workload == "c2":
         sd = seeded_vitl_weights()
         eng = engine.VitEngine(sd, "image.", engine.TowerCfg(), dev, res_dtype=res_dtype, gemm_cfg=a.gemm_cfg)
-        gathered = torch.empty(world * a.batch, 768, device=dev) if world > 1 else None
+        gathered = torch.empty(world * a.batch, 768, device=dev) if use_dist else None
 
         def step():
             f = eng.encode_image(images, normalize=True)
-            if world > 1:
+            if use_dist:
                 dist.all_gather_into_tensor(gathered, f)        # one fused RCCL all-gather of [b,768]
             return f
     elif a.workload in ("c4", "c5"):
@@ -491,7 +501,8 @@ def main():
         if mod == "audio":
             audio = (torch.randn(a.batch, 512, 128, generator=g) * 0.5).to(dev)
             trainer = vstep.DualAudioStep(sd, tower_cfg, engine.TextCfg(), lens_cfg, dev, micro_batch=a.micro_batch,
-                                          rank=rank, world_size=world, gemm_cfg=a.gemm_cfg, frozen_res_dtype=res_dtype, train_res_dtype=res_dtype, comm=comm)
+                                          rank=rank, world_size=world, gemm_cfg=a.gemm_cfg, frozen_res_dtype=res_dtype, train_res_dtype=res_dtype, comm=comm,
+                                          force_comm=a.force_dist)
 
             def step():
                 return trainer.step(audio, texts)
@@ -502,7 +513,7 @@ def main():
             start = torch.randint(0, 8192, (a.batch,), generator=g).to(dev)
             trainer = vstep.TriModalPCStep(sd, tower_cfg, engine.TextCfg(), lens_cfg, dev, micro_batch=a.micro_batch,
                                            rank=rank, world_size=world, gemm_cfg=a.gemm_cfg, bn_training=True, frozen_res_dtype=res_dtype, train_res_dtype=res_dtype, comm=comm,
-                                           bn_sync=a.bn_sync)
+                                           bn_sync=a.bn_sync, force_comm=a.force_dist)
 
             def step():
                 return trainer.step(images, texts, pts, start)
@@ -539,7 +550,8 @@ def main():
         depths = torch.randn(a.batch, 1, 224, 224, generator=g).to(dev)
         texts = synth_text(a.batch, g).to(dev)
         trainer = vstep.TriModalDepthStep(sd, engine.TowerCfg(), engine.TextCfg(), dev, micro_batch=a.micro_batch,
-                                          unlock_first_n=4, rank=rank, world_size=world, gemm_cfg=a.gemm_cfg, frozen_res_dtype=res_dtype, train_res_dtype=res_dtype, comm=comm)
+                                          unlock_first_n=4, rank=rank, world_size=world, gemm_cfg=a.gemm_cfg, frozen_res_dtype=res_dtype, train_res_dtype=res_dtype, comm=comm,
+                                          force_comm=a.force_dist)
 
         def step():
             return trainer.step(images, texts, depths)
@@ -547,7 +559,7 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     timer.on = True
@@ -557,13 +569,13 @@ def main():
     for _ in range(a.steps):
         f = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timer.on = False
     per_rank_ms, coll = None, None
-    if world > 1:
+    if use_dist:
         comm.on = False
         coll = comm.summary(a.steps)
         allt = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
@@ -612,9 +624,10 @@ def main():
                                   f"micro-batches of {a.micro_batch}"}[a.workload]
                            + (", packed RCCL embedding all-gather + flat gradient all-reduce" if world > 1 else "")),
                           "global_batch": world * a.batch, "residual_dtype": a.res_dtype,
-                          "accumulate": "fp32", "parallelism": f"dp{world}", "gemm_cfg": a.gemm_cfg, "via": a.via},
+                          "accumulate": "fp32", "parallelism": f"dp{world}", "gemm_cfg": a.gemm_cfg, "via": a.via,
+                          **({"force_dist": True} if a.force_dist else {})},
                "roofline": roof}
-        if world > 1:        # diagnosis of a scaling run: per-rank step time (stragglers) and the exchange's share of the step
+        if use_dist:         # diagnosis of a scaling run: per-rank step time (stragglers) and the exchange's share of the step
             out["per_rank_ms_per_step"] = per_rank_ms
             out["collective_ms_per_step"] = coll
             out["collective_share"] = round(sum(coll.values()) / ms, 4) if coll else 0.0
@@ -631,7 +644,7 @@ def main():
             with open(a.detail, "w") as fh:
                 json.dump({"shapes": shapes, "ms_per_step": ms}, fh, indent=1)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,147 @@
+"""Worker of tests/test_hip_rccl_w1.py: ONE process, ONE GPU, a one-rank "nccl" (= RCCL) process group.
+
+Drives the fused training steps through the REAL `TorchComm` with `force_comm=True`, i.e. every collective of the
+multi-GPU path executes on the RCCL communicator (`all_gather_into_tensor`, `reduce_scatter_tensor` under
+gather_with_grad, the async per-block gradient buckets with their `wait()` ordering, the flat all-reduce, the
+SyncBatchNorm exchange), and compares with the same step built without a communicator.  At world size 1 every collective
+is the identity, so the two runs must agree BIT FOR BIT (SyncBatchNorm: its Chan-merge of one rank's statistics rounds
+differently from the one-rank kernel, tolerance 1e-5).
+
+Reference: training/distributed.py:95-108 (init_process_group env://), open_clip/loss.py:55-76 (gather_features).
+Prints one JSON line.  Run in its own process so that the process group does not leak into the pytest session."""
+import json
+import os
+import socket
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "vit-lens_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from golden_util import load_npz, split, specs_from_meta  # noqa: E402
+
+
+def cfgs(name):
+    from vitlens_hip import engine as E
+    sd, ins, outs, grads, meta = split(load_npz(name))
+    tower, text, lens = specs_from_meta(meta)
+    tc = E.TowerCfg(width=tower.width, layers=tower.layers, heads=tower.heads, patch=tower.patch,
+                    image_size=tower.image_size, embed_dim=tower.embed_dim)
+    xc = E.TextCfg(context_length=text.context_length, vocab_size=text.vocab_size, width=text.width, heads=text.heads,
+                   layers=text.layers, embed_dim=text.embed_dim)
+    lc = E.LensCfg(**{k: getattr(lens, k) for k in E.LensCfg.__dataclass_fields__ if hasattr(lens, k)})
+    return sd, ins, tc, xc, lc
+
+
+class CountingComm:
+    """The real TorchComm with a call log (which collectives ran, on how many elements)."""
+
+    def __init__(self):
+        from vitlens_hip.step import TorchComm
+        self.inner, self.log = TorchComm(), []
+
+    def all_gather(self, out, inp):
+        self.log.append(("all_gather", inp.numel())); return self.inner.all_gather(out, inp)
+
+    def all_reduce_sum(self, t):
+        self.log.append(("all_reduce", t.numel())); return self.inner.all_reduce_sum(t)
+
+    def reduce_scatter_sum(self, out, inp):
+        self.log.append(("reduce_scatter", inp.numel())); return self.inner.reduce_scatter_sum(out, inp)
+
+    def all_reduce_sum_async(self, t):
+        self.log.append(("all_reduce_async", t.numel())); return self.inner.all_reduce_sum_async(t)
+
+
+def run_case(recipe, local_loss, gather_with_grad, bn_sync=False):
+    from vitlens_hip import step as ST
+    name = {"depth": "tiny_depth.npz", "audio": "tiny_audio.npz", "pc": "tiny_pc.npz"}[recipe]
+    sd, ins, tc, xc, lc = cfgs(name)
+
+    def make(force, comm):
+        kw = dict(local_loss=local_loss, gather_with_grad=gather_with_grad, force_comm=force, comm=comm, lr=1e-3)
+        if recipe == "depth":
+            return ST.TriModalDepthStep(sd, tc, xc, "cuda", micro_batch=2, unlock_first_n=2, **kw)
+        if recipe == "audio":
+            return ST.DualAudioStep(sd, tc, xc, lc, "cuda", micro_batch=2, **kw)
+        return ST.TriModalPCStep(sd, tc, xc, lc, "cuda", micro_batch=4, bn_training=True, unlock_cls=True, bn_sync=bn_sync, **kw)
+
+    if recipe == "depth":
+        args = (ins["image"].cuda(), ins["text"].cuda(), ins["visual_x"].cuda())
+    elif recipe == "audio":
+        args = (ins["visual_x"].cuda(), ins["text"].cuda())
+    else:
+        args = (ins["image"].cuda(), ins["text"].cuda(), ins["visual_x"].cuda(), ins["fps_start"].cuda())
+
+    out = []
+    for force in (False, True):
+        comm = CountingComm() if force else None
+        st = make(force, comm)
+        l1 = st.forward_backward(*args)
+        grads = {k: v.clone() for k, v in st.reduced_grads().items()}
+        st.optimizer_step()
+        l2 = st.step(*args)                      # a second step: buckets re-armed, handles waited, operands refreshed
+        torch.cuda.synchronize()
+        out.append((float(l1), float(l2), grads, {k: v.clone() for k, v in st.masters.items()}, comm.log if comm else []))
+    (a1, a2, ga, ma, _), (b1, b2, gb, mb, log) = out
+    # local_loss computes the same loss from two one-directional b x B logit blocks instead of one symmetric matrix: equal in
+    # exact arithmetic, not bit for bit (dL/dlogits is rounded to bf16 per block) -> a tolerance there, and the first AdamW
+    # update (m / sqrt(v) = +-1 at step one) turns a sign flip of a near-zero gradient into 2 lr: masters not compared
+    tol = 3e-2 if local_loss else (1e-5 if bn_sync else 0.0)
+    worst = 0.0
+    for d0, d1 in ((ga, gb),) + (() if local_loss else ((ma, mb),)):
+        assert set(d0) == set(d1)
+        for k in d0:
+            x, y = d0[k].float(), d1[k].float()
+            assert torch.isfinite(y).all(), k
+            err = float((x - y).norm() / (x.norm() + 1e-30)) if local_loss else float((x - y).abs().max() / (x.abs().max() + 1e-30))
+            worst = max(worst, err)
+            assert err <= tol, (recipe, local_loss, gather_with_grad, bn_sync, k, err)
+    ltol = 1e-3 if local_loss else tol
+    assert abs(a1 - b1) <= ltol * max(1.0, abs(a1)) and abs(a2 - b2) <= max(ltol, 10 * tol) * max(1.0, abs(a2)), (a1, b1, a2, b2)
+    kinds = sorted({k for k, _ in log})
+    assert "all_gather" in kinds, kinds
+    if recipe == "depth":
+        assert "all_reduce_async" in kinds, kinds          # per-block gradient buckets (reverse layer order)
+    assert "all_reduce" in kinds, kinds
+    if gather_with_grad:
+        assert "reduce_scatter" in kinds, kinds
+    return {"recipe": recipe, "local_loss": local_loss, "gather_with_grad": gather_with_grad, "bn_sync": bn_sync,
+            "loss": b1, "worst_rel_diff": worst, "collectives": kinds, "calls": len(log)}
+
+
+def main():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    res = []
+    try:
+        for ll, gg in ((False, False), (False, True), (True, False), (True, True)):
+            res.append(run_case("depth", ll, gg))
+        res.append(run_case("audio", False, False))
+        res.append(run_case("audio", True, True))
+        res.append(run_case("pc", False, False))
+        res.append(run_case("pc", False, False, bn_sync=True))
+        # bare collectives on the communicator's stream against the compute stream: the packed gather is consumed by a
+        # kernel enqueued right behind it
+        x = torch.randn(8, 2304, device="cuda")
+        out = torch.empty(8, 2304, device="cuda")
+        dist.all_gather_into_tensor(out, x)
+        y = out * 2
+        assert torch.equal(y, x * 2)
+    finally:
+        dist.destroy_process_group()
+    print(json.dumps({"ok": True, "backend": "nccl", "cases": res}))
+
+
+if __name__ == "__main__":
+    main()

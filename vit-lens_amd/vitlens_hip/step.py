@@ -92,6 +92,11 @@ class _StepState:
     checkpointed, resumed, and handed back to `TriCLIP.load_state_dict` (training/train.py checkpoints `model.state_dict()`
     and `optimizer.state_dict()`)."""
 
+    @property
+    def dist(self) -> bool:
+        """The multi-rank code path is taken: there are peers, or `force_comm` asked for it on one rank."""
+        return self.world > 1 or getattr(self, "_force_comm", False)
+
     def state_dict(self) -> Dict[str, torch.Tensor]:
         out = {k: v.detach().clone() for k, v in self._base_sd.items()}
         cfg = getattr(self.lens, "lens", None)
@@ -216,7 +221,7 @@ def pair_backward(ctx, g: float = 1.0, need_dx=True, need_dy=True):
 
 
 def pair_loss_and_grads(comm, rank: int, world: int, xl, yl, ax, ay, scale: float, local_loss: bool = False,
-                        gather_with_grad: bool = False, need_x: bool = True, need_y: bool = True):
+                        gather_with_grad: bool = False, need_x: bool = True, need_y: bool = True, dist: Optional[bool] = None):
     """One (x, y) pair of ClipLossGeneral / TriClipLoss over the global batch (loss.py:116-138, 293-308) as rank `rank`
     computes it, and the gradients that arrive at THIS rank's features.
 
@@ -226,9 +231,13 @@ def pair_loss_and_grads(comm, rank: int, world: int, xl, yl, ax, ay, scale: floa
       gather_with_grad=False: peers are constants; the own slot of the gather is differentiable unless local_loss
                               (gather_features re-inserts the local tensor only then, loss.py:71-74).
       gather_with_grad=True : the gather is differentiable everywhere -> backward = reduce-scatter (sum over ranks).
+    dist: run the multi-rank code path (default: world > 1).  True at world 1 = every collective of the path executes on a
+    one-rank communicator (`force_comm` of the steps: the RCCL calls, their streams and their buffer contracts are exercised
+    on one GPU; the values are those of the single-rank path).
     Returns (loss[1], dxl | None, dyl | None, dscale[1])."""
     b = xl.shape[0]
-    if world > 1 and local_loss:
+    dist = world > 1 if dist is None else dist
+    if dist and local_loss:
         l1, c1 = pair_forward(xl, ay, scale, label_off=rank * b, w_row=0.5, w_col=0.0)
         l2, c2 = pair_forward(yl, ax, scale, label_off=rank * b, w_row=0.5, w_col=0.0)
         dxl, d_ay, ds1 = pair_backward(c1, need_dx=need_x, need_dy=need_y and gather_with_grad)
@@ -242,7 +251,7 @@ def pair_loss_and_grads(comm, rank: int, world: int, xl, yl, ax, ay, scale: floa
     def fold(dl, d_all):
         if d_all is None:
             return dl
-        if world == 1:
+        if not dist:
             g = d_all
         elif gather_with_grad:
             g = torch.empty(b, d_all.shape[1], device=d_all.device, dtype=d_all.dtype)
@@ -258,8 +267,11 @@ class TriModalDepthStep(_StepState):
                  unlock_first_n: int = 4, lr: float = 5e-4, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2,
                  rank: int = 0, world_size: int = 1, gemm_cfg: int = -1, comm=None, frozen_res_dtype=torch.float32,
                  local_loss: bool = False, gather_with_grad: bool = False, train_res_dtype=torch.float32,
-                 grad_checkpointing: bool = False):
+                 grad_checkpointing: bool = False, force_comm: bool = False):
         self.dev, self.mb, self.rank, self.world = torch.device(device), micro_batch, rank, world_size
+        # the multi-rank path (packed all-gather, bucketed async all-reduce, optional reduce-scatter) runs when there are
+        # peers - or when asked for on ONE rank, so that the RCCL calls execute on a single GPU (tests, bench --force-dist)
+        self._force_comm = bool(force_comm)
         self.grad_checkpointing = bool(grad_checkpointing)      # block recompute in the trainable tower (transformer.py:366-368)
         self.comm = comm or TorchComm()
         self.local_loss, self.gather_with_grad = local_loss, gather_with_grad
@@ -344,7 +356,7 @@ class TriModalDepthStep(_StepState):
         between (clipping, norm logging, accumulation over several forward_backward calls) calls this first;
         `optimizer_step()` does.  Idempotent; a no-op on one rank.  The values are SUMS: the 1/world of DDP's mean is
         applied inside the optimizer step (`grad_scale`)."""
-        if self.world == 1 or self._reduce_done:
+        if not self.dist or self._reduce_done:
             return
         for h in self._pending:
             h.wait()
@@ -365,7 +377,7 @@ class TriModalDepthStep(_StepState):
         return self.grads
 
     def optimizer_step(self):
-        if self.world > 1:
+        if self.dist:
             # DDP semantics: mean of per-rank gradients.  Block buckets were started during the last micro-batch's backward
             # (reverse layer order); what is left - logit_scale and the adapter, produced last - goes in one more call.
             self.finish_reduce()
@@ -389,7 +401,7 @@ class TriModalDepthStep(_StepState):
         return min(r[0] for r in rs), max(r[1] for r in rs)
 
     def _start_block_reduce(self, l):
-        if self.world > 1 and hasattr(self.comm, "all_reduce_sum_async"):
+        if self.dist and hasattr(self.comm, "all_reduce_sum_async"):
             lo, hi = self._block_range(l)
             self._pending.append(self.comm.all_reduce_sum_async(self.flat_grad[lo:hi]))
             self._reduced_upto = l
@@ -418,21 +430,21 @@ class TriModalDepthStep(_StepState):
             vraw[s] = self._trainer(i).forward(depths[s])
         ops.l2_normalize(vraw, out=fv, norms=vnorm)
         scale = float(self.logit_scale.exp())
-        if self.world > 1:
+        if self.dist:
             packed = torch.cat([fi, ft, fv], dim=1)
             allp = torch.empty(self.world * B, 3 * E, device=self.dev)
             self.comm.all_gather(allp, packed)                    # ONE exchange: [b, 3*768] per rank over xGMI
             ai, at, av = [t.contiguous() for t in allp.split(E, dim=1)]
         else:
             ai, at, av = fi, ft, fv
-        kw = dict(local_loss=self.local_loss, gather_with_grad=self.gather_with_grad, need_x=False)
+        kw = dict(local_loss=self.local_loss, gather_with_grad=self.gather_with_grad, need_x=False, dist=self.dist)
         l1, _, dv1, ds1 = pair_loss_and_grads(self.comm, self.rank, self.world, fi, fv, ai, av, scale, **kw)
         l2, _, dv2, ds2 = pair_loss_and_grads(self.comm, self.rank, self.world, ft, fv, at, av, scale, **kw)
         loss = l1 + l2
         dvraw = ops.l2_normalize_bwd(fv, dv1 + dv2, vnorm)
         for i in range(nmb):
             # gradients accumulate over micro-batches: a block's bucket is final once the LAST micro-batch has passed it
-            cb = self._start_block_reduce if (i == nmb - 1 and self.world > 1 and self.unlock_first_n > 0) else None
+            cb = self._start_block_reduce if (i == nmb - 1 and self.dist and self.unlock_first_n > 0) else None
             self._trainer(i).backward(dvraw[i * mb:(i + 1) * mb].contiguous(), cb)
         # logit_scale is exp()'d in forward (model.py:619): d/d(log-scale) = dscale * scale
         self.grads["logit_scale"] += (ds1 + ds2) * scale
@@ -444,8 +456,10 @@ class _PerceiverLensStep(_StepState):
     fp32 masters of the Perceiver under the reference's parameter names, one flat fp32 gradient buffer (a single
     all-reduce per step = DDP's mean of per-rank gradients), AdamW, bf16 operand refresh, logit-scale clamp."""
 
-    def _init_common(self, sd, device, micro_batch, rank, world_size, comm=None, local_loss=False, gather_with_grad=False):
+    def _init_common(self, sd, device, micro_batch, rank, world_size, comm=None, local_loss=False, gather_with_grad=False,
+                     force_comm=False):
         self.dev, self.mb, self.rank, self.world = torch.device(device), micro_batch, rank, world_size
+        self._force_comm = bool(force_comm)          # (see TriModalDepthStep)
         self.comm = comm or TorchComm()
         self.local_loss, self.gather_with_grad = local_loss, gather_with_grad
         self.trainers = []
@@ -542,7 +556,7 @@ class _PerceiverLensStep(_StepState):
         """Sum `flat_grad` over ranks (one collective, once per forward_backward).  Until this has run the gradients are
         rank-local; clipping / logging / accumulation code calls it (or `reduced_grads()`) before touching them.  The 1/world
         of DDP's mean is applied in the optimizer step."""
-        if self.world > 1 and not self._reduce_done:
+        if self.dist and not self._reduce_done:
             self.comm.all_reduce_sum(self.flat_grad)
             self._reduce_done = True
 
@@ -551,7 +565,7 @@ class _PerceiverLensStep(_StepState):
         return self.grads
 
     def optimizer_step(self):
-        if self.world > 1:
+        if self.dist:
             self.finish_reduce()
             self.opt.step(self.grads, grad_scale=1.0 / self.world)
         else:
@@ -569,9 +583,9 @@ class DualAudioStep(_PerceiverLensStep):
     def __init__(self, sd, tower: TowerCfg, text: TextCfg, lens: LensCfg, device, micro_batch: int = 256, lr: float = 2e-4,
                  betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2, rank: int = 0, world_size: int = 1,
                  gemm_cfg: int = -1, comm=None, frozen_res_dtype=torch.float32, local_loss: bool = False,
-                 gather_with_grad: bool = False, train_res_dtype=torch.float32):
+                 gather_with_grad: bool = False, train_res_dtype=torch.float32, force_comm: bool = False):
         from .train import AudioLensTrainer
-        self._init_common(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad)
+        self._init_common(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad, force_comm)
         self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
         self.lens = LensEngine(sd, "visual.", tower, lens, device, gemm_cfg=gemm_cfg, res_dtype=train_res_dtype)
         self._mk = lambda: AudioLensTrainer(self.lens)
@@ -599,14 +613,14 @@ class DualAudioStep(_PerceiverLensStep):
             vraw[s] = self._trainer(i).forward(audio[s])
         ops.l2_normalize(vraw, out=fv, norms=vnorm)
         scale = float(self.logit_scale.exp())
-        if self.world > 1:
+        if self.dist:
             allp = torch.empty(self.world * B, 2 * E, device=self.dev)
             self.comm.all_gather(allp, torch.cat([fv, ft], dim=1))
             av, at = [t.contiguous() for t in allp.split(E, dim=1)]
         else:
             av, at = fv, ft
         loss, dv, _, ds = pair_loss_and_grads(self.comm, self.rank, self.world, fv, ft, av, at, scale,    # ClipLossGeneral(x=visual, y=text)
-                                              local_loss=self.local_loss, gather_with_grad=self.gather_with_grad, need_y=False)
+                                              local_loss=self.local_loss, gather_with_grad=self.gather_with_grad, need_y=False, dist=self.dist)
         dvraw = ops.l2_normalize_bwd(fv, dv, vnorm)
         for i in range(nmb):
             self._trainer(i).backward(dvraw[i * mb:(i + 1) * mb].contiguous())
@@ -632,15 +646,15 @@ class TriModalPCStep(_PerceiverLensStep):
                  betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2, rank: int = 0, world_size: int = 1,
                  gemm_cfg: int = -1, bn_training: bool = True, unlock_cls: bool = False, comm=None,
                  frozen_res_dtype=torch.float32, local_loss: bool = False, gather_with_grad: bool = False,
-                 train_res_dtype=torch.float32, bn_sync: bool = False):
+                 train_res_dtype=torch.float32, bn_sync: bool = False, force_comm: bool = False):
         from .points import PointTokenizerTrainer
         from .train import PCLensTrainer
-        self._init_common(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad)
+        self._init_common(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad, force_comm)
         self.image = VitEngine(sd, "image.", tower, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
         self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
         self.lens = LensEngine(sd, "visual.", tower, lens, device, gemm_cfg=gemm_cfg, res_dtype=train_res_dtype)
         self.tok = PointTokenizerTrainer(sd, "visual.visual_adapter.", lens, device, gemm_cfg=gemm_cfg, bn_training=bn_training,
-                                         bn_sync=self.comm if bn_sync and world_size > 1 else None, world_size=world_size)
+                                         bn_sync=self.comm if bn_sync and self.dist else None, world_size=world_size)
         self._mk = lambda: PCLensTrainer(self.lens, self.tok, train_cls=unlock_cls)
         if unlock_cls:
             self.masters["visual.class_embedding"] = self.lens.vit.cls
@@ -672,13 +686,13 @@ class TriModalPCStep(_PerceiverLensStep):
             vraw[s] = self._trainer(i).forward(points[s], None if fps_start is None else fps_start[s])
         ops.l2_normalize(vraw, out=fv, norms=vnorm)
         scale = float(self.logit_scale.exp())
-        if self.world > 1:
+        if self.dist:
             allp = torch.empty(self.world * B, 3 * E, device=self.dev)
             self.comm.all_gather(allp, torch.cat([fi, ft, fv], dim=1))
             ai, at, av = [t.contiguous() for t in allp.split(E, dim=1)]
         else:
             ai, at, av = fi, ft, fv
-        kw = dict(local_loss=self.local_loss, gather_with_grad=self.gather_with_grad, need_x=False)
+        kw = dict(local_loss=self.local_loss, gather_with_grad=self.gather_with_grad, need_x=False, dist=self.dist)
         l1, _, dv1, ds1 = pair_loss_and_grads(self.comm, self.rank, self.world, fi, fv, ai, av, scale, **kw)
         l2, _, dv2, ds2 = pair_loss_and_grads(self.comm, self.rank, self.world, ft, fv, at, av, scale, **kw)
         dvraw = ops.l2_normalize_bwd(fv, dv1 + dv2, vnorm)
