@@ -200,6 +200,16 @@ int vl_geglu_bf16(const void* h, void* y, long rows, int n_out, hipStream_t stre
 int vl_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dO, const void* o, const long* strides,
                      const float* lse, float* delta, void* dq, void* dk, void* dv, long ld_dq, long ld_dkv,
                      int B, int H, int Lq, int Lk, int dh, float qscale, int causal, float scale, hipStream_t stream);
+/* ONE-kernel attention backward for self-attention that fits a workgroup (csrc/vl_attn_bwd_fused.hip, round 4): head dim 64,
+ * Lq == Lk == L, no causal mask, L <= 256 or L = 32 m + 1 <= 257.  Same operands and destinations as vl_attn_bwd_bf16
+ * (strides[15]); delta is computed while dO is staged (no workspace).  Every score tile is evaluated once: 5 matrix products
+ * and 16 exponentials per lane per 32x32 tile instead of 7 and 32.  Replaces the autograd of
+ * F.multi_head_attention_forward (open_clip/transformer.py:241-252) and of the Perceiver's latent self-attention
+ * (open_clip/perceiver.py:128-145).  vl_attn_bwd_fused_supported returns 1 when the fused entry takes the problem. */
+int vl_attn_bwd_fused_supported(int Lq, int Lk, int dh, int causal);
+int vl_attn_bwd_fused_bf16(const void* q, const void* k, const void* v, const void* dO, const void* o, const long* strides,
+                           const float* lse, void* dq, void* dk, void* dv, long ld_dq, long ld_dkv, int B, int H, int L, int dh,
+                           float qscale, float scale, hipStream_t stream);
 /* torch.optim.AdamW step on one tensor (grad is multiplied by grad_scale first); step counts from 1. */
 /* ---- point-cloud tokenizer (PointBERT grouping) ---- */
 /* farthest point sampling: xyz [B,N,3] f32, start [B] (the reference draws it with torch.randint, misc.py:60);

@@ -93,7 +93,34 @@ def test_vitl_block_backward_vs_oracle_autograd():
 def test_attention_backward(B, L, H, dh, causal):
     """dq / dk / dv (and the in-kernel delta) against autograd through explicit softmax attention on the same bf16 q, k, v,
     all operands read in place from token-major matrices.  257 / 33 = shared last query AND key row, 289 = two
-    workgroups per (b, h), 600 = several LDS chunks."""
+    workgroups per (b, h), 600 = several LDS chunks.  (The two-kernel path; the one-kernel backward: next test.)"""
+    _attention_backward_case(B, L, H, dh, causal, fused=False)
+
+
+@pytest.mark.parametrize("B,L,H,dh", [(2, 257, 4, 64), (1, 256, 2, 64), (2, 33, 2, 64), (3, 50, 12, 64), (2, 200, 2, 64), (1, 32, 1, 64),
+                                      (2, 129, 3, 64), (1, 7, 2, 64), (5, 225, 2, 64)])
+def test_attention_backward_fused(B, L, H, dh):
+    """The ONE-kernel backward (vl_attn_bwd_fused_bf16: every score tile evaluated once, dS handed to the query-owning wave
+    through LDS, transposed fragments by ds_read_b64_tr_b16, delta while staging) on every geometry it claims: the lone
+    class-token row (257, 33, 129, 225 = 32 m + 1), whole tiles (256, 32), ragged last tiles (50, 200, 7)."""
+    from vitlens_hip import ops
+    assert ops._lib.vl_attn_bwd_fused_supported(L, L, dh, 0) == 1
+    _attention_backward_case(B, L, H, dh, False, fused=True)
+
+
+def test_attention_backward_fused_refuses_what_it_does_not_take():
+    from vitlens_hip import ops
+    sup = ops._lib.vl_attn_bwd_fused_supported
+    assert sup(257, 257, 64, 0) == 1 and sup(256, 256, 64, 0) == 1 and sup(77, 77, 64, 0) == 1
+    assert sup(257, 257, 64, 1) == 0 and sup(257, 256, 64, 0) == 0 and sup(257, 257, 32, 0) == 0 and sup(289, 289, 64, 0) == 0
+    assert sup(258, 258, 64, 0) == 0 and sup(600, 600, 64, 0) == 0
+    x = torch.zeros(4, 64, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.attn_bwd(*[ops.heads_view(torch.zeros(2 * 300, 64, dtype=torch.bfloat16, device="cuda"), 2, 300, 1, 64)] * 5,
+                     torch.zeros(2, 1, 300, device="cuda"), None, x, x, x, 64, 64, fused=True)
+
+
+def _attention_backward_case(B, L, H, dh, causal, fused):
     from vitlens_hip import ops
     D = H * dh
     g = torch.Generator().manual_seed(5)
@@ -110,7 +137,7 @@ def test_attention_backward(B, L, H, dh, causal):
     delta = torch.full((B, H, L), float("nan"), device="cuda")
     dqkv = torch.full((B * L, 3 * D), float("nan"), dtype=torch.bfloat16, device="cuda")
     ops.attn_bwd(q, k, v, ops.heads_view(do_tok, B, L, H, dh), ops.heads_view(o, B, L, H, dh), lse, delta,
-                 dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D, 3 * D, causal=causal)
+                 dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D, 3 * D, causal=causal, fused=fused)
     # reference: autograd through explicit softmax attention; the kernels use q2 = bf16(q * qscale)
     qr = q.float().cpu().requires_grad_(True)
     kr = k.float().cpu().requires_grad_(True); vr = v.float().cpu().requires_grad_(True)
@@ -122,7 +149,8 @@ def test_attention_backward(B, L, H, dh, causal):
     (out * dO).sum().backward()
     tok = lambda t: t.permute(0, 2, 1, 3).reshape(B * L, D)
     assert torch.isfinite(dqkv.float()).all()
-    assert relerr(delta, (out.detach() * dO).sum(-1)) < 1e-2
+    if not fused:          # (the one-kernel backward keeps delta in LDS)
+        assert relerr(delta, (out.detach() * dO).sum(-1)) < 1e-2
     assert relerr(dqkv[:, :D], tok(qr.grad)) < 2e-2, relerr(dqkv[:, :D], tok(qr.grad))
     assert relerr(dqkv[:, D:2 * D], tok(kr.grad)) < 2e-2, relerr(dqkv[:, D:2 * D], tok(kr.grad))
     assert relerr(dqkv[:, 2 * D:], tok(vr.grad)) < 2e-2, relerr(dqkv[:, 2 * D:], tok(vr.grad))

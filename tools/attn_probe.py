@@ -44,5 +44,12 @@ fl = 4.0 * B * H * L * L * dh
 ms = t(lambda: ops.attn_fwd(q, k, v, o, lse=lse, qscale=qs))
 print(f"L={L} attn fwd   {ms:.3f} ms  {fl / ms / 1e9:.0f} TF/s")
 ms = t(lambda: ops.attn_bwd(q, k, v, dOv, ops.heads_view(o, B, L, H, dh), lse, delta,
-                            dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D, 3 * D))
+                            dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D, 3 * D, fused=False))
 print(f"L={L} attn bwd   {ms:.3f} ms  {2.5 * fl / ms / 1e9:.0f} TF/s (dq + delta, dkv kernels)")
+ref = dqkv.clone()
+if ops._lib.vl_attn_bwd_fused_supported(L, L, dh, 0) and os.environ.get("LAYOUT") != "bhld":
+    dqkv.fill_(float("nan"))
+    ms = t(lambda: ops.attn_bwd(q, k, v, dOv, ops.heads_view(o, B, L, H, dh), lse, None,
+                                dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D, 3 * D, fused=True))
+    err = float((dqkv.float() - ref.float()).norm() / ref.float().norm())
+    print(f"L={L} attn bwd   {ms:.3f} ms  {2.5 * fl / ms / 1e9:.0f} TF/s (ONE kernel; vs the two-kernel result: rel L2 {err:.2e})")

@@ -69,6 +69,8 @@ SIGNATURES = {
     "vl_gelu_bf16": [P, P, L, P],
     "vl_geglu_bf16": [P, P, L, I, P],
     "vl_attn_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, I, I, F, I, F, P],
+    "vl_attn_bwd_fused_supported": [I, I, I, I],
+    "vl_attn_bwd_fused_bf16": [P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, I, F, F, P],
     "vl_adamw_step": [P, P, P, P, L, F, F, F, F, F, I, F, P],
     "vl_clamp_scalar": [P, F, F, P],
     "vl_axpy_f32": [P, P, F, L, P],

@@ -368,14 +368,24 @@ def gelu_bf16(u, out):
     return out
 
 
-def attn_bwd(q, k, v, dO, o, lse, delta, dq, dk, dv, ld_dq, ld_dkv, causal=False, softmax_scale=None, qscale=None):
+def attn_bwd(q, k, v, dO, o, lse, delta, dq, dk, dv, ld_dq, ld_dkv, causal=False, softmax_scale=None, qscale=None, fused=None):
     """q, k, v, dO, o: strided [B,H,L,dh] bf16 views read in place (o = the forward's token-major output viewed by
-    heads_view); delta [B,H,Lq] f32 workspace (filled here); dq/dk/dv token-major destinations."""
+    heads_view); delta [B,H,Lq] f32 workspace (filled by the two-kernel path); dq/dk/dv token-major destinations.
+    fused: None = the one-kernel backward whenever the library takes the shape (vl_attn_bwd_fused_supported: head dim 64,
+    self-attention, no mask, L <= 257), True = insist on it (error otherwise), False = the two-kernel path."""
     B, H, Lq, dh = q.shape
     Lk = k.shape[2]
     scale = dh ** -0.5 if softmax_scale is None else softmax_scale
     qs = scale * LOG2E if qscale is None else qscale
     st = _bhld_strides(q, k, v, dO, o)
+    if fused is None:
+        fused = bool(_lib.vl_attn_bwd_fused_supported(Lq, Lk, dh, 1 if causal else 0))
+    if fused:
+        if Lq != Lk or causal:
+            raise ValueError("attn_bwd(fused=True): self-attention without a causal mask only")
+        check(_lib.vl_attn_bwd_fused_bf16(_p(q), _p(k), _p(v), _p(dO), _p(o), st, _p(lse), _p(dq), _p(dk), _p(dv),
+                                          ld_dq, ld_dkv, B, H, Lq, dh, float(qs), float(scale), _stream()))
+        return
     check(_lib.vl_attn_bwd_bf16(_p(q), _p(k), _p(v), _p(dO), _p(o), st, _p(lse), _p(delta), _p(dq), _p(dk), _p(dv),
                                 ld_dq, ld_dkv, B, H, Lq, Lk, dh, float(qs), 1 if causal else 0, float(scale), _stream()))
 
