@@ -52,5 +52,19 @@ int main(int argc, char** argv) {
                                     B, H, L, L, dh, qs, 0, 0.125f, 0); });
   report("bwd dq", prof, nwg, ms);
   report("bwd dkv", prof + (size_t)nwg * 8, nwg, ms);
+  if (vl_attn_bwd_fused_supported(L, L, dh, 0)) {
+    if (argc > 2 && atoi(argv[2]) == 1) {      // every (batch, head) reads the SAME operand rows: staging out of L2 (is the load phase HBM-bound?)
+      for (int i = 0; i < 15; i += 3) { st[i] = 0; st[i + 1] = 0; }
+      printf("(all items alias item 0's operands)\n");
+    }
+    ms = timed([&] { vl_attn_bwd_fused_bf16(qkv, qkv + D, qkv + 2 * D, dO, o, st, lse, dqkv, dqkv + D, dqkv + 2 * D, W, W, B, H, L, dh, qs, 0.125f, 0); });
+    std::vector<long> hh((size_t)nwg * 8);
+    hipMemcpy(hh.data(), prof, hh.size() * 8, hipMemcpyDeviceToHost);
+    double d[6] = {0, 0, 0, 0, 0, 0};
+    for (int w = 0; w < nwg; ++w)
+      for (int i = 0; i < 6; ++i) d[i] += (double)(hh[w * 8 + i + 1] - hh[w * 8 + i]);
+    printf("bwd ONE  %.3f ms | per WG: load+stage %.0f  barrier %.0f  lone row/col %.0f  tiles %.0f  lone finish %.0f  stores %.0f  = %.0f clk\n", ms,
+           d[0] / nwg, d[1] / nwg, d[2] / nwg, d[3] / nwg, d[4] / nwg, d[5] / nwg, (d[0] + d[1] + d[2] + d[3] + d[4] + d[5]) / nwg);
+  }
   return 0;
 }

@@ -52,6 +52,7 @@ struct FusedBwdP {
   float qscale, scale;
   int l_main;               // rows handled by tiles (L, or L - 1 when the last row is the lone one)
   int tail;                 // 1: row l_main is the lone row
+  VL_PROF_FIELD
 };
 
 __device__ __forceinline__ int fb_swz(int row) {
@@ -123,7 +124,32 @@ __device__ __forceinline__ float fb_dot8f(bf16x8 a, const float* v, float acc) {
   return acc;
 }
 
-__global__ void __launch_bounds__(512, 2) attn_bwd_fused_kernel(const FusedBwdP p) {
+#ifdef VL_ATTN_PROF
+#define FB_STAMP(p, i) do { if ((p).prof && threadIdx.x == 0) (p).prof[(size_t)item * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FB_STAMP(p, i) do { } while (0)
+#endif
+
+// Persistent: one workgroup per CU walks the (batch, head) items blockIdx.x, blockIdx.x + gridDim.x, ...  The 128 KB of
+// images leave no LDS for a second resident workgroup or a second stage, so the overlap of one item's memory round trip
+// with another's arithmetic comes from L2: as soon as an item is staged the workgroup touches one dword of every 128-byte
+// line of the NEXT item's q, k, v, dO, o rows (each row of a head is exactly one line) - those loads fill L2 / the
+// Infinity Cache while the tiles are computed, when HBM would otherwise idle (measured: every CU staging at once is
+// HBM-bound, 20 k of 53 k cycles per item).
+// (kernel arguments re-read from the kernarg segment per item through an opaque pointer: 40 scalars of strides and base
+//  pointers otherwise live across the whole item loop and spill)
+typedef const __attribute__((address_space(4))) FusedBwdP* FbKernargP;
+__device__ __forceinline__ FusedBwdP fb_reload_params() {
+  FusedBwdP r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  FbKernargP kp = (FbKernargP)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp));
+  __builtin_memcpy(&r, (const void*)kp, sizeof(FusedBwdP));
+#endif
+  return r;
+}
+
+__global__ void __launch_bounds__(512, 2) attn_bwd_fused_kernel(const FusedBwdP p0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sQ = smem;
   unsigned char* sG = smem + FB_IMG;                 // dO
@@ -131,15 +157,26 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_fused_kernel(const FusedBwdP 
   unsigned char* sE = smem + 3 * FB_IMG;             // [2][8] dS slots
   float* sNegL = (float*)(sE + 2 * 8 * FB_ESLOT);    // [264]  -lse * log2e   (-inf: padded rows)
   float* sNegD = sNegL + 264;                        // [264]  -delta         (0: padded rows)
-  float* sTail = sNegD + 264;                        // [4][64] the lone row of q * qscale (bf16-rounded), dO, k, v as floats
-  float* sVec = sTail + 4 * 64;                      // [8][2][32] per-wave scratch for the single-row MFMA operands
+  float* sTail = sNegD + 264;                        // [4][64] the lone row of q * qscale (bf16-rounded), dO, k, v as floats + [4][64] bf16
+  float* sVec = sTail + 4 * 64 + 128;                      // [8][2][32] per-wave scratch for the single-row MFMA operands
   float* sPart = sVec + 8 * 64;                      // [8][3][64] per-wave partial dq / dk / dv of the lone row
+  float* sDummy = sPart + 8 * 192;                   // [64] landing area of the next item's prefetch loads (never read)
 
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), nt = nthr >> 6;
+  const int nthr = blockDim.x, nt = nthr >> 6;
+  const int nitems = p0.B * p0.H;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+  if (item != (int)blockIdx.x) __syncthreads();      // the previous item's last LDS reads (lone-row finish) are done
+  const FusedBwdP p = fb_reload_params();
+  // (thread / wave indices re-derived from laundered copies per item: hoisted out of the item loop, the address arithmetic
+  //  of every fragment read stays live across the whole body and spills - 119 VGPRs when first tried)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
+  int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  asm volatile("" : "+s"(wid));
   const int fr = lane & 31, fg = lane >> 5;
-  const size_t bh = (size_t)b * p.H + h;
+  const int b = item / p.H, h = item - b * p.H;
+  const size_t bh = (size_t)item;
   const bf16_t* Qb = p.q.p + b * p.q.sb + h * p.q.sh;
   const bf16_t* Kb = p.k.p + b * p.k.sb + h * p.k.sh;
   const bf16_t* Vb = p.v.p + b * p.v.sb + h * p.v.sh;
@@ -149,6 +186,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_fused_kernel(const FusedBwdP 
   const int kidx = wid * 32 + fr;                    // this lane's key (dK / dV column) and query (dQ column)
   const int krow = kidx < lm ? kidx : lm - 1;
 
+  FB_STAMP(p, 0);
   // ---------------------------------------------------------------- staging: one memory round trip for the workgroup
   // K / V rows of this lane as MFMA column operands
   bf16x8 kf[4], vf[4];
@@ -212,65 +250,147 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_fused_kernel(const FusedBwdP 
   if (p.tail && wid == 0) {
     sTail[lane] = bf2f(f2bf(tq * p.qscale));       // bf16-rounded like the staged q
     sTail[64 + lane] = tg; sTail[128 + lane] = tk; sTail[192 + lane] = tv;
+    bf16_t* tb16 = (bf16_t*)(sTail + 256);
+    tb16[lane] = f2bf(tq * p.qscale); tb16[64 + lane] = f2bf(tg); tb16[128 + lane] = f2bf(tk); tb16[192 + lane] = f2bf(tv);
     const float dT = wave_sum_dpp(tg * to);
     if (lane == 0) { sNegL[lm] = -tlse * FB_LOG2E; sNegD[lm] = -dT; }
   }
+  FB_STAMP(p, 1);
   __syncthreads();
+  FB_STAMP(p, 2);
+  if (item + (int)gridDim.x < nitems && tid < p.L) {
+    // touch the next item's lines (fire and forget: the values are never read; the loads retire under the tile loop)
+    const int nb = (item + gridDim.x) / p.H, nh = (item + gridDim.x) - nb * p.H;
+    const bf16_t* a0 = p.q.p + nb * p.q.sb + nh * p.q.sh + (long)tid * p.q.sr;
+    const bf16_t* a1 = p.k.p + nb * p.k.sb + nh * p.k.sh + (long)tid * p.k.sr;
+    const bf16_t* a2 = p.v.p + nb * p.v.sb + nh * p.v.sh + (long)tid * p.v.sr;
+    const bf16_t* a3 = p.dO.p + nb * p.dO.sb + nh * p.dO.sh + (long)tid * p.dO.sr;
+    const bf16_t* a4 = p.o.p + nb * p.o.sb + nh * p.o.sh + (long)tid * p.o.sr;
+    // LDS-DMA into a 256-byte dummy area: no destination registers (a plain load's VGPR could be re-allocated before the
+    // data arrives), and, written as inline assembly, no compiler-inserted vmcnt(0) in front of the tile loop's LDS reads
+    unsigned m0s;
+    const unsigned dummy = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)sDummy;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                 "global_load_lds_dword %1, off\n\tglobal_load_lds_dword %2, off\n\tglobal_load_lds_dword %3, off\n\t"
+                 "global_load_lds_dword %4, off\n\tglobal_load_lds_dword %5, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0s) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "s"(dummy) : "memory");
+  }
 
   // ---------------------------------------------------------------- tiles
+  // Fragment addresses.  The instruction mix of a step is 20 MFMAs against ~70 VALU instructions only if the LDS addresses cost
+  // (almost) nothing: left to the compiler, row * 128 + ((chunk ^ swz(row)) << 4) for 34 reads per step was ~180 VALU
+  // instructions and the loop ran VALU-bound (2.7 k cycles per step against 1.3 k of MFMA time per SIMD).  Every address
+  // below is ONE lane constant (byte offset inside a 32-row tile) + the tile base, and its variants are XORs with small
+  // constants (a tile base is a multiple of 32 rows, so the swizzle does not depend on it):
+  //   row fragment (row fr, d-slice ks)             aRows ^ ks*32
+  //   dO^T / Q^T (rows 16c + 4fg + 8hi + (li>>2))   (aTr ^ hi*32 ^ t2*64) + c*2048 + hi*1024
+  //   K^T        (rows 16c + 8fg + 4hi + (li>>2))   (aTrK ^ hi*16 ^ t2*64) + c*2048 + hi*512
+  //   dS slot read (keys 16c + 8fg + 4hi + (li>>2)) (aErd ^ hi*32) + c*1024 + hi*256;   write (key fr, group g): aEwr ^ g*16
+  const int li = lane & 15, cbl = (lane >> 4) & 1, lb3 = (li >> 3) & 1;
+  const unsigned cch = (unsigned)(cbl * 2 + ((li >> 1) & 1)), hb = (unsigned)((li & 1) << 3);
+  const unsigned aRows = (unsigned)(fr * 128 + ((fg ^ fb_swz(fr)) << 4));
+  const unsigned aTr = (unsigned)((fg * 4 + (li >> 2)) * 128) + ((cch ^ (unsigned)((lb3 << 2) | fg)) << 4) + hb;
+  const unsigned aTrK = (unsigned)((fg * 8 + (li >> 2)) * 128) + ((cch ^ (unsigned)((lb3 << 2) | (fg << 1))) << 4) + hb;
+  const unsigned aErd = (unsigned)((fg * 8 + (li >> 2)) * 64) + ((cch ^ (unsigned)lb3) << 4) + hb;
+  const unsigned aEwr = (unsigned)(fr * 64 + fg * 8 + (((fr >> 1) & 3) << 4));
+  auto ld16 = [&](unsigned off) { return *(const bf16x8*)(smem + off); };
+  auto ldtr = [&](unsigned lo, unsigned hi) {
+    FbFrag2 f;
+    f.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fb_lds_s16x4)(smem + lo));
+    f.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fb_lds_s16x4)(smem + hi));
+    return __builtin_bit_cast(bf16x8, f);
+  };
+  // transposed fragment of image `img` (byte offset of sQ / sG): tile base tb (bytes), 16-row slice c, 32-column half t2
+  auto trQG = [&](unsigned img, unsigned tb, int c, int t2) {
+    const unsigned a = (aTr + tb) ^ (unsigned)(t2 * 64);
+    return ldtr(img + a + c * 2048, img + (a ^ 32u) + c * 2048 + 1024);
+  };
+  auto trK = [&](unsigned tb, int c, int t2) {
+    const unsigned a = (aTrK + tb) ^ (unsigned)(t2 * 64);
+    return ldtr(2 * FB_IMG + a + c * 2048, 2 * FB_IMG + (a ^ 16u) + c * 2048 + 512);
+  };
+
   f32x16 dk[2], dv[2], dq[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) { dk[t] = zero16(); dv[t] = zero16(); dq[t] = zero16(); }
   float* myVec = sVec + wid * 64;
   float* myPart = sPart + wid * 192;
   const bool key_ok = kidx < lm;
+  const bool ragged = (lm & 31) != 0 && wid == nt - 1;        // the last key tile has padded keys (wave-uniform)
 
   if (p.tail) {
     // ================= the lone row / column (class token of a 257-token sequence), before the tile loop =================
-    const int q0 = wid * 32;
-    // ---- the lone key (column lm) against this wave's OWN query tile: lane = query row fr ----
-    float sc = 0.f, dc = 0.f;
+    // Scores through the matrix pipe too: the lone key is column 0 of a column operand that is zero elsewhere (its 32 scores
+    // against this wave's query tile land in lanes 0 and 32), the lone query row 0 of a row operand (its scores against this
+    // wave's keys land in slot 0 of lanes 0-31).  (First version: VALU dot products, 7 k of 50 k cycles per item.)
+    const unsigned tb = (unsigned)(wid * 4096);
+    const bf16_t* sTailB = (const bf16_t*)(sTail + 256);       // the four lone rows as bf16 (q2, dO, k, v)
+    {
+      f32x16 sc, dc;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      sc = fb_dot8f(fb_rows(sQ, q0 + fr, ks, fg), sTail + 128 + ks * 16 + fg * 8, sc);
-      dc = fb_dot8f(fb_rows(sG, q0 + fr, ks, fg), sTail + 192 + ks * 16 + fg * 8, dc);
-    }
-    sc = xhalf_sum(sc); dc = xhalf_sum(dc);
-    const float pc = __builtin_amdgcn_exp2f(sc + sNegL[q0 + fr]);          // padded query rows: -inf -> 0
-    const float dsc = pc * (dc + sNegD[q0 + fr]);
-    // dQ[q, :] += dS[q, lm] * K[lm, :]
+      for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 l4 = *(const f32x4*)(sNegL + wid * 32 + qd * 8 + fg * 4);
+        const f32x4 d4 = *(const f32x4*)(sNegD + wid * 32 + qd * 8 + fg * 4);
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 k4 = *(const f32x4*)(sTail + 128 + t2 * 32 + g * 8 + fg * 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dq[t2][g * 4 + e] = fmaf(dsc, k4[e], dq[t2][g * 4 + e]);
+        for (int e = 0; e < 4; ++e) { sc[qd * 4 + e] = l4[e]; dc[qd * 4 + e] = d4[e]; }
       }
-    // dV[lm, :] += sum_q P[q, lm] dO[q, :],  dK[lm, :] += sum_q dS[q, lm] Q2[q, :]: single-row MFMAs
-    if (fg == 0) { myVec[fr] = pc; myVec[32 + fr] = dsc; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kT = fr == 0 ? *(const bf16x8*)(sTailB + 128 + ks * 16 + fg * 8) : zero_bf8();
+        const bf16x8 vT = fr == 0 ? *(const bf16x8*)(sTailB + 192 + ks * 16 + fg * 8) : zero_bf8();
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld16((aRows + tb) ^ (unsigned)(ks * 32)), kT, sc, 0, 0, 0);
+        dc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld16(FB_IMG + ((aRows + tb) ^ (unsigned)(ks * 32))), vT, dc, 0, 0, 0);
+      }
+      if (fr == 0) {       // column 0: queries (r&3) + 8*(r>>2) + 4*fg of the tile
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 pq, dq4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { pq[e] = __builtin_amdgcn_exp2f(sc[g * 4 + e]); dq4[e] = pq[e] * dc[g * 4 + e]; }
+          *(f32x4*)(myVec + g * 8 + fg * 4) = pq;
+          *(f32x4*)(myVec + 32 + g * 8 + fg * 4) = dq4;
+        }
+      }
+    }
     fb_wave_lds_sync();
+    {
+      // dQ[q, :] += dS[q, lm] * K[lm, :]
+      const float dsc = myVec[32 + fr];
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 k4 = *(const f32x4*)(sTail + 128 + t2 * 32 + g * 8 + fg * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dq[t2][g * 4 + e] = fmaf(dsc, k4[e], dq[t2][g * 4 + e]);
+        }
+    }
+    // dV[lm, :] += sum_q P[q, lm] dO[q, :],  dK[lm, :] += sum_q dS[q, lm] Q2[q, :]: single-row MFMAs
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
       f32x16 av = zero16(), ak = zero16();
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const int rlo = q0 + c * 16 + fg * 4, cb = t2 * 2 + ((lane >> 4) & 1);
-        av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_row0_perm(myVec, c, fr, fg), fb_tr(sG, rlo, rlo + 8, cb, lane), av, 0, 0, 0);
-        ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_row0_perm(myVec + 32, c, fr, fg), fb_tr(sQ, rlo, rlo + 8, cb, lane), ak, 0, 0, 0);
+        av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_row0_perm(myVec, c, fr, fg), trQG(FB_IMG, tb, c, t2), av, 0, 0, 0);
+        ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_row0_perm(myVec + 32, c, fr, fg), trQG(0, tb, c, t2), ak, 0, 0, 0);
       }
       if (fg == 0) { myPart[128 + t2 * 32 + fr] = av[0]; myPart[64 + t2 * 32 + fr] = ak[0]; }
     }
-    // ---- the lone query (row lm) against this wave's key tile: lane = key fr ----
-    float sr = 0.f, dr = 0.f;
+    // ---- the lone query (row lm) against this wave's key tile: row 0 of the products, lane = key fr ----
+    float pr, dsr;
+    {
+      f32x16 sr = zero16(), dr = zero16();
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      sr = fb_dot8f(kf[ks], sTail + ks * 16 + fg * 8, sr);
-      dr = fb_dot8f(vf[ks], sTail + 64 + ks * 16 + fg * 8, dr);
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 qT = fr == 0 ? *(const bf16x8*)(sTailB + ks * 16 + fg * 8) : zero_bf8();
+        const bf16x8 gT = fr == 0 ? *(const bf16x8*)(sTailB + 64 + ks * 16 + fg * 8) : zero_bf8();
+        sr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT, kf[ks], sr, 0, 0, 0);
+        dr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gT, vf[ks], dr, 0, 0, 0);
+      }
+      const float p0v = fg == 0 ? __builtin_amdgcn_exp2f(sr[0] + sNegL[lm]) : 0.f;
+      const float d0v = fg == 0 ? p0v * (dr[0] + sNegD[lm]) : 0.f;
+      pr = xhalf_sum(p0v); dsr = xhalf_sum(d0v);                // both halves of the wave hold their key's values
     }
-    sr = xhalf_sum(sr); dr = xhalf_sum(dr);
-    const float pr = key_ok ? __builtin_amdgcn_exp2f(sr + sNegL[lm]) : 0.f;
-    const float dsr = pr * (dr + sNegD[lm]);
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -291,124 +411,112 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_fused_kernel(const FusedBwdP 
     for (int t2 = 0; t2 < 2; ++t2) {
       f32x16 aq = zero16();
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int klo = wid * 32 + c * 16 + fg * 8;
-        aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_row0_nat(myVec, c, fr, fg),
-                                                     fb_tr(sK, klo, klo + 4, t2 * 2 + ((lane >> 4) & 1), lane), aq, 0, 0, 0);
-      }
+      for (int c = 0; c < 2; ++c)
+        aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_row0_nat(myVec, c, fr, fg), trK(tb, c, t2), aq, 0, 0, 0);
       if (fg == 0) myPart[t2 * 32 + fr] = aq[0];
     }
   }
 
+  FB_STAMP(p, 3);
+  int qi = wid, kj = wid;                            // (wid + t) mod nt, (wid - t) mod nt
   for (int t = 0; t < nt; ++t) {
-    const int qi = (wid + t) % nt;                  // query tile of this step (wave-uniform)
-    const int q0 = qi * 32;
+    const unsigned tb = (unsigned)(qi * 4096);       // byte offset of the step's 32 query rows in the images
     // rows of the accumulators = queries (r&3) + 8*(r>>2) + 4*fg of the tile; column = this lane's key
     f32x16 s, dp;
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
-      const f32x4 l4 = *(const f32x4*)(sNegL + q0 + qd * 8 + fg * 4);
-      const f32x4 d4 = *(const f32x4*)(sNegD + q0 + qd * 8 + fg * 4);
+      const f32x4 l4 = *(const f32x4*)(sNegL + qi * 32 + qd * 8 + fg * 4);
+      const f32x4 d4 = *(const f32x4*)(sNegD + qi * 32 + qd * 8 + fg * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { s[qd * 4 + e] = l4[e]; dp[qd * 4 + e] = d4[e]; }
     }
+    {
+      const unsigned aR = aRows + tb;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_rows(sQ, q0 + fr, ks, fg), kf[ks], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_rows(sG, q0 + fr, ks, fg), vf[ks], dp, 0, 0, 0);
+      for (int ks = 0; ks < 4; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld16(aR ^ (unsigned)(ks * 32)), kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld16(FB_IMG + (aR ^ (unsigned)(ks * 32))), vf[ks], dp, 0, 0, 0);
+      }
     }
     // transposed fragments (dO^T, Q^T) of the first 16-query slice, requested ahead of the exponentials
-    const int cbl = (lane >> 4) & 1;
     bf16x8 gt0[2], qt0[2];
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2) {
-      const int rlo = q0 + fg * 4;
-      gt0[t2] = fb_tr(sG, rlo, rlo + 8, t2 * 2 + cbl, lane);
-      qt0[t2] = fb_tr(sQ, rlo, rlo + 8, t2 * 2 + cbl, lane);
+    for (int t2 = 0; t2 < 2; ++t2) { gt0[t2] = trQG(FB_IMG, tb, 0, t2); qt0[t2] = trQG(0, tb, 0, t2); }
+    if (ragged) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = key_ok ? s[r] : -INFINITY;
     }
     float pv[16], ds[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      pv[r] = key_ok ? __builtin_amdgcn_exp2f(s[r]) : 0.f;        // (padded query rows carry -inf: p = 0)
-      ds[r] = pv[r] * dp[r];
-    }
-    // dS tile -> slot [t & 1][wid] as [key][query] bf16 for the owner of these queries
+    for (int r = 0; r < 16; ++r) { pv[r] = __builtin_amdgcn_exp2f(s[r]); ds[r] = pv[r] * dp[r]; }     // (padded query rows carry -inf: p = 0)
+    const bf16x8 pf0 = pack8(pv), df0 = pack8(ds), pf1 = pack8(pv + 8), df1 = pack8(ds + 8);
+    // dS tile -> slot [t & 1][wid] as [key][query] bf16 for the owner of these queries (the packed MFMA operands are the rows)
     {
-      unsigned char* slot = sE + ((t & 1) * 8 + wid) * FB_ESLOT + fr * 64 + fg * 8;
-      const int sw = (fr >> 1) & 3;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u32x2 w; w[0] = pack2bf(ds[g * 4], ds[g * 4 + 1]); w[1] = pack2bf(ds[g * 4 + 2], ds[g * 4 + 3]);
-        *(u32x2*)(slot + ((g ^ sw) << 4)) = w;
-      }
+      const unsigned sb = (unsigned)(3 * FB_IMG + ((t & 1) * 8 + wid) * FB_ESLOT) + aEwr;
+      const u32x4 w0 = __builtin_bit_cast(u32x4, df0), w1 = __builtin_bit_cast(u32x4, df1);
+      *(u32x2*)(smem + sb) = u32x2{w0[0], w0[1]};
+      *(u32x2*)(smem + (sb ^ 16u)) = u32x2{w0[2], w0[3]};
+      *(u32x2*)(smem + (sb ^ 32u)) = u32x2{w1[0], w1[1]};
+      *(u32x2*)(smem + (sb ^ 48u)) = u32x2{w1[2], w1[3]};
     }
     bf16x8 gt1[2], qt1[2];
 #pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) { gt1[t2] = trQG(FB_IMG, tb, 1, t2); qt1[t2] = trQG(0, tb, 1, t2); }
+#pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
-      const int rlo = q0 + 16 + fg * 4;
-      gt1[t2] = fb_tr(sG, rlo, rlo + 8, t2 * 2 + cbl, lane);
-      qt1[t2] = fb_tr(sQ, rlo, rlo + 8, t2 * 2 + cbl, lane);
+      dv[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt0[t2], pf0, dv[t2], 0, 0, 0);
+      dk[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt0[t2], df0, dk[t2], 0, 0, 0);
     }
-    {
-      const bf16x8 pf = pack8(pv), df = pack8(ds);
 #pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        dv[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt0[t2], pf, dv[t2], 0, 0, 0);
-        dk[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt0[t2], df, dk[t2], 0, 0, 0);
-      }
-    }
-    {
-      const bf16x8 pf = pack8(pv + 8), df = pack8(ds + 8);
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        dv[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt1[t2], pf, dv[t2], 0, 0, 0);
-        dk[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt1[t2], df, dk[t2], 0, 0, 0);
-      }
+    for (int t2 = 0; t2 < 2; ++t2) {
+      dv[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt1[t2], pf1, dv[t2], 0, 0, 0);
+      dk[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt1[t2], df1, dk[t2], 0, 0, 0);
     }
     __syncthreads();                                 // every dS tile of this step is in its slot
     // ---- dQ of this wave's queries: the tile produced by the owner of keys (wid - t) mod nt ----
     {
-      const int kj = (wid - t + nt) % nt;
-      const unsigned char* slot = sE + ((t & 1) * 8 + kj) * FB_ESLOT;
+      const unsigned sb = (unsigned)(3 * FB_IMG + ((t & 1) * 8 + kj) * FB_ESLOT) + aErd;
+      const unsigned kb = (unsigned)(kj * 4096);
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const bf16x8 dst = fb_tr_e(slot, c * 16 + fg * 8, c * 16 + fg * 8 + 4, lane);
+        const bf16x8 dst = ldtr(sb + c * 1024, (sb ^ 32u) + c * 1024 + 256);
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-          const int klo = kj * 32 + c * 16 + fg * 8;
-          dq[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_tr(sK, klo, klo + 4, t2 * 2 + cbl, lane), dst, dq[t2], 0, 0, 0);
-        }
+        for (int t2 = 0; t2 < 2; ++t2) dq[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trK(kb, c, t2), dst, dq[t2], 0, 0, 0);
       }
     }
+    qi = qi + 1 == nt ? 0 : qi + 1;
+    kj = kj == 0 ? nt - 1 : kj - 1;
   }
 
+  FB_STAMP(p, 4);
   // ---------------------------------------------------------------- results
   const float ln2 = 0.6931471805599453f;
+  if (p.tail && wid == 0) {
+    // the lone row: the waves' partial sums were complete before the first barrier of the tile loop
+    const int d = lane;
+    float aq = 0.f, ak = 0.f, av = 0.f;
+    for (int w = 0; w < nt; ++w) { aq += sPart[w * 192 + d]; ak += sPart[w * 192 + 64 + d]; av += sPart[w * 192 + 128 + d]; }
+    // ... and the lone row against itself
+    const float q2 = sTail[d], gT = sTail[64 + d], kT = sTail[128 + d], vT = sTail[192 + d];
+    const float sT = wave_sum_dpp(q2 * kT), dT = wave_sum_dpp(gT * vT);
+    const float pT = __builtin_amdgcn_exp2f(sT + sNegL[lm]);
+    const float dsT = pT * (dT + sNegD[lm]);
+    aq = fmaf(dsT, kT, aq); ak = fmaf(dsT, q2, ak); av = fmaf(pT, gT, av);
+    const size_t row = (size_t)b * p.L + lm;
+    p.dq[row * p.ld_dq + h * 64 + d] = f2bf(aq * p.scale);
+    p.dk[row * p.ld_dkv + h * 64 + d] = f2bf(ak * ln2);
+    p.dv[row * p.ld_dkv + h * 64 + d] = f2bf(av);
+  }
+  FB_STAMP(p, 5);
   const size_t orow = (size_t)b * p.L + krow;
   store_rows_t<2>(dk, ln2, p.dk + orow * p.ld_dkv + h * 64, fg, key_ok, 8);
   store_rows_t<2>(dv, 1.f, p.dv + orow * p.ld_dkv + h * 64, fg, key_ok, 8);
   store_rows_t<2>(dq, p.scale, p.dq + orow * p.ld_dq + h * 64, fg, key_ok, 8);
-  if (p.tail) {
-    __syncthreads();
-    if (wid == 0) {
-      const int d = lane;
-      float aq = 0.f, ak = 0.f, av = 0.f;
-      for (int w = 0; w < nt; ++w) { aq += sPart[w * 192 + d]; ak += sPart[w * 192 + 64 + d]; av += sPart[w * 192 + 128 + d]; }
-      // the lone row against itself
-      const float q2 = sTail[d], gT = sTail[64 + d], kT = sTail[128 + d], vT = sTail[192 + d];
-      const float sT = wave_sum_dpp(q2 * kT), dT = wave_sum_dpp(gT * vT);
-      const float pT = __builtin_amdgcn_exp2f(sT + sNegL[lm]);
-      const float dsT = pT * (dT + sNegD[lm]);
-      aq = fmaf(dsT, kT, aq); ak = fmaf(dsT, q2, ak); av = fmaf(pT, gT, av);
-      const size_t row = (size_t)b * p.L + lm;
-      p.dq[row * p.ld_dq + h * 64 + d] = f2bf(aq * p.scale);
-      p.dk[row * p.ld_dkv + h * 64 + d] = f2bf(ak * ln2);
-      p.dv[row * p.ld_dkv + h * 64 + d] = f2bf(av);
-    }
-  }
+  FB_STAMP(p, 6);
+  }   // items
 }
 
-constexpr size_t FB_LDS = (size_t)3 * FB_IMG + 2 * 8 * FB_ESLOT + (264 + 264 + 256 + 512 + 1536) * sizeof(float);
+constexpr size_t FB_LDS = (size_t)3 * FB_IMG + 2 * 8 * FB_ESLOT + (264 + 264 + 256 + 128 + 512 + 1536 + 64) * sizeof(float);
 
 }  // namespace
 
@@ -444,9 +552,16 @@ extern "C" int vl_attn_bwd_fused_bf16(const void* q, const void* k, const void* 
   FusedBwdP p{TV{(const bf16_t*)q, s[0], s[1], s[2]},   TV{(const bf16_t*)k, s[3], s[4], s[5]},
               TV{(const bf16_t*)v, s[6], s[7], s[8]},   TV{(const bf16_t*)dO, s[9], s[10], s[11]},
               TV{(const bf16_t*)o, s[12], s[13], s[14]}, lse, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, ld_dq, ld_dkv,
-              B, H, L, qscale, scale, lm, tail ? 1 : 0};
+              B, H, L, qscale, scale, lm, tail ? 1 : 0
+#ifdef VL_ATTN_PROF
+              , vl_attn_prof_buf
+#endif
+  };
   const int nt = (lm + 31) / 32;
-  hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(1, H, B), dim3(nt * 64), FB_LDS, stream, p);
+  int dev = 0, ncu = 0;
+  static const int cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) ? ncu : 256;
+  const int items = B * H;
+  hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(items < cus ? items : cus), dim3(nt * 64), FB_LDS, stream, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : vl_set_error(hipGetErrorString(e));
 }
