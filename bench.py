@@ -60,6 +60,9 @@ def parse():
                          "recipe, out = model(image, text, visual_x); loss(**out).backward(); torch.optim.AdamW.step(); clamp")
     ap.add_argument("--gemm-cfg", type=int, default=-1)
     ap.add_argument("--bn-sync", action="store_true", help="c5 with --gpus N: SyncBatchNorm in the point tokenizer (--use-bn-sync)")
+    ap.add_argument("--text-wsplit", default="on", choices=["on", "off"],
+                    help="text tower weights as two bf16 terms (on: cosine matrices within 1e-3 of the fp32 CPU path; off: the "
+                         "reference's amp_bf16 arithmetic, 1.3-1.5e-3)")
     ap.add_argument("--force-dist", action="store_true",
                     help="--gpus 1 only: initialise a ONE-rank RCCL communicator and run the step's multi-rank code path on it "
                          "(packed all-gather, bucketed async all-reduce; prints collective_ms_per_step) - the API / stream "
@@ -502,7 +505,7 @@ def main():
             audio = (torch.randn(a.batch, 512, 128, generator=g) * 0.5).to(dev)
             trainer = vstep.DualAudioStep(sd, tower_cfg, engine.TextCfg(), lens_cfg, dev, micro_batch=a.micro_batch,
                                           rank=rank, world_size=world, gemm_cfg=a.gemm_cfg, frozen_res_dtype=res_dtype, train_res_dtype=res_dtype, comm=comm,
-                                          force_comm=a.force_dist)
+                                          force_comm=a.force_dist, text_wsplit=a.text_wsplit == "on")
 
             def step():
                 return trainer.step(audio, texts)
@@ -513,7 +516,7 @@ def main():
             start = torch.randint(0, 8192, (a.batch,), generator=g).to(dev)
             trainer = vstep.TriModalPCStep(sd, tower_cfg, engine.TextCfg(), lens_cfg, dev, micro_batch=a.micro_batch,
                                            rank=rank, world_size=world, gemm_cfg=a.gemm_cfg, bn_training=True, frozen_res_dtype=res_dtype, train_res_dtype=res_dtype, comm=comm,
-                                           bn_sync=a.bn_sync, force_comm=a.force_dist)
+                                           bn_sync=a.bn_sync, force_comm=a.force_dist, text_wsplit=a.text_wsplit == "on")
 
             def step():
                 return trainer.step(images, texts, pts, start)
@@ -551,7 +554,7 @@ def main():
         texts = synth_text(a.batch, g).to(dev)
         trainer = vstep.TriModalDepthStep(sd, engine.TowerCfg(), engine.TextCfg(), dev, micro_batch=a.micro_batch,
                                           unlock_first_n=4, rank=rank, world_size=world, gemm_cfg=a.gemm_cfg, frozen_res_dtype=res_dtype, train_res_dtype=res_dtype, comm=comm,
-                                          force_comm=a.force_dist)
+                                          force_comm=a.force_dist, text_wsplit=a.text_wsplit == "on")
 
         def step():
             return trainer.step(images, texts, depths)
@@ -625,6 +628,7 @@ def main():
                            + (", packed RCCL embedding all-gather + flat gradient all-reduce" if world > 1 else "")),
                           "global_batch": world * a.batch, "residual_dtype": a.res_dtype,
                           "accumulate": "fp32", "parallelism": f"dp{world}", "gemm_cfg": a.gemm_cfg, "via": a.via,
+                          "text_tower_weights": "bf16 x 2 terms" if (a.text_wsplit == "on" and a.workload != "c2") else "bf16",
                           **({"force_dist": True} if a.force_dist else {})},
                "roofline": roof}
         if use_dist:         # diagnosis of a scaling run: per-rank step time (stragglers) and the exchange's share of the step

@@ -494,3 +494,25 @@ def test_tri_create_model_from_pretrained(tmp_path):
         assert torch.equal(model.state_dict()[k], want), k
     assert preprocess.image_size == 224 and not preprocess.is_train
     assert isinstance(oc.tri_create_model_from_pretrained("tiny-b32", str(tmp_path / "w.pt"), return_transform=False), type(src))
+
+
+def test_precision_modes_say_what_they_run():
+    """`precision` is accepted with the reference's spellings, but the path has ONE arithmetic (bf16 operands, fp32
+    accumulation): "fp32" and "amp" say so with a warning instead of silently computing something else
+    (reference: open_clip/factory.py:260-295, training/precision.py:5-12)."""
+    import warnings
+    import open_clip as oc
+    from mm_vit_lens.model_cfg import fetch_model_cfg
+    args = fetch_model_cfg(modality="image")
+    with pytest.warns(UserWarning, match="no fp32-arithmetic mode"):
+        m = oc.tri_create_model("ViT-B-32", precision="fp32", device="cpu", args=args)
+    assert m.precision_requested == "fp32" and "residual stream fp32" in m.precision_effective and "bf16 x bf16" in m.precision_effective
+    with pytest.warns(UserWarning, match="runs as amp_bf16"):
+        m = oc.tri_create_model("ViT-B-32", precision="amp", device="cpu", args=args)
+    assert "residual stream bf16" in m.precision_effective
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        m = oc.tri_create_model("ViT-B-32", precision="amp_bf16", device="cpu", args=args)       # what it runs: no warning
+    assert m.precision_requested == "amp_bf16"
+    with pytest.raises(NotImplementedError):
+        oc.tri_create_model("ViT-B-32", precision="fp16", device="cpu", args=args)

@@ -103,3 +103,43 @@ def test_text_processor_against_the_reference(tmp_path):
     assert [tp.pre_caption(t) for t in texts] == ref["pre"]
     assert [tp5.pre_caption(t) for t in texts] == ref["pre5"]
     assert tp(texts[:64]).tolist() == ref["ids"]
+
+
+def test_audio_clips_have_exactly_the_target_length_and_keep_channels(tmp_path):
+    """Host logic of AudioASTProcessorEval (reference at_processor.py:55-65,193-224,876-903): clip boundaries are exact
+    Fractions (end = start + clip_duration), so every clip of a long recording has exactly sr * clip_duration samples -
+    never one short (which would be doubled and cropped at a random offset) - and a multi-channel .wav keeps its channels:
+    the clip mean is over all of them, the spectrogram reads channel 0."""
+    import random
+    import wave
+    from fractions import Fraction
+
+    import numpy as np
+    from open_clip.modal_audio.processors import at_processor as AP
+    sr, cd = 16000, 5.0
+    rnd = random.Random(7)
+    bad = 0
+    for _ in range(3000):
+        n = rnd.randint(int(sr * cd) + 1, sr * 600)
+        dur = n / sr
+        for s, e in AP.clip_timepoints(dur, cd, 3):
+            assert isinstance(s, Fraction) and e - s == Fraction(cd)
+            bad += (int(e * sr) - int(s * sr)) != int(sr * cd)
+            assert 0 <= s and e <= dur + 1e-9
+    assert bad == 0
+    assert AP.clip_timepoints(12.0, 5.0, 3) == [(0, 5), (Fraction(7, 2), Fraction(17, 2)), (7, 12)]
+    # audio_get_clip on those boundaries: exactly the slice, deterministic (no repetition, no random crop)
+    wf = torch.arange(sr * 13, dtype=torch.float32)[None] / sr
+    for s, e in AP.clip_timepoints(13.0, cd, 3):
+        c = AP.audio_get_clip(wf, sr, cd, start=s, end=e, sub_mean=False)
+        assert c.shape == (1, int(sr * cd)) and float(c[0, 0]) == float(wf[0, int(s * sr)])
+    # stereo file -> [2, n]; the processor's clips keep both channels for the mean
+    path = str(tmp_path / "st.wav")
+    pcm = (np.stack([np.arange(1000), -2 * np.arange(1000)], 1) % 3000).astype("<i2")
+    with wave.open(path, "wb") as f:
+        f.setnchannels(2); f.setsampwidth(2); f.setframerate(sr); f.writeframes(pcm.tobytes())
+    w, r = AP.read_wav(path)
+    assert r == sr and w.shape == (2, 1000)
+    assert torch.equal(w[0], torch.from_numpy(pcm[:, 0].astype(np.float32) / 32768.0))
+    clip = AP.audio_get_clip(w.repeat(1, 100), sr, cd)
+    assert clip.shape[0] == 2 and abs(float(clip.mean())) < 1e-6

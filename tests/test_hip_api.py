@@ -55,7 +55,7 @@ def test_c1_vitb32_image_text_pairs_through_api():
     fi, ft = out["image_features"], out["text_features"]
     assert fi.shape == (4, 512) and ft.shape == (4, 512)
     assert float((cos_matrix(fi, fi) - cos_matrix(ri, ri)).abs().max()) < 1e-3
-    assert float((cos_matrix(ft, ft) - cos_matrix(rt, rt)).abs().max()) < 2e-3
+    assert float((cos_matrix(ft, ft) - cos_matrix(rt, rt)).abs().max()) < 1e-3          # (two-term text weights: TextEngine's default)
     assert float((1 - torch.nn.functional.cosine_similarity(fi.float().cpu(), ri, dim=-1)).max()) < 1e-3
     assert float((1 - torch.nn.functional.cosine_similarity(ft.float().cpu(), rt, dim=-1)).max()) < 1e-3
     p = torch.softmax(100.0 * fi.float().cpu() @ ft.float().cpu().t(), dim=-1)

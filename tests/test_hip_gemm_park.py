@@ -212,3 +212,30 @@ def test_many_tiles_no_sporadic_epilogue_faults(pcfg):
                 first[k] = o.clone()
             else:
                 assert torch.equal(o, first[k]), (k, rep)
+
+
+@pytest.mark.parametrize("M,N,K", [(256 * 40, 1024, 1024), (256 * 5, 768, 3072), (256 * 257, 256, 512), (256 * 77, 768, 768)])
+def test_fp32_residual_epilogue_on_the_persistent_kernel(M, N, K):
+    """EPI_RES_F32 (out f32 = res + acc * alpha + bias, in place allowed) on the persistent 256x256 kernel (round 4: the
+    Perceiver's residual projections, the two-term text tower and f32-stream towers ran it on the round-1 kernel): against
+    fp32 torch on the same bf16 operands and BIT-identical to the round-1 kernel (same products, same fp32 rounding points),
+    out of place, in place, without bias, with alpha, into a strided residual view."""
+    ops = _ops()
+    a = rnd(M, K, seed=1).bfloat16().cuda(); w = rnd(N, K, seed=2, scale=K ** -0.5).bfloat16().cuda()
+    bias = rnd(N, seed=3).cuda()
+    res = rnd(M, N, seed=4).cuda()
+    acc = a.float() @ w.float().t()
+    out8 = ops.gemm(a, w, bias, res=res, epi=ops.EPI_RES_F32, cfg=8)
+    assert relerr(out8, acc + bias + res) < 1e-5
+    out5 = ops.gemm(a, w, bias, res=res, epi=ops.EPI_RES_F32, cfg=5)
+    assert float((out8 - out5).abs().max()) <= 2e-6 * float(out5.abs().max())
+    x = res.clone()
+    ops.gemm(a, w, None, out=x, res=x, epi=ops.EPI_RES_F32, cfg=8, alpha=0.25)        # in place, no bias, alpha
+    assert relerr(x, 0.25 * acc + res) < 1e-5
+    big = torch.zeros(M, N + 64, device="cuda"); view = big[:, 32:32 + N]
+    view.copy_(res)
+    ops.gemm(a, w, bias, out=view, res=view, epi=ops.EPI_RES_F32, cfg=8)
+    assert relerr(view, acc + bias + res) < 1e-5 and float(big[:, :32].abs().max()) == 0.0 and float(big[:, 32 + N:].abs().max()) == 0.0
+    # what the auto dispatch does with it (whole rounds persistent + leftover rows)
+    auto = ops.gemm(a, w, bias, res=res, epi=ops.EPI_RES_F32)
+    assert relerr(auto, acc + bias + res) < 1e-5

@@ -101,20 +101,28 @@ def test_head_dim_104_tower_vs_oracle():
     assert float((1 - torch.nn.functional.cosine_similarity(got.float().cpu(), ref, dim=-1)).max()) < 1e-3
 
 
-def test_vitl_text_tower_vs_oracle():
+@pytest.mark.parametrize("seed", [77, 5, 123])
+def test_vitl_text_tower_vs_oracle(seed):
+    """ViT-L text tower (12 x 768, 77 tokens) vs the oracle on 8 captions: cosine-similarity MATRIX within the north-star's
+    1e-3 with the default two-term weights (`wsplit=True`); the plain-bf16 mode (= the reference's amp_bf16 arithmetic) is
+    measured beside it and held to its documented 2e-3 (random-init text features share a mutual cosine of ~0.6, which
+    amplifies operand rounding; the reference's own amp_bf16 forward is off by 1.4e-3 on this matrix)."""
     E = _engine()
     spec = O.TextSpec()
-    g = torch.Generator().manual_seed(77)
+    g = torch.Generator().manual_seed(seed)
     sd = O.init_text(spec, g)
-    text = O.synth_text(4, g)
+    text = O.synth_text(8, g)
     ref = O.encode_text(sd, text, spec)
-    eng = E.TextEngine(sd, E.TextCfg(), "cuda")
-    got = eng.encode_text(text.cuda())
-    assert relerr(got, ref) < 2e-2, relerr(got, ref)
-    # random-init text features share a large common component (mutual cosine ~0.6), which makes the
-    # cosine matrix ~2x more sensitive to the bf16 operand rounding than the image tower's: 2e-3 here.
-    assert float((cos_matrix(got, got) - cos_matrix(ref, ref)).abs().max()) < 2e-3
-    assert float((1 - torch.nn.functional.cosine_similarity(got.float().cpu(), ref, dim=-1)).max()) < 1e-3
+    errs = {}
+    for wsplit in (True, False):
+        eng = E.TextEngine(sd, E.TextCfg(), "cuda", wsplit=wsplit)
+        got = eng.encode_text(text.cuda())
+        assert relerr(got, ref) < 2e-2, relerr(got, ref)
+        errs[wsplit] = float((cos_matrix(got, got) - cos_matrix(ref, ref)).abs().max())
+        assert float((1 - torch.nn.functional.cosine_similarity(got.float().cpu(), ref, dim=-1)).max()) < 1e-3
+    print(f"text tower cos-matrix error, seed {seed}: two-term weights {errs[True]:.2e}, plain bf16 {errs[False]:.2e}")
+    assert errs[True] < 1e-3, errs
+    assert errs[False] < 2e-3, errs
 
 
 def test_batch_invariance_full_size():

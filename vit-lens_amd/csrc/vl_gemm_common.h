@@ -47,6 +47,14 @@ struct GemmP {
 // few times per launch (100-2000 of 268 M elements; the other order, which round 2 happened to get, never did).  Found in
 // round 3 by tests/test_hip_gemm_park.py after an unrelated refactor flipped the operand order; evidence and the bisection
 // in profiles/r03_pk_fma_fault.log.  Plain FMAs were clean in every run and cost two more VALU issues per eight values.
+// The FMAs below are inline assembly, which LLVM's hazard recognizer does not see: the wait states a VALU read of a matrix-pipe
+// result needs (up to 18 for a 16-pass MFMA) must not depend on how many instructions the compiler happens to place between
+// the last MFMA of a tile and the first scale_bias.  Every epilogue that uses scale_bias calls this once, first: 32 idle
+// issue slots per 256x256 tile.
+__device__ __forceinline__ void mfma_results_settled() {
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+}
+
 __device__ __forceinline__ f32x4 scale_bias(f32x4 v, float alpha, f32x4 b) {
   f32x4 r;
 #pragma unroll

@@ -295,6 +295,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     {
       // ---------------- tile finished: arithmetic, LDS transpose, one burst of 16-byte non-temporal stores ----------------
       const GemmP pe = reload_params();
+      mfma_results_settled();
       const int mrow0 = cur_m0 + wave_m * 128, ncol0 = cur_n0 + wave_n * WTN;
       int el = lane;
       asm volatile("" : "+v"(el));
@@ -331,34 +332,56 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
       };
       if constexpr (IS_DGEGLU) load_h(IC<0>{}, IC<0>{});
-      if constexpr (EPI == EPI_F32) {
-        // fp32 partial product of a k-slice: 32x32 blocks through the slab, 16-byte stores (8 lanes per 128-byte line)
-        float* const fout = (float*)pe.out + (size_t)cur_sp * pe.split_stride + (size_t)mrow0 * pe.ldo + ncol0;
+      if constexpr (EPI == EPI_F32 || EPI == EPI_RES_F32) {
+        // fp32 outputs: partial product of a k-slice (EPI_F32) or res + acc * alpha + bias into an fp32 residual stream
+        // (EPI_RES_F32, in place allowed; round 4 - the Perceiver's residual projections and the two-term text tower ran on
+        // the round-1 kernel until then): 32x32 blocks through the slab, 16-byte stores (8 lanes per 128-byte line)
+        float* const fout = (float*)pe.out + (EPI == EPI_F32 ? (size_t)cur_sp * pe.split_stride : (size_t)0) + (size_t)mrow0 * pe.ldo + ncol0;
+        [[maybe_unused]] const float* const rin = (const float*)pe.res + (size_t)mrow0 * pe.ldo + ncol0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
           for (int j = 0; j < NTL; ++j) {
+            [[maybe_unused]] f32x4 rr[4];
+            if constexpr (EPI == EPI_RES_F32) {        // the block's residual values, requested ahead of the slab round trip
+#pragma unroll
+              for (int pass = 0; pass < 4; ++pass)
+                rr[pass] = *(const f32x4*)(rin + (size_t)(i * 32 + pass * 8 + prow) * pe.ldo + j * 32 + (el & 7) * 4);
+            }
             if constexpr (M16) {
 #pragma unroll
               for (int ibh = 0; ibh < 2; ++ibh)
 #pragma unroll
                 for (int jbh = 0; jbh < 2; ++jbh) {
                   const int row = ibh * 16 + fr16;
+                  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                  if constexpr (EPI == EPI_RES_F32) {
+                    bv = *(const f32x4*)(bsrc + ncol0 + j * 32 + jbh * 16 + fq * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[e] = has_bias ? bv[e] : 0.f;
+                  }
                   *(f32x4*)(slab + row * 128 + (((jbh * 4 + fq) ^ (row & 7)) << 4)) =
-                      scale_bias(acc16[M16 ? i * 2 + ibh : 0][M16 ? j * 2 + jbh : 0], pe.alpha, f32x4{0.f, 0.f, 0.f, 0.f});
+                      scale_bias(acc16[M16 ? i * 2 + ibh : 0][M16 ? j * 2 + jbh : 0], pe.alpha, bv);
                 }
             } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               f32x4 v = {acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 0], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 1], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 2], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 3]};
-              *(f32x4*)(slab + fr * 128 + (((q * 2 + fg) ^ wsw) << 4)) = scale_bias(v, pe.alpha, f32x4{0.f, 0.f, 0.f, 0.f});
+              f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+              if constexpr (EPI == EPI_RES_F32) {
+                bv = *(const f32x4*)(bsrc + ncol0 + j * 32 + q * 8 + fg * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[e] = has_bias ? bv[e] : 0.f;
+              }
+              *(f32x4*)(slab + fr * 128 + (((q * 2 + fg) ^ wsw) << 4)) = scale_bias(v, pe.alpha, bv);
             }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
               const int r = pass * 8 + prow;
-              const f32x4 w = *(const f32x4*)(slab + r * 128 + (((el & 7) ^ (r & 7)) << 4));
+              f32x4 w = *(const f32x4*)(slab + r * 128 + (((el & 7) ^ (r & 7)) << 4));
+              if constexpr (EPI == EPI_RES_F32) w = w + rr[pass];
               __builtin_nontemporal_store(w, (f32x4*)(fout + (size_t)(i * 32 + r) * pe.ldo + j * 32 + (el & 7) * 4));
             }
           }
@@ -498,6 +521,11 @@ bool vl_gemm_park_supported(int epi, const void* params) {
     if (p.ksplit_len < 2 || nk % p.ksplit_len) return false;
     return !((((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.out) & 15));
   }
+  if (epi == EPI_RES_F32) {   // fp32 residual stream: out = res + acc * alpha + bias (in place allowed)
+    if ((p.M & 255) || (p.N & 255) || (p.K & 63) || p.K < 512 || p.M <= 0 || p.N <= 0 || (p.ldo & 3) || !p.res || !p.out) return false;
+    if (p.res_div != 1 || p.act != 0 || p.out2 || p.ksplit_len) return false;
+    return !((((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.out | (uintptr_t)p.res) & 15));
+  }
   if (!(epi == EPI_BF16 || epi == EPI_RES_BF16 || epi == EPI_DGELU || epi == EPI_GEGLU || epi == EPI_DGEGLU)) return false;
   if (epi == EPI_GEGLU && p.act != 0) return false;
   if (epi == EPI_DGEGLU && (p.bias || !p.res)) return false;
@@ -526,6 +554,7 @@ int vl_gemm_park_launch(int epi, const void* params, int ncu, hipStream_t s) {
     case EPI_GEGLU: return (int)launch_pk<EPI_GEGLU, 0>(p, ncu, s);
     case EPI_DGEGLU: return (int)launch_pk<EPI_DGEGLU, 0>(p, ncu, s);
     case EPI_F32: return (int)launch_pk<EPI_F32, 0>(p, ncu, s);
+    case EPI_RES_F32: return (int)launch_pk<EPI_RES_F32, 0>(p, ncu, s);
     default: return (int)hipErrorInvalidValue;
   }
 }

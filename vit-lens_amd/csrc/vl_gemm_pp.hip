@@ -214,6 +214,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     {
       // ---------------- tile finished: arithmetic, LDS transpose, one burst of 16-byte non-temporal stores ----------------
       const GemmP pe = reload_params();
+      mfma_results_settled();
       const int mrow0 = cur_m0 + wave_m * 128, ncol0 = cur_n0 + wave_n * WTN;
       if constexpr (HAS_AUX) {
         load_pair(IC<0>{}); load_pair(IC<1>{}); load_pair(IC<2>{}); load_pair(IC<3>{});

@@ -204,6 +204,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     {
       // fp32 partial product of the slice: 32x32 blocks through the wave's slab, 16-byte non-temporal stores (8 lanes per line)
       const GemmP pe = reload_params();
+      mfma_results_settled();
       const int mrow0 = cur_m0 + wave_m * 128, ncol0 = cur_n0 + wave_n * WTN;
       unsigned char* const slab = smem + 2 * TN_STAGE + wid * SLAB;
       float* const fout = (float*)pe.out + (size_t)cur_sp * pe.split_stride + (size_t)mrow0 * pe.ldo + ncol0;

@@ -3,7 +3,7 @@ open_clip/modal_audio/processors/at_processor.py:823-903): a waveform -> `n_clip
 Kaldi log-mel filterbank [512, 128] per clip -> (x - mean) / std.  The spectrogram runs in vl_kaldi_fbank; the clip
 selection is host arithmetic on sample indices.
 
-Inputs: a mono waveform tensor [1, n] / [n] at `sampling_rate`, or the path of a PCM .wav file at that rate (read with the
+Inputs: a waveform tensor [channels, n] / [n] at `sampling_rate`, or the path of a PCM .wav file at that rate (read with the
 standard library; torchaudio - the reference's loader and resampler - is not available, other rates are refused).
 Clip placement for recordings longer than one clip: `clips_per_video` windows spread uniformly from the start to
 (duration - clip_duration), which is what pytorchvideo's ConstantClipsPerVideoSampler computes for the reference."""
@@ -16,8 +16,9 @@ AST_AS_STD = (4.5689974,)
 
 
 def read_wav(path):
-    """-> (waveform [1, n] float32 in [-1, 1), sample rate): PCM 16 / 32-bit little-endian .wav, channels averaged to mono
-    as torchaudio.load(...) followed by the model's mono expectation."""
+    """-> (waveform [channels, n] float32 in [-1, 1), sample rate): PCM 16 / 32-bit little-endian .wav, channel-major like
+    torchaudio.load (the reference keeps every channel: `audio_get_clip` subtracts the mean over all of them and
+    kaldi.fbank reads channel 0, at_processor.py:193-224,855-866)."""
     import wave
 
     import numpy as np
@@ -34,15 +35,18 @@ def read_wav(path):
         a = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
     else:
         raise NotImplementedError(f"{width * 8}-bit wav")
-    a = a.reshape(-1, ch).mean(axis=1) if ch > 1 else a
-    return torch.from_numpy(np.ascontiguousarray(a))[None], sr
+    return torch.from_numpy(np.ascontiguousarray(a.reshape(-1, ch).T)), sr
 
 
 def clip_timepoints(duration: float, clip_duration: float, clips_per_video: int):
-    """(start, end) seconds of every clip: uniformly spread over [0, duration - clip_duration]."""
+    """(start, end) seconds of every clip, uniformly spread over [0, duration - clip_duration], as exact Fractions - what
+    pytorchvideo's ConstantClipsPerVideoSampler hands the reference (at_processor.py:55-65): end = start + clip_duration
+    exactly, so `int(end * sr) - int(start * sr)` can never exceed the clip length by rounding start and end separately.
+    (Round 3 returned floats: 4 % of the clips of long recordings came out one sample long and 0.4 % one short - a short
+    clip is doubled and cropped at a RANDOM offset by audio_get_clip, i.e. non-deterministic eval input.)"""
     last = Fraction(max(duration - clip_duration, 0.0))
     step = last / max(clips_per_video - 1, 1)
-    return [(float(step * i), float(step * i + Fraction(clip_duration))) for i in range(clips_per_video)]
+    return [(step * i, step * i + Fraction(clip_duration)) for i in range(clips_per_video)]
 
 
 def audio_get_clip(waveform, sampling_rate, target_duration, start=None, end=None, sub_mean=True, rng=None):
@@ -95,4 +99,5 @@ class AudioASTProcessorEval:
         else:
             clips = [audio_get_clip(wav, self.sampling_rate, self.clip_duration, start=s, end=e)
                      for s, e in clip_timepoints(dur, self.clip_duration, self.n_clip)]
-        return self.convert2fbank(torch.cat(clips, dim=0))            # [n_clip, target_length, mel_bins]
+        # kaldi.fbank takes channel 0 of each clip (its default `channel=-1` -> 0); the clip mean above was over all channels
+        return self.convert2fbank(torch.cat([c[:1] for c in clips], dim=0))            # [n_clip, target_length, mel_bins]

@@ -580,9 +580,23 @@ class TriCLIP(nn.Module):
         """`precision` of tri_create_model (factory.py:164): the GEMMs always run bf16 x bf16 -> f32 (what the reference's
         amp_bf16 autocast computes); "fp32" keeps the residual stream and its gradient in f32 (more precise than the
         reference's autocast), "amp" / "amp_bf16" / "bf16" carry them in bf16 exactly as autocast does."""
+        import warnings
         dt = torch.float32 if precision == "fp32" else torch.bfloat16
         self._res_dtype = self.image.res_dtype = self.visual.res_dtype = dt
         self._text_engine = None
+        # what actually runs, stated where the caller asked for something else (reference: factory.py:260-295 converts the
+        # model / sets up autocast; training/precision.py:5-12)
+        self.precision_requested = precision
+        self.precision_effective = ("bf16 x bf16 -> fp32 matrix products (text tower: two-term bf16 weights); LayerNorm / softmax "
+                                    "statistics, features, logits, loss in fp32; residual stream "
+                                    + ("fp32" if dt == torch.float32 else "bf16"))
+        if precision == "fp32":
+            warnings.warn("precision='fp32': the MI355X path has no fp32-arithmetic mode - matrix products take bf16 operands with "
+                          "fp32 accumulation (cosine matrices within 1e-3 of the fp32 CPU path); 'fp32' selects the fp32 residual "
+                          "stream.  See model.precision_effective.", UserWarning, stacklevel=3)
+        elif precision == "amp":
+            warnings.warn("precision='amp' (fp16 autocast in the reference) runs as amp_bf16 on the MI355X path: bf16 operands, "
+                          "fp32 accumulation, no loss scaling.", UserWarning, stacklevel=3)
         return self
 
     # ---- lock recipes (model.py:448-502) -------------------------------------------------------

@@ -114,6 +114,45 @@ def run_blocks(blocks, ws: _Workspace, B, L, D, H, causal=False, cfg=-1):
         ops.gemm(ws.hid, w["proj_w"], w["proj_b"], out=ws.x, res=ws.x, epi=res_epi, cfg=cfg)
 
 
+def _hi_lo(w: torch.Tensor, device):
+    """fp32 weight -> (hi, lo) bf16 with hi + lo = w to ~2^-17 relative (hi = bf16(w), lo = bf16(w - hi))."""
+    w = w.detach().float().to(device)
+    hi = w.bfloat16()
+    lo = (w - hi.float()).bfloat16()
+    return hi.contiguous(), lo.contiguous()
+
+
+def prep_block_wsplit(sd: Dict[str, torch.Tensor], p: str, device) -> Dict[str, torch.Tensor]:
+    """One ResidualAttentionBlock with TWO-TERM bf16 weights (`TextEngine(wsplit=True)`): the projections that write a
+    bf16 activation take the pair K-concatenated ([N, 2K] against an activation row [a, a]); the two residual projections
+    run as two launches (hi, then lo) that accumulate into the fp32 residual stream."""
+    blk = prep_block(sd, p, device)
+    for key, name in (("in_w", "attn.in_proj_weight"), ("fc_w", "mlp.c_fc.weight")):
+        hi, lo = _hi_lo(sd[p + name], device)
+        blk[key + "2"] = torch.cat([hi, lo], dim=1).contiguous()
+    for key, name in (("out_w", "attn.out_proj.weight"), ("proj_w", "mlp.c_proj.weight")):
+        blk[key], blk[key + "_lo"] = _hi_lo(sd[p + name], device)
+    return blk
+
+
+def run_blocks_wsplit(blocks, ws: "_Workspace", B, L, D, H, causal=False, cfg=-1):
+    """run_blocks with two-term weights (prep_block_wsplit); the residual stream must be fp32."""
+    dh = D // H
+    h2 = ws.h2
+    for w in blocks:
+        ops.layernorm(ws.x, w["ln1_w"], w["ln1_b"], h2[:, :D], B * L, D)
+        ops.layernorm(ws.x, w["ln1_w"], w["ln1_b"], h2[:, D:], B * L, D)
+        ops.gemm(h2, w["in_w2"], w["in_b"], out=ws.qkv, epi=ops.EPI_BF16, cfg=cfg)
+        ops.attn_fwd(ws.q, ws.k, ws.v, ws.a, causal=causal, qscale=dh ** -0.5 * ops.LOG2E)
+        ops.gemm(ws.a, w["out_w"], w["out_b"], out=ws.x, res=ws.x, epi=ops.EPI_RES_F32, cfg=cfg)
+        ops.gemm(ws.a, w["out_w_lo"], None, out=ws.x, res=ws.x, epi=ops.EPI_RES_F32, cfg=cfg)
+        ops.layernorm(ws.x, w["ln2_w"], w["ln2_b"], h2[:, :D], B * L, D)
+        ops.layernorm(ws.x, w["ln2_w"], w["ln2_b"], h2[:, D:], B * L, D)
+        ops.gemm(h2, w["fc_w2"], w["fc_b"], out=ws.hid, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg)
+        ops.gemm(ws.hid, w["proj_w"], w["proj_b"], out=ws.x, res=ws.x, epi=ops.EPI_RES_F32, cfg=cfg)
+        ops.gemm(ws.hid, w["proj_w_lo"], None, out=ws.x, res=ws.x, epi=ops.EPI_RES_F32, cfg=cfg)
+
+
 class VitEngine:
     """One ViT tower (`image.` or `visual.` prefix of the TriCLIP state_dict) on the GPU."""
 
@@ -192,15 +231,31 @@ class VitEngine:
 
 
 class TextEngine:
-    """TriCLIP.encode_text (model.py:528-540): embedding + causal transformer + ln_final + EOT + proj."""
+    """TriCLIP.encode_text (model.py:528-540): embedding + causal transformer + ln_final + EOT + proj.
 
-    def __init__(self, sd, cfg: TextCfg, device, res_dtype=torch.float32, gemm_cfg: int = -1):
-        self.cfg, self.device, self.res_dtype, self.gemm_cfg = cfg, torch.device(device), res_dtype, gemm_cfg
+    wsplit=True (the default): every weight of the tower is the sum of TWO bf16 terms and the residual stream is fp32 whatever
+    `res_dtype` says.  Why only here: random-init (and trained) text features share a large common component - mutual cosine
+    ~0.6 - which amplifies operand rounding in the cosine-similarity MATRIX; with plain bf16 weights that matrix is off by
+    1.3-1.5e-3 from the fp32 CPU path (the reference's own amp_bf16 forward: 1.4e-3), above the 1e-3 of BASELINE.json's
+    north_star.  Emulated on the CPU per rounding point: weights 4.6e-4, GEMM input activations 5.0e-4,
+    bf16 stores 5.7e-4, attention internals 2.2e-4 taken alone; two-term weights bring the whole tower to 5.5-9.3e-4.  Cost:
+    the tower's GEMM flops double (K-concatenated [hi | lo] for the in-projection and c_fc, two accumulating launches for
+    the residual projections) = +2.5 % of the C3 step's arithmetic.  wsplit=False is the reference's amp_bf16 arithmetic."""
+
+    def __init__(self, sd, cfg: TextCfg, device, res_dtype=torch.float32, gemm_cfg: int = -1, wsplit: bool = True):
+        self.cfg, self.device, self.gemm_cfg = cfg, torch.device(device), gemm_cfg
+        self.wsplit = bool(wsplit)
+        self.res_dtype = torch.float32 if self.wsplit else res_dtype
         self.tok = _dev(sd["token_embedding.weight"], device)
         self.pos = _dev(sd["positional_embedding"], device)
         self.ln_final = (_dev(sd["ln_final.weight"], device), _dev(sd["ln_final.bias"], device))
-        self.projT = _dev(sd["text_projection"].t(), device, torch.bfloat16)
-        self.blocks = [prep_block(sd, f"transformer.resblocks.{i}.", device) for i in range(cfg.layers)]
+        if self.wsplit:
+            hi, lo = _hi_lo(sd["text_projection"].t(), device)
+            self.projT = torch.cat([hi, lo], dim=1).contiguous()                      # [E, 2D]
+            self.blocks = [prep_block_wsplit(sd, f"transformer.resblocks.{i}.", device) for i in range(cfg.layers)]
+        else:
+            self.projT = _dev(sd["text_projection"].t(), device, torch.bfloat16)
+            self.blocks = [prep_block(sd, f"transformer.resblocks.{i}.", device) for i in range(cfg.layers)]
         self._ws = {}
 
     def encode_text(self, text: torch.Tensor, normalize: bool = False) -> torch.Tensor:
@@ -213,10 +268,18 @@ class TextEngine:
         ws = self._ws[key]
         text = text.to(self.device).contiguous()
         ops.text_embed(text, self.tok, self.pos, ws.x)
-        run_blocks(self.blocks, ws, B, L, D, cfg.heads, causal=True, cfg=self.gemm_cfg)
         eot = text.argmax(dim=-1).contiguous()            # index-exact EOT position (model.py:539)
-        pooled = torch.empty(B, D, device=self.device, dtype=torch.bfloat16)
-        ops.layernorm(ws.x, self.ln_final[0], self.ln_final[1], pooled, B, D, x_row_stride=D, row_index=eot, row_mul=L)
+        if self.wsplit:
+            if not hasattr(ws, "h2"):
+                ws.h2 = torch.empty(B * L, 2 * D, device=self.device, dtype=torch.bfloat16)
+            run_blocks_wsplit(self.blocks, ws, B, L, D, cfg.heads, causal=True, cfg=self.gemm_cfg)
+            pooled = torch.empty(B, 2 * D, device=self.device, dtype=torch.bfloat16)
+            for half in (pooled[:, :D], pooled[:, D:]):
+                ops.layernorm(ws.x, self.ln_final[0], self.ln_final[1], half, B, D, x_row_stride=D, row_index=eot, row_mul=L)
+        else:
+            run_blocks(self.blocks, ws, B, L, D, cfg.heads, causal=True, cfg=self.gemm_cfg)
+            pooled = torch.empty(B, D, device=self.device, dtype=torch.bfloat16)
+            ops.layernorm(ws.x, self.ln_final[0], self.ln_final[1], pooled, B, D, x_row_stride=D, row_index=eot, row_mul=L)
         f = ops.gemm(pooled, self.projT, None, epi=ops.EPI_F32, cfg=self.gemm_cfg)
         return ops.l2_normalize(f) if normalize else f
 
