@@ -304,6 +304,9 @@ int vl_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr
                   float eps, float weight_decay, int step, float grad_scale, hipStream_t stream);
 int vl_clamp_scalar(float* p, float lo, float hi, hipStream_t stream);
 int vl_axpy_f32(float* y, const float* x, float alpha, long n, hipStream_t stream);
+/* out[i] = x[i] * exp(log_scale[0]) * mul (in place allowed): `logit_scale.exp()` (open_clip/model.py:619, loss.py:125-127)
+ * applied on the device, so that a training step never reads the temperature on the host (hipGraph-capturable). */
+int vl_scale_exp_f32(const float* x, float* out, long n, const float* log_scale, float mul, hipStream_t stream);
 /* out[t,:] += sum_b x[b*batch_stride_rows + row_offset + t, :]   (positional-embedding gradients) */
 int vl_batch_rowsum(const float* x, float* out, int B, int T, int D, long batch_stride_rows, long row_offset,
                     hipStream_t stream);

@@ -126,3 +126,26 @@ def test_loss_module_takes_chunk_rows():
     assert abs(float(a) - float(b)) < 1e-5 * max(1.0, abs(float(a)))
     b.backward()
     assert torch.isfinite(xb.grad).all()
+
+
+@pytest.mark.parametrize("chunk_rows", [0, 128])
+def test_device_side_temperature_equals_the_host_scalar_path(chunk_rows):
+    """`logit_scale` as a 1-element device tensor (the log-temperature the model holds, model.py:619): exp() and every use
+    of the scale happen on the device (vl_scale_exp_f32), nothing reads it on the host.  Same loss and feature gradients as
+    the float-scale path; the third result is d/d(logit_scale) = scale * dL/d(scale)."""
+    import math
+    from vitlens_hip import step as ST
+    g = torch.Generator().manual_seed(11)
+    R, E = 384, 768
+    x = torch.nn.functional.normalize(torch.randn(R, E, generator=g), dim=-1).cuda()
+    y = torch.nn.functional.normalize(torch.randn(R, E, generator=g), dim=-1).cuda()
+    log_s = torch.tensor([math.log(1 / 0.07)], device="cuda")
+    s = float(log_s.exp())
+    la, ca = ST.pair_forward(x, y, s, chunk_rows=chunk_rows)
+    lb, cb = ST.pair_forward(x, y, log_s, chunk_rows=chunk_rows)
+    assert abs(float(la) - float(lb)) < 2e-5 * max(1.0, abs(float(la)))
+    dxa, dya, dsa = ST.pair_backward(ca)
+    dxb, dyb, dsb = ST.pair_backward(cb)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    assert rel(dxb, dxa) < 2e-3 and rel(dyb, dya) < 2e-3, (rel(dxb, dxa), rel(dyb, dya))
+    assert abs(float(dsb) - float(dsa) * s) < 2e-3 * max(1.0, abs(float(dsa) * s)), (float(dsb), float(dsa) * s)

@@ -154,3 +154,39 @@ def test_gathered_loss_values(world):
         # tri loss value: every rank computes the same global loss
         allx, ally, allz = torch.cat(xs), torch.cat(ys), torch.cat(zs)
         close(O.tri_clip_loss(allx, ally, allz, ls), z[f"rank{r}/tri_loss"])
+
+
+def test_oracle_on_c1_example_photographs():
+    """The oracle against what the IMPORTED reference computed for BASELINE config C1's actual inputs (four example
+    photographs + the example.py texts, tests/golden/c1_examples.npz): ViT-B/32 features from the reference pipeline's
+    preprocessed tensors and token ids, on the seeded weights the fixture names.  Also: the oracle's numpy restatement of the
+    preprocessing reproduces the reference's tensors from the JPEG bytes, byte for byte."""
+    import io
+    import sys
+    import warnings
+    from PIL import Image
+    import preproc_oracle as po
+    z = load_npz("c1_examples.npz")
+    for k in [k for k in sys.modules if k == "open_clip" or k.startswith("open_clip.")]:
+        if "vit-lens_amd" not in (getattr(sys.modules[k], "__file__", "") or ""):
+            del sys.modules[k]
+    import open_clip as oc
+    from open_clip.constants import OPENAI_DATASET_MEAN, OPENAI_DATASET_STD
+    from mm_vit_lens.model_cfg import fetch_model_cfg
+    torch.manual_seed(int(z["meta/seed"]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = oc.tri_create_model("ViT-B-32", None, precision="fp32", device="cpu", output_dict=True, args=fetch_model_cfg(modality="image"))
+    sd = {k: v.detach().float() for k, v in m.state_dict().items()}
+    tower = O.TowerSpec(width=768, layers=12, heads=12, patch=32, image_size=224, embed_dim=512)
+    tspec = O.TextSpec(width=512, heads=8, layers=12, embed_dim=512)
+    fi = O.encode_image(sd, torch.from_numpy(z["pre"]), tower, normalize=True)
+    ft = O.encode_text(sd, torch.from_numpy(z["text_ids"]), tspec, normalize=True)
+    assert float((fi - torch.from_numpy(z["image_features"])).abs().max()) < 2e-5
+    assert float((ft - torch.from_numpy(z["text_features"])).abs().max()) < 2e-5
+    p = torch.softmax(100.0 * fi @ ft.t(), dim=-1)
+    assert float((p - torch.from_numpy(z["probs"])).abs().max()) < 1e-4
+    for i, n in enumerate(["bird", "fire", "dog", "beach"]):
+        im = np.array(Image.open(io.BytesIO(z[f"jpeg/{n}"].tobytes())).convert("RGB"))
+        got = po.image_eval_transform(im, 224, OPENAI_DATASET_MEAN, OPENAI_DATASET_STD)
+        assert np.array_equal(got, z["pre"][i]), n

@@ -42,6 +42,14 @@ def _fake_ops():
         return (df - f * s) / norms.clamp_min(eps)[:, None]
     o.l2_normalize, o.l2_normalize_bwd = l2_normalize, l2_normalize_bwd
     o.split_bf16x3 = lambda x, pattern: x
+
+    def scale_exp(x, log_scale, out=None, mul=1.0):        # x * exp(logit_scale) with the scalar read from its tensor
+        r = x * torch.exp(log_scale) * mul
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
+    o.scale_exp = scale_exp
     o.logits_gemm = lambda xb, yb, scale: scale * xb @ yb.t()
 
     def ce_stats(logits, label_off=0, want_cols=True):

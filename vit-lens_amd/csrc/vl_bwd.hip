@@ -279,6 +279,13 @@ __global__ void __launch_bounds__(256) axpy_kernel(float* y, const float* x, flo
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = fmaf(alpha, x[i], y[i]);
 }
 
+// out[i] = x[i] * exp(*log_scale) * mul: the learnable temperature applied ON THE DEVICE (model.py:619 `logit_scale.exp()`):
+// the step never reads the scalar on the host
+__global__ void __launch_bounds__(256) scale_exp_kernel(const float* x, float* out, long n, const float* log_scale, float mul) {
+  const float s = __expf(log_scale[0]) * mul;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = x[i] * s;
+}
+
 // rows -> sum over the batch index: out[t, :] += sum_b x[(b*T_stride + t_off + t), :]   (pos-embedding grads)
 __global__ void __launch_bounds__(256) batch_rowsum_kernel(const float* x, float* out, int B, int T, int D, long bstride, long toff) {
   const long n = (long)T * D;
@@ -412,6 +419,14 @@ extern "C" int vl_clamp_scalar(float* p, float lo, float hi, hipStream_t stream)
 extern "C" int vl_axpy_f32(float* y, const float* x, float alpha, long n, hipStream_t stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, stream, y, x, alpha, n);
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vl_scale_exp_f32(const float* x, float* out, long n, const float* log_scale, float mul, hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (!x || !out || !log_scale) return vl_set_error("vl_scale_exp_f32: null argument");
+  hipLaunchKernelGGL(scale_exp_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, out, n, log_scale, mul);
   VL_HIP_OK(hipGetLastError());
   return 0;
 }

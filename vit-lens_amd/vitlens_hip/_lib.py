@@ -74,6 +74,7 @@ SIGNATURES = {
     "vl_adamw_step": [P, P, P, P, L, F, F, F, F, F, I, F, P],
     "vl_clamp_scalar": [P, F, F, P],
     "vl_axpy_f32": [P, P, F, L, P],
+    "vl_scale_exp_f32": [P, P, L, P, F, P],
     "vl_batch_rowsum": [P, P, I, I, I, L, L, P],
 }
 

@@ -406,6 +406,15 @@ def axpy(y, x, alpha=1.0):
     check(_lib.vl_axpy_f32(_p(y), _p(x), float(alpha), y.numel(), _stream()))
 
 
+def scale_exp(x, log_scale, out=None, mul=1.0):
+    """out = x * exp(log_scale) * mul with log_scale a 1-element f32 tensor ON THE DEVICE (no host read)."""
+    if x.dtype != torch.float32 or not x.is_contiguous() or log_scale.dtype != torch.float32:
+        raise ValueError("scale_exp: contiguous f32 tensors required")
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.vl_scale_exp_f32(_p(x), _p(out), x.numel(), _p(log_scale), float(mul), _stream()))
+    return out
+
+
 def batch_rowsum(x, out, B, T, D, batch_stride_rows, row_offset):
     check(_lib.vl_batch_rowsum(_p(x), _p(out), B, T, D, batch_stride_rows, row_offset, _stream()))
 

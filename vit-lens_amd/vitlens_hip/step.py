@@ -153,9 +153,19 @@ def _chunk_rows(R: int, Cn: int, chunk_rows: Optional[int]) -> int:
     return 0 if chunk_rows <= 0 or chunk_rows >= R else int(chunk_rows)
 
 
-def pair_forward(x, y, scale: float, label_off: int = 0, w_row: float = 0.5, w_col: float = 0.5,
+def _is_dev_scale(scale) -> bool:
+    return torch.is_tensor(scale)
+
+
+def pair_forward(x, y, scale, label_off: int = 0, w_row: float = 0.5, w_col: float = 0.5,
                  chunk_rows: Optional[int] = None):
     """loss contribution w_row*CE(scale*x y^T) + w_col*CE(columns); returns (loss[1] tensor, ctx).
+
+    scale: a Python float (the temperature itself), or - round 4 - the LEARNABLE LOG-temperature as a 1-element f32 tensor
+    on the device (`logit_scale` as the model holds it, model.py:619): x is multiplied by exp(logit_scale) on the device
+    (vl_scale_exp_f32) and the logits GEMM runs with alpha = 1, so the step never reads the scalar on the host and the loss
+    section is capturable in a hipGraph.  In that mode pair_backward's third result is d/d(logit_scale) (the log-domain
+    parameter) directly: sum(G * logits) - no division by the scale and re-multiplication.
 
     Row-blocked mode (chunk_rows, or automatically for B_glob^2 above LOGITS_CHUNK_ELEMS): the B_glob x B_glob logits
     are never held whole.  Forward = per block of rows: logits GEMM, exact row log-sum-exp, the block's column
@@ -164,9 +174,12 @@ def pair_forward(x, y, scale: float, label_off: int = 0, w_row: float = 0.5, w_c
     accumulation step; here only one thin GEMM is re-run)."""
     R, Cn = x.shape[0], y.shape[0]
     rb = _chunk_rows(R, Cn, chunk_rows)
-    xb, yb = ops.split_bf16x3(x, 0), ops.split_bf16x3(y, 1)
+    dev_scale = _is_dev_scale(scale)
+    alpha = 1.0 if dev_scale else scale
+    xb = ops.split_bf16x3(ops.scale_exp(x.contiguous(), scale) if dev_scale else x, 0)
+    yb = ops.split_bf16x3(y, 1)
     if rb == 0:
-        logits = ops.logits_gemm(xb, yb, scale)
+        logits = ops.logits_gemm(xb, yb, alpha)
         row_lse, col_lse, diag = ops.ce_stats(logits, label_off, want_cols=(w_col != 0.0))
         loss = torch.zeros(1, device=x.device, dtype=torch.float32)
         ops.ce_loss_accum(loss, row_lse if w_row != 0.0 else None, col_lse, diag, R, Cn, label_off, w_row, w_col)
@@ -175,7 +188,7 @@ def pair_forward(x, y, scale: float, label_off: int = 0, w_row: float = 0.5, w_c
     col_parts = []
     for r0 in range(0, R, rb):
         r1 = min(R, r0 + rb)
-        lg = ops.logits_gemm(xb[r0:r1], yb, scale)
+        lg = ops.logits_gemm(xb[r0:r1], yb, alpha)
         rl, cl, dg = ops.ce_stats(lg, label_off + r0, want_cols=(w_col != 0.0))
         row_lse[r0:r1] = rl; diag[r0:r1] = dg
         if cl is not None:
@@ -188,16 +201,21 @@ def pair_forward(x, y, scale: float, label_off: int = 0, w_row: float = 0.5, w_c
 
 
 def pair_backward(ctx, g: float = 1.0, need_dx=True, need_dy=True):
+    """-> (dx, dy, dscale).  dscale = dL/d(scale) for a float scale, dL/d(logit_scale) (log domain) for a device scale."""
     x, y, logits, row_lse, col_lse, label_off, w_row, w_col, scale, rb, xb, yb = ctx
     dscale = torch.zeros(1, device=x.device, dtype=torch.float32)
+    dev_scale = _is_dev_scale(scale)
+    # vl_ce_grad accumulates sum(G * logits) / logit_scale: with 1.0 that IS d/d(log-scale)
+    alpha, cscale = (1.0, 1.0) if dev_scale else (scale, scale)
+    fin = (lambda t: ops.scale_exp(t, scale, out=t)) if dev_scale else (lambda t: t)
     if rb == 0:
-        G, GT = ops.ce_grad(logits, row_lse if w_row != 0.0 else None, col_lse, label_off, w_row * g, w_col * g, scale,
+        G, GT = ops.ce_grad(logits, row_lse if w_row != 0.0 else None, col_lse, label_off, w_row * g, w_col * g, cscale,
                             dscale, need_g=need_dx, need_gt=need_dy)
         dx = dy = None
         if need_dx:
-            dx = ops.gemm(G, ops.transpose_to_bf16(y, ldo=G.shape[1]), None, epi=ops.EPI_F32, alpha=scale)
+            dx = fin(ops.gemm(G, ops.transpose_to_bf16(y, ldo=G.shape[1]), None, epi=ops.EPI_F32, alpha=alpha))
         if need_dy:
-            dy = ops.gemm(GT, ops.transpose_to_bf16(x, ldo=GT.shape[1]), None, epi=ops.EPI_F32, alpha=scale)
+            dy = fin(ops.gemm(GT, ops.transpose_to_bf16(x, ldo=GT.shape[1]), None, epi=ops.EPI_F32, alpha=alpha))
         return dx, dy, dscale
     R, Cn = x.shape[0], y.shape[0]
     dx = torch.empty(R, x.shape[1], device=x.device) if need_dx else None
@@ -206,21 +224,21 @@ def pair_backward(ctx, g: float = 1.0, need_dx=True, need_dy=True):
     for r0 in range(0, R, rb):
         r1 = min(R, r0 + rb)
         f = (r1 - r0) / R                      # the kernels average over the rows they are given: re-weight to the global mean
-        lg = ops.logits_gemm(xb[r0:r1], yb, scale)
+        lg = ops.logits_gemm(xb[r0:r1], yb, alpha)
         G, GT = ops.ce_grad(lg, row_lse[r0:r1] if w_row != 0.0 else None, col_lse, label_off + r0, w_row * g * f, w_col * g * f,
-                            scale, dscale, need_g=need_dx, need_gt=need_dy)
+                            cscale, dscale, need_g=need_dx, need_gt=need_dy)
         if need_dx:
             if yt is None:
                 yt = ops.transpose_to_bf16(y, ldo=G.shape[1])
-            ops.gemm(G, yt, None, out=dx[r0:r1], epi=ops.EPI_F32, alpha=scale)
+            ops.gemm(G, yt, None, out=dx[r0:r1], epi=ops.EPI_F32, alpha=alpha)
         if need_dy:
             xt = ops.transpose_to_bf16(x[r0:r1].contiguous(), ldo=GT.shape[1])
-            ops.gemm(GT, xt, None, out=dy, res=dy, epi=ops.EPI_RES_F32, alpha=scale)       # dy += scale * G_b^T x_b
+            ops.gemm(GT, xt, None, out=dy, res=dy, epi=ops.EPI_RES_F32, alpha=alpha)       # dy += scale * G_b^T x_b
         del lg, G, GT
-    return dx, dy, dscale
+    return (fin(dx) if need_dx else None), (fin(dy) if need_dy else None), dscale
 
 
-def pair_loss_and_grads(comm, rank: int, world: int, xl, yl, ax, ay, scale: float, local_loss: bool = False,
+def pair_loss_and_grads(comm, rank: int, world: int, xl, yl, ax, ay, scale, local_loss: bool = False,
                         gather_with_grad: bool = False, need_x: bool = True, need_y: bool = True, dist: Optional[bool] = None):
     """One (x, y) pair of ClipLossGeneral / TriClipLoss over the global batch (loss.py:116-138, 293-308) as rank `rank`
     computes it, and the gradients that arrive at THIS rank's features.
@@ -431,7 +449,7 @@ class TriModalDepthStep(_StepState):
             ops.l2_normalize(self.image.encode_image(images[s]), out=fi[s])
             vraw[s] = self._trainer(i).forward(depths[s])
         ops.l2_normalize(vraw, out=fv, norms=vnorm)
-        scale = float(self.logit_scale.exp())
+        scale = self.logit_scale          # the log-temperature, on the device: exp() is applied inside the loss section
         if self.dist:
             packed = torch.cat([fi, ft, fv], dim=1)
             allp = torch.empty(self.world * B, 3 * E, device=self.dev)
@@ -448,8 +466,8 @@ class TriModalDepthStep(_StepState):
             # gradients accumulate over micro-batches: a block's bucket is final once the LAST micro-batch has passed it
             cb = self._start_block_reduce if (i == nmb - 1 and self.dist and self.unlock_first_n > 0) else None
             self._trainer(i).backward(dvraw[i * mb:(i + 1) * mb].contiguous(), cb)
-        # logit_scale is exp()'d in forward (model.py:619): d/d(log-scale) = dscale * scale
-        self.grads["logit_scale"] += (ds1 + ds2) * scale
+        # logit_scale is exp()'d in forward (model.py:619); with the device-side scale pair_backward returns d/d(log-scale)
+        self.grads["logit_scale"] += ds1 + ds2
         return loss
 
 
@@ -614,7 +632,7 @@ class DualAudioStep(_PerceiverLensStep):
             s = slice(i * mb, (i + 1) * mb)
             vraw[s] = self._trainer(i).forward(audio[s])
         ops.l2_normalize(vraw, out=fv, norms=vnorm)
-        scale = float(self.logit_scale.exp())
+        scale = self.logit_scale          # device-side log-temperature (see TriModalDepthStep)
         if self.dist:
             allp = torch.empty(self.world * B, 2 * E, device=self.dev)
             self.comm.all_gather(allp, torch.cat([fv, ft], dim=1))
@@ -626,7 +644,7 @@ class DualAudioStep(_PerceiverLensStep):
         dvraw = ops.l2_normalize_bwd(fv, dv, vnorm)
         for i in range(nmb):
             self._trainer(i).backward(dvraw[i * mb:(i + 1) * mb].contiguous())
-        self.grads["logit_scale"] += ds * scale
+        self.grads["logit_scale"] += ds
         return loss
 
     def step(self, audio, texts):
@@ -687,7 +705,7 @@ class TriModalPCStep(_PerceiverLensStep):
             ops.l2_normalize(self.image.encode_image(images[s]), out=fi[s])
             vraw[s] = self._trainer(i).forward(points[s], None if fps_start is None else fps_start[s])
         ops.l2_normalize(vraw, out=fv, norms=vnorm)
-        scale = float(self.logit_scale.exp())
+        scale = self.logit_scale          # device-side log-temperature (see TriModalDepthStep)
         if self.dist:
             allp = torch.empty(self.world * B, 3 * E, device=self.dev)
             self.comm.all_gather(allp, torch.cat([fi, ft, fv], dim=1))
@@ -700,7 +718,7 @@ class TriModalPCStep(_PerceiverLensStep):
         dvraw = ops.l2_normalize_bwd(fv, dv1 + dv2, vnorm)
         for i in range(nmb):
             self._trainer(i).backward(dvraw[i * mb:(i + 1) * mb].contiguous())
-        self.grads["logit_scale"] += (ds1 + ds2) * scale
+        self.grads["logit_scale"] += ds1 + ds2
         return l1 + l2
 
     def step(self, images, texts, points, fps_start=None):
