@@ -16,6 +16,17 @@ from open_clip import ModalityType, tri_create_model
 from .model_cfg import fetch_model_cfg
 
 
+
+def _create(name, device, args):
+    """tri_create_model with the reference wrapper's (default) precision="fp32" = the fp32 residual stream of this path.
+    The factory's note that no fp32-ARITHMETIC mode exists is for callers who ask for it; this wrapper's arithmetic is
+    documented on the class (bf16 operands, fp32 accumulation - the reference's example runs under autocast)."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.filterwarnings("ignore", message="precision='fp32'")
+        return tri_create_model(name, None, precision="fp32", device=device, args=args)
+
+
 class ViTLens(nn.Module):
     def __init__(self, model_var: str = "vitlensL", modality_loaded: Optional[List[str]] = None,
                  load_from_ckpt: Optional[str] = None, device="cuda"):
@@ -31,14 +42,14 @@ class ViTLens(nn.Module):
             if m in (ModalityType.IMAGE, ModalityType.TEXT):
                 if base is None:
                     cfg = fetch_model_cfg(modality="image", model_option=model_var)
-                    base = tri_create_model(cfg.model, None, device=self._dev, args=cfg)
+                    base = _create(cfg.model, device=self._dev, args=cfg)
                 self.vitlens[m] = base
             elif m in (ModalityType.DEPTH, ModalityType.AUDIO, ModalityType.PC, ModalityType.TACTILE, ModalityType.EEG):
                 # only the modality's `visual` tower is kept, as in the reference (`self.vitlens.add_module(modality,
                 # model.visual); del model`, vitlens.py:100-107): the model's own image / text towers would be 1.7 GB of unused,
                 # randomly initialised fp32 parameters per modality
                 cfg = fetch_model_cfg(modality=m, model_option=model_var)
-                full = tri_create_model(cfg.model, None, device="cpu", args=cfg)
+                full = _create(cfg.model, device="cpu", args=cfg)
                 self.vitlens[m] = full.visual.to(self._dev)
                 del full
             else:
