@@ -72,6 +72,8 @@ def _check(step, ref_loss, ref_grads, loss, names, tol=8e-2, tag=None, cos_min=0
         elif k == "logit_scale":
             ref = ref.reshape(1)
         assert g is not None, k
+        if g.numel() == ref.numel():
+            ref = ref.reshape(g.shape)                # (1x1 convolutions are kept as [out, in] matrices)
         e, c = relerr(g, ref), cosine(g, ref)
         errs[k] = [round(e, 5), round(c, 6)] if k != "logit_scale" else [float(g), float(ref)]
         if k == "logit_scale":          # a scalar; at random init a difference of nearly cancelling sums (|g| ~ 0.02 - 0.12)
@@ -226,4 +228,145 @@ def test_c3_step_at_bench_geometry_is_finite_and_split_invariant(res_dtype):
     assert abs(res[0][0] - 2 * math.log(B)) < 1.0        # random init: TriClipLoss = two pair losses, each near ln(256)
     # (measured 3.2-3.6e-2 on the block-0 MLP gradients: 24 blocks of bf16 streams summed in a different order)
     bad = {k: relerr(res[1][1][k], v) for k, v in res[0][1].items() if relerr(res[1][1][k], v) > 5e-2}
+    assert not bad, bad
+
+
+def test_c5_pc_backward_vitl_given_forward_routing_and_upstream_gradient():
+    """C5's BACKWARD at ViT-L geometry with the two things that make the end-to-end comparison loose taken out (round 4):
+    (1) the ROUTING - the max-pools' arg-max rows are read from the HIP forward's own activations and the oracle's autograd
+    runs its mini-PointNet with those indices on the kernel's own grouped patches; (2) the UPSTREAM gradient - at random
+    init with 4 samples dL/dfeatures is a difference of nearly equal terms, so the 1e-2 forward error of the features turns
+    into 7 % on dL/dfeatures and from there, uniformly, on every parameter gradient (measured with given routing only:
+    6.5-7.4e-2, cosine 0.9975 on all ten tensors).  Here both sides back-propagate the SAME seeded dL/dfeatures through
+    tokenizer -> Perceiver (4 layers) -> 24 locked ViT-L blocks: what is left is the bf16 operand rounding of the backward
+    kernels (measured 0.6-0.9e-2 relative, cosine >= 0.99996 on every tensor).  The end-to-end test above keeps its 1.4e-1 as the envelope of routing flips + loss conditioning."""
+    from test_hip_train import _point_tokens_routed
+    from vitlens_hip import engine as E, step as ST
+    lens = O.LensSpec(modality="pc", perceiver_identity=False, depth=4, self_per_cross=1, num_latents=256, latent_dim=1024,
+                      input_chan=384)
+    sd, tower, text, g = _weights(lens)
+    B = 4
+    img = torch.randn(B, 3, 224, 224, generator=g); txt = O.synth_text(B, g)
+    pts = torch.rand(B, 8192, 3, generator=g) * 2 - 1
+    start = torch.randint(0, 8192, (B,), generator=g)
+    dfeat = torch.randn(B, 768, generator=g) * 0.05
+    P = "visual.perceiver.layers."
+    names = ["visual.perceiver.latents", P + "0.0.fn.to_kv.weight", P + "0.1.fn.net.2.weight",
+             P + "3.2.0.0.fn.to_q.weight", P + "3.2.0.1.fn.net.0.weight", "visual.visual_adapter.reduce_dim.weight",
+             "visual.visual_adapter.pos_embed.2.weight", "visual.visual_adapter.encoder.first_conv.0.weight",
+             "visual.visual_adapter.encoder.second_conv.3.weight"]
+    lc = E.LensCfg(modality="pc", perceiver_identity=False, depth=4, self_per_cross=1, input_chan=384)
+    st = ST.TriModalPCStep(sd, E.TowerCfg(), E.TextCfg(), lc, "cuda", micro_batch=B, bn_training=False)
+    st.forward_backward(img.cuda(), txt.cuda(), pts.cuda(), start.cuda())        # allocates the gradient views
+    st.flat_grad.zero_()
+    tr = st.trainers[0]
+    feat = tr.forward(pts.cuda(), start.cuda())
+    tr.backward(dfeat.cuda())
+    st.grads.update(tr.perc.reference_named_grads())
+    tk = tr.tok
+    M = lens.pc_group_size
+    patches, f, f2, c3 = tk.ctx[0], tk.ctx[5], tk.ctx[11], tk.ctx[13]
+    BG = f.shape[0] // M
+    idx1 = f.float().view(BG, M, -1).argmax(dim=1).cpu()
+    idx2 = f2.float().view(BG, M, -1).argmax(dim=1).cpu()
+    gp = patches[:, :3].float().cpu().view(BG, M, 3).transpose(1, 2).contiguous()
+    centers = c3[:, :3].float().cpu()
+    a = "visual.visual_adapter."
+    ref_feat = []
+
+    def fwd(s):
+        tok = _point_tokens_routed(s, a, gp, centers, lens, idx1, idx2, False).reshape(B, lens.pc_num_group, -1)
+        lat = O.perceiver(s, "visual.perceiver.", tok, lens)
+        fv = O.vit_trunk(s, "visual.", lat, tower, lens.use_orig_pos)
+        ref_feat.append(fv.detach())
+        return (fv * dfeat).sum()
+    _, ref_grads = _oracle_step(sd, names, fwd)
+    assert relerr(feat, ref_feat[0]) < 2e-2, relerr(feat, ref_feat[0])
+    bad, errs = {}, {}
+    for k in names:
+        gk, ref = st.grads[k], ref_grads[k]
+        ref = ref.reshape(gk.shape)
+        errs[k] = [round(relerr(gk, ref), 5), round(cosine(gk, ref), 6)]
+        if errs[k][0] > 2e-2 or errs[k][1] < 0.9995:          # measured 0.6-0.9e-2 / 0.99996+
+            bad[k] = errs[k]
+    _record("c5_given_routing_and_upstream", errs)
+    print("c5 backward given routing + upstream gradient:", errs)
+    assert not bad, bad
+
+
+def _poison():
+    junk = torch.full((1 << 28,), float("nan"), device="cuda")          # 1 GiB of NaN back to the allocator
+    del junk
+
+
+def test_c4_step_at_bench_geometry_is_finite_and_split_invariant():
+    """C4 at bench.py's geometry (b = 256: 65 536 latent rows and 307 200 context rows per GEMM - GEGLU / DGEGLU / fp32-residual
+    epilogues on the persistent kernel, whole rounds + leftover rows in the ViT trunk) against two micro-batches of 128: same
+    loss, same gradients up to bf16 noise, everything finite, recycled memory poisoned with NaN first."""
+    from vitlens_hip import engine as E, step as ST
+    lens = O.LensSpec(modality="audio", perceiver_identity=False, depth=2, self_per_cross=3, num_latents=256, latent_dim=1024,
+                      input_chan=1024)
+    sd, tower, text, g = _weights(lens, seed=8)
+    B = 256
+    aud = (torch.randn(B, 512, 128, generator=g) * 0.5).cuda(); txt = O.synth_text(B, g).cuda()
+    lc = E.LensCfg(modality="audio", perceiver_identity=False, depth=2, self_per_cross=3)
+    _poison()
+    res = []
+    for mb in (256, 128):
+        st = ST.DualAudioStep(sd, E.TowerCfg(), E.TextCfg(), lc, "cuda", micro_batch=mb, train_res_dtype=torch.bfloat16,
+                              frozen_res_dtype=torch.bfloat16)
+        loss = st.forward_backward(aud, txt)
+        assert torch.isfinite(loss), float(loss)
+        assert all(bool(torch.isfinite(v).all()) for v in st.grads.values())
+        res.append((float(loss), {k: v.detach().clone() for k, v in st.grads.items()}))
+        del st
+        torch.cuda.empty_cache()
+    assert abs(res[0][0] - res[1][0]) < 2e-3, (res[0][0], res[1][0])
+    assert abs(res[0][0] - math.log(B)) < 0.5
+    errs = {k: relerr(res[1][1][k], v) for k, v in res[0][1].items() if float(v.abs().max()) > 0}
+    print("c4 split invariance, worst:", sorted(errs.items(), key=lambda kv: -kv[1])[:3])
+    bad = {k: e for k, e in errs.items() if e > 6e-2}
+    assert not bad, bad
+
+
+def test_c5_step_at_bench_geometry_is_finite_and_split_invariant():
+    """C5 at bench.py's geometry (b = 128: 65 536 x 32 grouped points through the mini-PointNet, 65 536 latent rows): with
+    train-mode BatchNorm (per-micro-batch statistics, what bench.py runs) finiteness and the running-statistics update; with
+    frozen statistics (where the micro-batch split does not change the mathematics) b = 128 against 2 x 64."""
+    from vitlens_hip import engine as E, step as ST
+    lens = O.LensSpec(modality="pc", perceiver_identity=False, depth=4, self_per_cross=1, num_latents=256, latent_dim=1024,
+                      input_chan=384)
+    sd, tower, text, g = _weights(lens, seed=9)
+    B = 128
+    img = torch.randn(B, 3, 224, 224, generator=g).cuda(); txt = O.synth_text(B, g).cuda()
+    pts = torch.rand(B, 8192, 3, generator=g) * 2 - 1
+    pts = (pts / pts.norm(dim=-1).amax(1)[:, None, None]).cuda()
+    start = torch.randint(0, 8192, (B,), generator=g).cuda()
+    lc = E.LensCfg(modality="pc", perceiver_identity=False, depth=4, self_per_cross=1, input_chan=384)
+    kw = dict(train_res_dtype=torch.bfloat16, frozen_res_dtype=torch.bfloat16)
+    _poison()
+    st = ST.TriModalPCStep(sd, E.TowerCfg(), E.TextCfg(), lc, "cuda", micro_batch=128, bn_training=True, **kw)
+    rm0 = {k: v[0].clone() for k, v in st.tok.running.items()}
+    loss = st.forward_backward(img, txt, pts, start)
+    assert torch.isfinite(loss) and abs(float(loss) - 2 * math.log(B)) < 1.0, float(loss)
+    assert all(bool(torch.isfinite(v).all()) for v in st.grads.values())
+    assert all(bool(torch.isfinite(v[0]).all()) and not torch.equal(v[0], rm0[k]) for k, v in st.tok.running.items())
+    st.optimizer_step()
+    assert all(bool(torch.isfinite(v).all()) for v in st.masters.values())
+    del st
+    torch.cuda.empty_cache()
+    res = []
+    for mb in (128, 64):
+        st = ST.TriModalPCStep(sd, E.TowerCfg(), E.TextCfg(), lc, "cuda", micro_batch=mb, bn_training=False, **kw)
+        loss = st.forward_backward(img, txt, pts, start)
+        assert torch.isfinite(loss) and all(bool(torch.isfinite(v).all()) for v in st.grads.values())
+        res.append((float(loss), {k: v.detach().clone() for k, v in st.grads.items()}))
+        del st
+        torch.cuda.empty_cache()
+    assert abs(res[0][0] - res[1][0]) < 2e-3, (res[0][0], res[1][0])
+    errs = {k: relerr(res[1][1][k], v) for k, v in res[0][1].items() if float(v.abs().max()) > 0}
+    print("c5 split invariance, worst:", sorted(errs.items(), key=lambda kv: -kv[1])[:3])
+    # (measured 7.3e-2 on the first cross-attention's latent-side tensors: another GEMM dispatch for the 64-sample micro-batch
+    #  moves a few bf16 activations across the max-pools' arg-max ties; everything else stays below 6e-2)
+    bad = {k: e for k, e in errs.items() if e > 1e-1}
     assert not bad, bad
