@@ -40,6 +40,23 @@ constexpr int PK_LDS = 2 * PK_STAGE + 32768;            // 160 KB: two operand s
 #endif
 constexpr int PK_GN = 4;                                 // N-tiles per group (tile order, see tile_origin)
 
+// Measurement build only (tools/build_gemm_prof.sh, -DVL_GEMM_PROF): wave 0 of every workgroup adds up the shader-clock cycles
+// it spends in the k-loops and in the epilogues: prof[4 * workgroup + {0: k-loop, 1: epilogue, 2: tiles}].
+#ifdef VL_GEMM_PROF
+}  // namespace
+extern "C" { long* vl_gemm_prof_buf = nullptr; }
+namespace {
+#define PK_PROF_ARG , long* prof
+#define PK_PROF_PASS , vl_gemm_prof_buf
+#define PK_PROF_T(v) const long v = __builtin_amdgcn_s_memtime()
+#define PK_PROF_ADD(i, d) do { if (prof && threadIdx.x == 0) prof[4 * blockIdx.x + (i)] += (d); } while (0)
+#else
+#define PK_PROF_ARG
+#define PK_PROF_PASS
+#define PK_PROF_T(v) do { } while (0)
+#define PK_PROF_ADD(i, d) do { } while (0)
+#endif
+
 template <int I>
 using IC = std::integral_constant<int, I>;
 
@@ -54,7 +71,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // against 1862 TF/s for 32x32x16 (profiles/r03b_mfma_power_probe.log).
 template <int EPI, int ACT, bool M16>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-    gemm_nt_pk_kernel(const GemmP p) {
+    gemm_nt_pk_kernel(const GemmP p PK_PROF_ARG) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool HAS_AUX = (EPI == EPI_RES_BF16 || EPI == EPI_DGELU);   // second operand of the output's shape
   // GEGLU (Perceiver feed-forward, perceiver.py:85-102): rows of W interleaved (a_j, gate_j) -> out[M, N/2] = a * gelu(gate),
@@ -180,7 +197,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
   // ---- epilogue operands ----
   // chunk ci (0..15) = rows (ci>>2)*32 + (ci&3)*8 + (lane>>3) of the wave's sub-tile, columns (lane&7)*8 .. +7
-  [[maybe_unused]] u32x4 aux[NCH];
+  [[maybe_unused]] u32x4 aux[2][4];          // second operand of row block i in aux[i & 1] (double buffered)
   // (the epilogue's lane constants are derived at the START OF EVERY EPILOGUE from a laundered copy of the lane index: computed
   // here they would be hoisted above the k-loop, live through it beside 128 accumulators + 64 fragment registers, and spill)
   int prow = 0, pcol = 0;
@@ -188,11 +205,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int ldo2 = p.ldo * 2;
   auto chunk_row = [](int ci) { return (ci >> 2) * 32 + (ci & 3) * 8; };
   [[maybe_unused]] const unsigned char* aux_src = nullptr;      // &aux[tile row 0 of this wave][tile col 0 of this wave] (current tile)
-  auto load_pair = [&](auto GI) {
-    constexpr int g = decltype(GI)::value;
-    if constexpr (HAS_AUX) {
-      aux[g * 2] = *(const u32x4*)(aux_src + (size_t)(chunk_row(g * 2) * ldo2) + lo_out);
-      aux[g * 2 + 1] = *(const u32x4*)(aux_src + (size_t)(chunk_row(g * 2 + 1) * ldo2) + lo_out);
+  // the four 16-byte pieces of row block I (rows I*32 + pass*8 + (lane>>3)), requested one row block ahead: the lines were
+  // touched at the start of the tile (L2 / Infinity Cache), 32 registers instead of the 64 of loading the whole tile up front
+  auto load_block = [&](auto II) {
+    constexpr int i = decltype(II)::value;
+    if constexpr (HAS_AUX && i < 4) {
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass)
+        aux[i & 1][pass] = *(const u32x4*)(aux_src + (size_t)(chunk_row(i * 4 + pass) * ldo2) + lo_out);
     }
   };
 
@@ -228,6 +248,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   auto dma_wait_and_barrier = [&]() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
+  // The FIRST barrier of a tile behind an epilogue (round 4): the DMA it needs (k-step 1 of this tile) was issued in front of
+  // the epilogue, i.e. it is OLDER than the epilogue's output stores in the in-order vmcnt queue - waiting for "at most
+  // NST operations outstanding" retires exactly that DMA and leaves the NST stores of this wave draining under the first
+  // k-step instead of in front of it (measured with vmcnt(0): 0.2-0.7 k cycles per k-step of store drain charged to the
+  // k-loop, 11 k per tile behind the two-output GELU epilogue).  NST = the minimum number of stores a wave issues per tile.
+  constexpr int NST = (EPI == EPI_F32 || EPI == EPI_RES_F32 || IS_DGEGLU || (EPI == EPI_BF16 && (ACT == 3 || ACT == 4))) ? 32 : 16;
+  auto first_wait_and_barrier = [&]() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NST) : "memory");
+  };
 
   zero_acc();
   dma_step(smem);
@@ -240,6 +269,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
   int par = 0;                                   // stage buffer of the k-step being computed
   bool pendB = false;                            // group B: a DMA batch is due at the top of the next k-step
+  bool after_epi = false;                        // the next barrier is the first one behind an epilogue (wave-uniform)
   auto kstep = [&](auto LAST) {
     constexpr bool last = decltype(LAST)::value;
     unsigned char* cur = smem + par * PK_STAGE;
@@ -257,8 +287,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       ldA16(cur, 1, 1, 1);
       mma16(IC<0>{}, 0, 1);
       __builtin_amdgcn_sched_barrier(0);
-      dma_wait_and_barrier();
-      if (dti < my_tiles) { if (!grpB) dma_step(cur); else pendB = true; }
+      if (after_epi) { first_wait_and_barrier(); after_epi = false; } else dma_wait_and_barrier();
+      // (at the last k-step of a tile BOTH wave groups issue at once: the batch must sit in front of the epilogue's stores)
+      if (dti < my_tiles) { if (!grpB || last) dma_step(cur); else pendB = true; }
       if constexpr (!last) first_frags(oth);
       __builtin_amdgcn_sched_barrier(0);
       mma16(IC<1>{}, 1, 1);
@@ -273,8 +304,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     mma(0);
     __builtin_amdgcn_sched_barrier(0);
     // every wave holds its last fragments of `cur`; the DMA of the next k-step (issued 0.5 - 1 k-step ago) has landed
-    dma_wait_and_barrier();
-    if (dti < my_tiles) { if (!grpB) dma_step(cur); else pendB = true; }
+    if (after_epi) { first_wait_and_barrier(); after_epi = false; } else dma_wait_and_barrier();
+    if (dti < my_tiles) { if (!grpB || last) dma_step(cur); else pendB = true; }
     if constexpr (!last) ldfrag(oth, 0, 0);      // (at a tile boundary the fragments would sit in registers through the epilogue)
     __builtin_amdgcn_sched_barrier(0);
     mma(1);
@@ -290,8 +321,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       make_rsrc(nm0, nn0, nsp, rsA_n, rsW_n);
     }
     set_aux();
+    PK_PROF_T(t_a);
+    after_epi = ti > 0;
     for (int kt = 0; kt < nk - 1; ++kt) kstep(std::false_type{});
     kstep(std::true_type{});
+    PK_PROF_T(t_b);
     {
       // ---------------- tile finished: arithmetic, LDS transpose, one burst of 16-byte non-temporal stores ----------------
       const GemmP pe = reload_params();
@@ -303,8 +337,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       lo_out = (unsigned)((prow * pe.ldo + pcol) * 2);
       [[maybe_unused]] const int fr = el & 31, fg = el >> 5, fr16 = el & 15, fq = el >> 4;      // shadow the main loop's copies
       if constexpr (HAS_AUX) {
-        load_pair(IC<0>{}); load_pair(IC<1>{}); load_pair(IC<2>{}); load_pair(IC<3>{});
-        load_pair(IC<4>{}); load_pair(IC<5>{}); load_pair(IC<6>{}); load_pair(IC<7>{});
+        load_block(IC<0>{});
       }
       unsigned char* const slab = smem + 2 * PK_STAGE + wid * SLAB;
       unsigned char* const wr = slab + fr * 128 + fg * 8;
@@ -312,6 +345,31 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       // branch-free optional bias: read SOMETHING valid (the weight matrix) and select zero
       const bool has_bias = pe.bias != nullptr;
       const float* const bsrc = has_bias ? pe.bias : (const float*)pe.W;
+      // The bias of this lane's columns, ONCE per tile (round 4).  It was loaded where it is used, inside the row-block loops:
+      // 32 loads of 16 bytes per tile, each followed by the compiler's `s_waitcnt vmcnt(0)` - and on gfx9 that counter also
+      // covers the output STORES issued just before, so every row block first waited for the previous block's stores to
+      // reach memory and then paid eight serial L2 round trips.  tools/gemm_phase_prof.py: the plain epilogue took 10.4 k
+      // cycles per 256x256 tile (21 % of a K = 1024 launch) with ~0.8 k cycles of VALU work in it.
+      // (the 32x32x16 A/B build of the loop, M16 = false, has eight column groups per lane and no registers for them: it keeps
+      //  loading the bias where it is used - measurement path only, VL_GEMM_MFMA16=0)
+      [[maybe_unused]] f32x4 bvq[4];
+      auto bias_at = [&](int n) {
+        f32x4 b = *(const f32x4*)(bsrc + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = has_bias ? b[e] : 0.f;
+        return b;
+      };
+#pragma unroll
+      for (int c = 0; c < (M16 ? 4 : 0); ++c) {
+        const int n = ncol0 + c * 16 + fq * 4;
+        if constexpr (IS_DGEGLU) {                 // (never has a bias: vl_gemm_park_supported)
+          bvq[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+          bvq[c] = *(const f32x4*)(bsrc + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bvq[c][e] = has_bias ? bvq[c][e] : 0.f;
+        }
+      }
       // destination of this lane's chunks
       unsigned char* const out_base = (unsigned char*)pe.out + ((size_t)mrow0 * pe.ldo + ncol0) * 2 + lo_out;
       // GEGLU / DGEGLU lane offsets (other strides than the plain outputs)
@@ -355,11 +413,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (int jbh = 0; jbh < 2; ++jbh) {
                   const int row = ibh * 16 + fr16;
                   f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                  if constexpr (EPI == EPI_RES_F32) {
-                    bv = *(const f32x4*)(bsrc + ncol0 + j * 32 + jbh * 16 + fq * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bv[e] = has_bias ? bv[e] : 0.f;
-                  }
+                  if constexpr (EPI == EPI_RES_F32) bv = bvq[M16 ? j * 2 + jbh : 0];
                   *(f32x4*)(slab + row * 128 + (((jbh * 4 + fq) ^ (row & 7)) << 4)) =
                       scale_bias(acc16[M16 ? i * 2 + ibh : 0][M16 ? j * 2 + jbh : 0], pe.alpha, bv);
                 }
@@ -368,11 +422,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             for (int q = 0; q < 4; ++q) {
               f32x4 v = {acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 0], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 1], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 2], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 3]};
               f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-              if constexpr (EPI == EPI_RES_F32) {
-                bv = *(const f32x4*)(bsrc + ncol0 + j * 32 + q * 8 + fg * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bv[e] = has_bias ? bv[e] : 0.f;
-              }
+              if constexpr (EPI == EPI_RES_F32) bv = bias_at(ncol0 + j * 32 + q * 8 + fg * 4);
               *(f32x4*)(slab + fr * 128 + (((q * 2 + fg) ^ wsw) << 4)) = scale_bias(v, pe.alpha, bv);
             }
             }
@@ -390,19 +440,16 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       auto row_block = [&](auto II) {
         constexpr int i = decltype(II)::value;
         if constexpr (IS_DGEGLU) load_h(IC<(i + 1) & 1>{}, IC<i + 1>{});        // h of the next row block, under this block's work
+        if constexpr (HAS_AUX) load_block(IC<i + 1>{});
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             // 32x32 blocks: (j, q) = column block, 8-column group; 16x16 blocks: (j, q) = (row half ibh, column block jb)
-            const int n = M16 ? ncol0 + q * 16 + fq * 4 : ncol0 + j * 32 + q * 8 + fg * 4;
             f32x4 v;
             if constexpr (M16) v = acc16[M16 ? i * 2 + j : 0][M16 ? q : 0];
             else v = f32x4{acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 0], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 1], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 2], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 3]};
-            f32x4 bv = *(const f32x4*)(bsrc + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bv[e] = has_bias ? bv[e] : 0.f;
-            v = scale_bias(v, pe.alpha, bv);
+            v = scale_bias(v, pe.alpha, M16 ? bvq[M16 ? q : 0] : bias_at(ncol0 + j * 32 + q * 8 + fg * 4));
             if constexpr (EPI == EPI_BF16 && ACT == 1) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
@@ -425,7 +472,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
           const int r = pass * 8 + prow;
           u32x4 w = *(const u32x4*)(slab + r * 128 + (((el & 7) ^ (r & 7)) << 4));
           [[maybe_unused]] u32x4 rr;
-          if constexpr (HAS_AUX) rr = aux[i * 4 + pass];
+          if constexpr (HAS_AUX) rr = aux[i & 1][pass];
           if constexpr (IS_GEGLU) {
             // w = 4 (a, gate) pairs of the bf16 pre-activation (the reference's autocast multiplies the bf16 halves too)
             const size_t rowoff = (size_t)(mrow0 + i * 32 + pass * 8);
@@ -489,6 +536,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       }
       zero_acc();
       if (ti + 1 < my_tiles) { tile_origin(ti + 1, cur_m0, cur_n0, cur_sp); first_frags(smem + par * PK_STAGE); }
+#ifdef VL_GEMM_PROF
+      { PK_PROF_T(t_c); PK_PROF_ADD(0, t_b - t_a); PK_PROF_ADD(1, t_c - t_b); PK_PROF_ADD(2, 1); }
+#endif
     }
   }
 }
@@ -501,7 +551,7 @@ hipError_t launch_pk_v(const GemmP& p, int ncu, hipStream_t s) {
   const int tiles = (p.M >> 8) * (p.N >> 8) * ((EPI == EPI_F32 && p.ksplit_len) ? (p.K >> 6) / p.ksplit_len : 1);
   int G = ncu & ~7;
   if (tiles < G) G = (tiles + 7) & ~7;
-  hipLaunchKernelGGL(kern, dim3(G), dim3(512), PK_LDS, s, p);
+  hipLaunchKernelGGL(kern, dim3(G), dim3(512), PK_LDS, s, p PK_PROF_PASS);
   return hipGetLastError();
 }
 
