@@ -90,7 +90,8 @@ __device__ __forceinline__ GemmP reload_params() {
 #if defined(__HIP_DEVICE_COMPILE__)
   KernargP kp = (KernargP)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(kp));
-  __builtin_memcpy(&r, (const void*)kp, sizeof(GemmP));
+  r = *kp;      // a copy THROUGH the constant address space: scalar loads (the memcpy through a generic pointer of rounds 1-3
+                // became per-lane global_load_dwordx4 + readfirstlane: one more vector-memory round trip at every epilogue start)
 #endif
   return r;
 }
