@@ -182,15 +182,15 @@ def hbm_traffic(dom):
     collected by tools/gpu_evidence_r03.sh with this very command and corrected per the MI355X guide by
     tools/traffic_summary.py).  PMC collection cannot run inside the timed process, so the number is read from
     profiles/; None when no summary for this kernel shape has been committed."""
-    p = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    try:
-        t = json.load(open(p))
-        for e in t.get("shapes", [t]):
-            if (e.get("shape") == [dom["M"], dom["N"], dom["K"]] and e.get("epi", dom["epi"]) == dom["epi"]
-                    and e.get("act", dom["act"]) == dom["act"]):
-                return round(e["traffic_bytes_per_launch"])
-    except (OSError, ValueError, KeyError):
-        pass
+    for name in ("r04_hbm_traffic_c3.json", "hbm_traffic.json"):        # newest summary first
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", name)))
+            for e in t.get("shapes", [t]):
+                if (e.get("shape") == [dom["M"], dom["N"], dom["K"]] and e.get("epi", dom["epi"]) == dom["epi"]
+                        and e.get("act", dom["act"]) == dom["act"]):
+                    return round(e["traffic_bytes_per_launch"])
+        except (OSError, ValueError, KeyError):
+            continue
     return None
 
 
@@ -204,7 +204,7 @@ def pmc_mfma_busy(dom):
     key = {(1024, 4096, 3, 0): "gemm_nt_pk_kernel<3, 0, true>", (4096, 1024, 0, 1): "gemm_nt_pk_kernel<0, 1, true>",
            (4096, 1024, 0, 4): "gemm_nt_pk_kernel<0, 4, true>", (4096, 1024, 6, 4): "gemm_nt_pk_kernel<6, 4, true>",
            (3072, 1024, 0, 0): "gemm_nt_pk_kernel<0, 0, true>"}.get((dom["N"], dom["K"], dom["epi"], dom["act"]))
-    for src in ("r03d_gemm_pmc.json", "r03c_gemm_pmc.json"):       # r03d: the shipped 16x16x32 main loop; r03c: the 32x32x16 one
+    for src in ("r04_gemm_pmc.json", "r03d_gemm_pmc.json", "r03c_gemm_pmc.json"):       # r04: round-4 epilogue; r03d: 16x16x32 main loop; r03c: 32x32x16
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", src)))["kernels"]
             k = t.get(key) or t[key.replace(", true>", ">")]
