@@ -38,7 +38,7 @@ constexpr int PK_LDS = 2 * PK_STAGE + 32768;            // 160 KB: two operand s
 #ifndef VL_PK_VARIANT
 #define VL_PK_VARIANT 0          // measurement builds only (tools/build_pk_variants.sh): bit 0 = MFMA order, bit 1 = static wave priority
 #endif
-constexpr int PK_GN = 4;                                 // N-tiles per group (tile order, see tile_origin)
+constexpr int PK_GN = 8;                                 // N-tiles per group (tile order, see tile_origin; in-step A/B of 2 / 4 / 8 / 16: profiles/r04_gemm_tile_order_ab.log)
 
 // Measurement build only (tools/build_gemm_prof.sh, -DVL_GEMM_PROF): wave 0 of every workgroup adds up the shader-clock cycles
 // it spends in the k-loops and in the epilogues: prof[4 * workgroup + {0: k-loop, 1: epilogue, 2: tiles}].
