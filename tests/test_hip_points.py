@@ -31,7 +31,36 @@ def test_fps_bit_exact(B, N, G):
     assert torch.equal(centers.cpu(), torch.gather(pts, 1, ref[:, :, None].expand(B, G, 3)))
 
 
-@pytest.mark.parametrize("B,N,G,k", [(4, 256, 16, 8), (2, 8192, 512, 32)])
+@pytest.mark.parametrize("B,N,G,k,mass", [(3, 256, 16, 8, 0), (1, 8192, 64, 32, 0), (2, 1024, 24, 16, 0), (1, 8192, 16, 32, 600),
+                                          (2, 1024, 8, 100, 0), (1, 2048, 8, 64, 300)])
+def test_knn_lds_staged_and_direct_paths_agree(B, N, G, k, mass):
+    """Round 4: with 8 centres of one cloud per workgroup the cloud is staged in LDS (`knn_group_reg_kernel<.., 8, true>`)
+    and the selection runs on a short candidate list (keys below the k-th smallest per-lane minimum); a cloud pointer that is
+    not 16-byte aligned (or G not a multiple of 8) takes the direct kernel with the full-width radix select.  Same
+    arithmetic: the neighbour indices and the centred bf16 patches must be IDENTICAL, ties included (duplicated points force
+    ties; `mass` copies of ONE point overflow the candidate list -> the full-width path inside the LDS kernel; k > 64 never
+    enters the candidate path)."""
+    from vitlens_hip import ops
+    g = torch.Generator().manual_seed(N + G)
+    pts = torch.rand(B, N, 3, generator=g) * 2 - 1
+    pts[:, N // 2:N // 2 + 40] = pts[:, :40]                     # exact duplicates: equal distances at the k-th place
+    cidx = torch.stack([torch.randperm(N, generator=g)[:G] for _ in range(B)])
+    if mass:
+        pts[:, 100:100 + mass] = pts[:, 5:6]                     # a mass of points at one place, and a centre on it
+        cidx[:, 0] = 5
+    a = pts.cuda()
+    buf = torch.empty(B * N * 3 + 1, device="cuda")
+    m = buf[1:].view(B, N, 3)                                    # 4 bytes off a 16-byte boundary
+    m.copy_(a)
+    assert a.data_ptr() % 16 == 0 and m.data_ptr() % 16 == 4
+    p1, i1 = ops.knn_group(a, cidx.cuda(), k, Kp=8, want_idx=True)
+    p2, i2 = ops.knn_group(m, cidx.cuda(), k, Kp=8, want_idx=True)
+    assert torch.equal(i1, i2)
+    assert torch.equal(p1.view(torch.int16), p2.view(torch.int16))
+    assert len(set(i1[0, 0].tolist())) == k
+
+
+@pytest.mark.parametrize("B,N,G,k", [(4, 256, 16, 8), (2, 8192, 512, 32), (4, 256, 12, 8)])
 def test_knn_sets(B, N, G, k):
     from vitlens_hip import ops
     g = torch.Generator().manual_seed(N + k)

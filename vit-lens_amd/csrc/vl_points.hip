@@ -165,16 +165,34 @@ __device__ __forceinline__ int wave_sum_int(int v) {
   return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 
-template <int NPL>
-__global__ void __launch_bounds__(256) knn_group_reg_kernel(const float* xyz, const int64_t* cidx, int G, int k, int* nidx,
-                                                            bf16_t* patches, int Kp) {
+// LDSC (round 4): the WPB centres of a workgroup belong to ONE cloud (host: G % WPB == 0), which is copied once into LDS -
+// [N][3] as it lies in memory (lane stride 3 dwords: conflict-free) plus the N squared norms - instead of every wave reading
+// its 96 KB twice through L1 / L2 (12.6 GB of cache traffic per 128 x 512 centres of 8192 points); the squared norms are the
+// same expression evaluated once per cloud instead of twice per centre.  Same arithmetic, same bits, same selection order.
+constexpr int KNN_CAP = 256;      // candidate list entries per wave (LDS-staged form)
+template <int NPL, int WPB, bool LDSC>
+__global__ void __launch_bounds__(WPB * 64) knn_group_reg_kernel(const float* xyz, const int64_t* cidx, int G, int k, int* nidx,
+                                                                bf16_t* patches, int Kp) {
   constexpr int N = NPL * 64;
+  extern __shared__ __attribute__((aligned(16))) float s_cloud[];    // LDSC: [N * 3] points, [N] squared norms, [WPB][2][KNN_CAP] candidates
   const int lane = threadIdx.x & 63;
-  const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);        // global centre index b*G + g
+  const long w = (long)blockIdx.x * WPB + (threadIdx.x >> 6);      // global centre index b*G + g
   const int b = (int)(w / G);
   const float* P = xyz + (size_t)b * N * 3;
+  if constexpr (LDSC) {
+    const f32x4* src = (const f32x4*)P;                              // (host: 16-byte aligned; N * 12 bytes is a multiple of 16)
+    for (int i = threadIdx.x; i < N * 3 / 4; i += WPB * 64) ((f32x4*)s_cloud)[i] = src[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += WPB * 64) {
+#pragma clang fp contract(off)
+      const float x = s_cloud[i * 3], y = s_cloud[i * 3 + 1], z = s_cloud[i * 3 + 2];
+      s_cloud[N * 3 + i] = (x * x + y * y) + z * z;
+    }
+    __syncthreads();
+  }
+  auto coord = [&](int i, int c) { if constexpr (LDSC) return s_cloud[i * 3 + c]; else return P[i * 3 + c]; };
   const int ci = (int)cidx[w];
-  const float cx = P[ci * 3], cy = P[ci * 3 + 1], cz = P[ci * 3 + 2];
+  const float cx = coord(ci, 0), cy = coord(ci, 1), cz = coord(ci, 2);
   float cc;
   {
 #pragma clang fp contract(off)
@@ -183,9 +201,10 @@ __global__ void __launch_bounds__(256) knn_group_reg_kernel(const float* xyz, co
   auto dist_key = [&](int i) {
     // no implicit contraction: the key is computed twice (radix select, selection pass) and must come out identical
 #pragma clang fp contract(off)
-    const float x = P[i * 3], y = P[i * 3 + 1], z = P[i * 3 + 2];
+    const float x = coord(i, 0), y = coord(i, 1), z = coord(i, 2);
     const float dot = __builtin_fmaf(cz, z, __builtin_fmaf(cy, y, cx * x));
-    const float pp = (x * x + y * y) + z * z;
+    float pp;
+    if constexpr (LDSC) pp = s_cloud[N * 3 + i]; else pp = (x * x + y * y) + z * z;
     return sort_key((-2.0f * dot + cc) + pp);                    // dist = -2ab; dist += |a|^2; dist += |b|^2
   };
   unsigned int key[NPL];
@@ -193,6 +212,84 @@ __global__ void __launch_bounds__(256) knn_group_reg_kernel(const float* xyz, co
   for (int j = 0; j < NPL; ++j) {
     key[j] = dist_key(lane + j * 64);
     if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);      // at most 16 points' loads in flight: the keys need the registers
+  }
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  auto emit = [&](int i, int slot) {
+    if (nidx) nidx[w * k + slot] = i;
+    if (patches) {
+      bf16_t* o = patches + ((size_t)w * k + slot) * Kp;
+      o[0] = f2bf(__fsub_rn(coord(i, 0), cx)); o[1] = f2bf(__fsub_rn(coord(i, 1), cy)); o[2] = f2bf(__fsub_rn(coord(i, 2), cz));
+      for (int e = 3; e < Kp; ++e) o[e] = 0;
+    }
+  };
+  if constexpr (LDSC) {
+    // Candidate pre-selection (k <= 64): the k-th smallest of the 64 per-lane MINIMA is an upper bound U of the k-th smallest
+    // key with at least k keys <= U (each lane minimum is a key) and - for scattered points - only about 1.4 k keys below it.
+    // Those candidates go to a per-wave LDS list in INDEX order (ballot prefix), and both the radix select and the
+    // tie-aware selection run on <= 4 keys per lane instead of NPL.  More than KNN_CAP candidates (masses of equal
+    // distances): the full-width path below.  Same threshold, same tie rule, same output order - bit-identical results.
+    unsigned int* ck_l = (unsigned int*)(s_cloud + N * 4) + (threadIdx.x >> 6) * (2 * KNN_CAP);
+    int* ci_l = (int*)ck_l + KNN_CAP;
+    if (k <= 64) {
+      unsigned int mn = key[0];
+#pragma unroll
+      for (int j = 1; j < NPL; ++j) mn = min(mn, key[j]);
+      unsigned int U = 0;                                      // largest U with count(mn < U) < k == k-th smallest lane minimum
+      for (int bit = 31; bit >= 0; --bit) {
+        const unsigned int trial = U | (1u << bit);
+        if (__popcll(__ballot(mn < trial)) < k) U = trial;
+      }
+      int ncand = 0;
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) {
+        const bool c = key[j] <= U;
+        const unsigned long long bl = __ballot(c);
+        if (bl != 0ull) {                                      // (wave-uniform)
+          const int pos = ncand + __popcll(bl & lt_mask);
+          if (c && pos < KNN_CAP) { ck_l[pos] = key[j]; ci_l[pos] = lane + j * 64; }
+          ncand += __popcll(bl);
+        }
+      }
+      if (ncand <= KNN_CAP) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        constexpr int CPL = KNN_CAP / 64;
+        unsigned int ck[CPL]; int ci[CPL]; bool cv[CPL];
+#pragma unroll
+        for (int m = 0; m < CPL; ++m) {
+          const int pth = lane + m * 64;
+          cv[m] = pth < ncand;
+          ck[m] = cv[m] ? ck_l[pth] : 0xffffffffu;             // never < any trial; equality is masked by cv
+          ci[m] = cv[m] ? ci_l[pth] : 0;
+        }
+        unsigned int T = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+          const unsigned int trial = T | (1u << bit);
+          int c = 0;
+#pragma unroll
+          for (int m = 0; m < CPL; ++m) c += __popcll(__ballot(ck[m] < trial));
+          if (c < k) T = trial;
+        }
+        int nlt = 0;
+#pragma unroll
+        for (int m = 0; m < CPL; ++m) nlt += __popcll(__ballot(ck[m] < T));
+        int need_eq = k - nlt, base = 0;
+#pragma unroll
+        for (int m = 0; m < CPL; ++m) {
+          const bool less = ck[m] < T;
+          const bool eq = cv[m] && ck[m] == T;
+          const unsigned long long bl = __ballot(less), be = __ballot(eq);
+          const int eq_rank = __popcll(be & lt_mask);
+          const bool take_eq = eq && eq_rank < need_eq;
+          const unsigned long long bt = bl | __ballot(take_eq);
+          if (less || take_eq) emit(ci[m], base + __popcll(bt & lt_mask));
+          base += __popcll(bt);
+          need_eq -= min(need_eq, __popcll(be));
+        }
+        return;
+      }
+    }
   }
   // largest T with count(key < T) < k  ==  k-th smallest key
   unsigned int T = 0;
@@ -208,9 +305,8 @@ __global__ void __launch_bounds__(256) knn_group_reg_kernel(const float* xyz, co
   for (int j = 0; j < NPL; ++j) nl += key[j] < T;
   int need_eq = k - wave_sum_int(nl);                        // ties at the k-th distance: lowest indices first
   int base = 0;
-  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  // selection in index order: a ROLLED loop that recomputes each key from the (cache-resident) cloud - the same arithmetic,
-  // hence the same bits - instead of 128 unrolled ballot groups on the register array (which spilled 178 SGPRs)
+  // selection in index order: a ROLLED loop that recomputes each key from the (cache- or LDS-resident) cloud - the same
+  // arithmetic, hence the same bits - instead of 128 unrolled ballot groups on the register array (which spilled 178 SGPRs)
   for (int j = 0; j < NPL; ++j) {
     const int i = lane + j * 64;
     const unsigned int kj = dist_key(i);
@@ -221,15 +317,7 @@ __global__ void __launch_bounds__(256) knn_group_reg_kernel(const float* xyz, co
     const int eq_rank = __popcll(be & lt_mask);
     const bool take_eq = eq && eq_rank < need_eq;
     const unsigned long long bt = bl | __ballot(take_eq);
-    if (less || take_eq) {
-      const int slot = base + __popcll(bt & lt_mask);
-      if (nidx) nidx[w * k + slot] = i;
-      if (patches) {
-        bf16_t* o = patches + ((size_t)w * k + slot) * Kp;
-        o[0] = f2bf(__fsub_rn(P[i * 3], cx)); o[1] = f2bf(__fsub_rn(P[i * 3 + 1], cy)); o[2] = f2bf(__fsub_rn(P[i * 3 + 2], cz));
-        for (int e = 3; e < Kp; ++e) o[e] = 0;
-      }
-    }
+    if (less || take_eq) emit(i, base + __popcll(bt & lt_mask));
     base += __popcll(bt);
     need_eq -= min(need_eq, __popcll(be));
   }
@@ -383,8 +471,24 @@ extern "C" int vl_knn_group(const float* xyz, const int64_t* center_idx, int* ni
   if ((N & 63) || ((long)B * G) % 4) return vl_set_error("vl_knn_group: N must be a multiple of 64 and B*G of 4");
   if (patches && Kp < 3) return vl_set_error("vl_knn_group: Kp < 3");
   const dim3 grid((unsigned)(((long)B * G) / 4)), block(256);
-  switch (N) {       // keys in registers for the cloud sizes of the configs (8192: the Lens, 1024 / 2048: ablations, 256: the tests)
-#define VL_KNN_REG(NPLV) case NPLV * 64: hipLaunchKernelGGL(knn_group_reg_kernel<NPLV>, grid, block, 0, stream, xyz, center_idx, G, k, nidx, (bf16_t*)patches, Kp); VL_HIP_OK(hipGetLastError()); return 0;
+  // keys in registers for the cloud sizes of the configs (8192: the Lens, 1024 / 2048: ablations, 256: the tests); with 8
+  // centres of one cloud per workgroup the cloud itself is staged in LDS (16 bytes per point)
+  const bool lds_ok = (G % 8) == 0 && (((uintptr_t)xyz) & 15) == 0;
+  switch (N) {
+#define VL_KNN_REG(NPLV)                                                                                                       \
+  case NPLV * 64:                                                                                                              \
+    if (lds_ok) {                                                                                                              \
+      static const hipError_t attr = hipFuncSetAttribute((const void*)knn_group_reg_kernel<NPLV, 8, true>,                     \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, NPLV * 64 * 16 + 8 * KNN_CAP * 8);          \
+      VL_HIP_OK(attr);                                                                                                         \
+      hipLaunchKernelGGL((knn_group_reg_kernel<NPLV, 8, true>), dim3((unsigned)(((long)B * G) / 8)), dim3(512),                \
+                         (size_t)NPLV * 64 * 16 + 8 * KNN_CAP * 8, stream, xyz, center_idx, G, k, nidx, (bf16_t*)patches, Kp);                   \
+    } else {                                                                                                                   \
+      hipLaunchKernelGGL((knn_group_reg_kernel<NPLV, 4, false>), grid, block, 0, stream, xyz, center_idx, G, k, nidx,          \
+                         (bf16_t*)patches, Kp);                                                                                \
+    }                                                                                                                          \
+    VL_HIP_OK(hipGetLastError());                                                                                              \
+    return 0;
     VL_KNN_REG(4) VL_KNN_REG(16) VL_KNN_REG(32) VL_KNN_REG(128)
 #undef VL_KNN_REG
     default: break;
