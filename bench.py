@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--text-wsplit", default="on", choices=["on", "off"],
                     help="text tower weights as two bf16 terms (on: cosine matrices within 1e-3 of the fp32 CPU path; off: the "
                          "reference's amp_bf16 arithmetic, 1.3-1.5e-3)")
+    ap.add_argument("--ln-fold", default="on", choices=["on", "off"],
+                    help="LayerNorms of the frozen ViT blocks folded into the GEMMs either side of them (on) or run as their own "
+                         "passes (off): A/B switch, sets VL_LN_FOLD before the package is imported")
     ap.add_argument("--force-dist", action="store_true",
                     help="--gpus 1 only: initialise a ONE-rank RCCL communicator and run the step's multi-rank code path on it "
                          "(packed all-gather, bucketed async all-reduce; prints collective_ms_per_step) - the API / stream "
@@ -117,6 +120,31 @@ class GemmTimer:
             return out
 
         self.ops.gemm = gemm
+        # the LayerNorm-folding entries (ops.gemm_lnfold / gemm_res_rowstats: persistent kernel on the main rows + the leftover
+        # rows through ops.gemm) are timed as ONE record per call under the key of the GEMM they stand for
+        inner, lnf, rrs = self._gemm, self.ops.gemm_lnfold, self.ops.gemm_res_rowstats
+
+        def timed(key, fn, *args, **kw):
+            if not self.on:
+                return fn(*args, **kw)
+            self.ops.gemm = inner                      # the leftover-row call inside must not add a record of its own
+            try:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); out = fn(*args, **kw); e1.record()
+            finally:
+                self.ops.gemm = gemm
+            self.records.append((key, e0, e1))
+            return out
+
+        def gemm_lnfold(x, fold, mean, rstd, out, *args, **kw):
+            key = ("gemm", x.shape[0], fold[0].shape[0], x.shape[1], self.ops.EPI_BF16, kw.get("act", 0))
+            return timed(key, lnf, x, fold, mean, rstd, out, *args, **kw)
+
+        def gemm_res_rowstats(a, w, *args, **kw):
+            key = ("gemm", a.shape[0], w.shape[0], a.shape[1], self.ops.EPI_RES_BF16, 0)
+            return timed(key, rrs, a, w, *args, **kw)
+
+        self.ops.gemm_lnfold, self.ops.gemm_res_rowstats = gemm_lnfold, gemm_res_rowstats
 
     def summary(self):
         agg = {}
@@ -444,6 +472,7 @@ def selftest_main(a, rank, world):
 
 def main():
     a = parse()
+    os.environ["VL_LN_FOLD"] = "1" if a.ln_fold == "on" else "0"      # read when vitlens_hip.engine is imported
     have_rank = "RANK" in os.environ
     if a.gpus > 1 and not have_rank:
         sys.exit(spawn_ranks(a.gpus))
@@ -629,6 +658,7 @@ def main():
                           "global_batch": world * a.batch, "residual_dtype": a.res_dtype,
                           "accumulate": "fp32", "parallelism": f"dp{world}", "gemm_cfg": a.gemm_cfg, "via": a.via,
                           "text_tower_weights": "bf16 x 2 terms" if (a.text_wsplit == "on" and a.workload != "c2") else "bf16",
+                          "layernorm": "folded into the GEMMs (frozen blocks)" if a.ln_fold == "on" else "own passes",
                           **({"force_dist": True} if a.force_dist else {})},
                "roofline": roof}
         if use_dist:         # diagnosis of a scaling run: per-rank step time (stragglers) and the exchange's share of the step

@@ -107,6 +107,32 @@ int vl_device_info(int device, char* arch, int arch_len, int* cus, int* clock_kh
 int vl_attn_fwd_bf16(const void* q, const void* k, const void* v, const long* strides, void* out, float* lse,
                      int B, int H, int Lq, int Lk, int dh, float qscale, int causal, hipStream_t stream);
 
+/* LayerNorm folded into the GEMMs either side of it (round 4).  For a FROZEN pre-LN block on a bf16 residual stream
+ * (ResidualAttentionBlock, transformer.py:254-272: x + attn(ln_1(x)), x + mlp(ln_2(x)); LayerNorm transformer.py:17-34)
+ *     LN(x) W^T + b  =  rstd_m (x (W gamma)^T - mean_m c) + (b + W beta),      c_n = sum_k (W gamma)[n, k]
+ * so the consuming GEMM can read the raw residual rows and apply the row statistics in its epilogue, and the GEMM that
+ * produced those rows can leave their partial sums behind: the normalised activations are never written or read.
+ *   vl_gemm_main_rows          rows of an [M, K] x [N, K]^T problem that vl_gemm_bf16 (cfg -1) gives to the persistent
+ *                              256x256-tile kernel; the entries below take exactly such row ranges (0: none)
+ *   vl_gemm_lnfold_bf16        out bf16[M,N] = act(rstd_m * (A Wg^T - mean_m * ln_c) + bias_f); A = raw rows bf16 [M,K],
+ *                              Wg = bf16(W * gamma) [N,K], bias_f = b + W beta f32 [N], ln_c f32 [N] (sums of the ROUNDED
+ *                              Wg rows), ln_mean / ln_rstd f32 [M]; act = VL_ACT_NONE / VL_ACT_GELU / VL_ACT_GELU_DSAVE
+ *                              (out2 = gelu', as vl_gemm_bf16_ex)
+ *   vl_gemm_res_rowstats_bf16  out bf16 = res + A W^T + bias (VL_EPI_RES_BF16, in place allowed) and row_part f32
+ *                              [M][N/64][2] = (sum, sum of squares) of the STORED bf16 values per row and 64-column slice
+ *   vl_ln_row_stats            mean / rstd [rows]: rows < m_main from row_part (P = N/64 slices, summed in slice order),
+ *                              rows >= m_main from the bf16 rows themselves (the leftover rows of a row-split GEMM)
+ * Whole 256x256 tiles, K >= 512, 16-byte aligned operands; anything else is refused (the caller keeps vl_layernorm_fwd +
+ * vl_gemm_bf16 for it). */
+int vl_gemm_main_rows(int M, int N);
+int vl_gemm_lnfold_bf16(const void* A, const void* Wg, const float* bias_f, const float* ln_c, const float* ln_mean,
+                        const float* ln_rstd, void* out, void* out2, int M, int N, int K, int lda, int ldw, int ldo, int act,
+                        hipStream_t stream);
+int vl_gemm_res_rowstats_bf16(const void* A, const void* W, const float* bias, void* out, const void* res, float* row_part,
+                              int M, int N, int K, int lda, int ldw, int ldo, hipStream_t stream);
+int vl_ln_row_stats(const float* row_part, int P, const void* x_bf16, long x_row_stride, int D, int m_main, int rows, float eps,
+                    float* mean, float* rstd, hipStream_t stream);
+
 /* LayerNorm over the last dim (eps inside sqrt, biased variance): y = (x-mean)*rstd*w + b.
  * Source row for output row r is  r*row_mul + row_index[r]  when row_index != NULL (EOT gather,
  * model.py:539; cls pooling uses row_index == NULL with x_row_stride = (T+1)*D), else r.

@@ -46,3 +46,44 @@ for name, (M, N, K), kw in CASES:
     ms = e0.elapsed_time(e1) / n
     print(f"{name:20s} {ms:7.4f} ms {2.0 * M * N * K / ms / 1e9:7.1f} TF/s | per tile: k-loop {p[:, 0].sum() / tiles:8.0f} clk ({K // 64} k-steps, "
           f"{p[:, 0].sum() / tiles / (K // 64):6.0f} per step)  epilogue {p[:, 1].sum() / tiles:7.0f} clk = {100 * p[:, 1].sum() / (p[:, 0].sum() + p[:, 1].sum()):4.1f} %", flush=True)
+
+# ---- round 4: the LayerNorm-folding variants next to their plain counterparts ----
+def _prof(name, fn, M, N, K):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    prof.zero_(); buf_sym.value = prof.data_ptr()
+    n = 5
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    buf_sym.value = None
+    p = prof.view(256, 4).cpu().double()
+    tiles = p[:, 2].sum()
+    ms = e0.elapsed_time(e1) / n
+    print(f"{name:28s} {ms:7.4f} ms {2.0 * M * N * K / ms / 1e9:7.1f} TF/s | per tile: k-loop {p[:, 0].sum() / tiles:8.0f} clk ({K // 64} k-steps, "
+          f"{p[:, 0].sum() / tiles / (K // 64):6.0f} per step)  epilogue {p[:, 1].sum() / tiles:7.0f} clk = {100 * p[:, 1].sum() / (p[:, 0].sum() + p[:, 1].sum()):4.1f} %", flush=True)
+
+
+if os.environ.get("LNFOLD", "1") != "0":
+    D = 1024
+    x = torch.randn(T, D, device="cuda").bfloat16()
+    gam, bet = 1 + 0.2 * torch.randn(D, device="cuda"), 0.1 * torch.randn(D, device="cuda")
+    mean, rstd = torch.empty(T, device="cuda"), torch.empty(T, device="cuda")
+    ops.ln_row_stats(None, x, 0, mean, rstd)
+    part = torch.empty(T * (D // 64) * 2, device="cuda")
+    hws = torch.empty(1, D, device="cuda", dtype=torch.bfloat16)
+    for name, N, act in (("qkv", 3072, ops.ACT_NONE), ("c_fc gelu", 4096, ops.ACT_GELU), ("c_fc gelu+dsave", 4096, ops.ACT_GELU_DSAVE)):
+        w = torch.randn(N, D, device="cuda") * D ** -0.5; b = 0.02 * torch.randn(N, device="cuda")
+        f = ops.fold_ln_linear(w, b, gam, bet); w16 = w.bfloat16()
+        out = torch.empty(T, N, device="cuda", dtype=torch.bfloat16)
+        out2 = torch.empty_like(out) if act == ops.ACT_GELU_DSAVE else None
+        _prof(name + " plain", lambda: ops.gemm(x, w16, b, out=out, epi=ops.EPI_BF16, act=act, cfg=8, out2=out2), T, N, D)
+        _prof(name + " LN-folded", lambda: ops.gemm_lnfold(x, f, mean, rstd, out, w16, b, gam, bet, hws, act=act, out2=out2), T, N, D)
+    for name, K in (("out + res", 1024), ("c_proj + res", 4096)):
+        a = torch.randn(T, K, device="cuda").bfloat16(); w = (torch.randn(D, K, device="cuda") * K ** -0.5).bfloat16(); b = 0.02 * torch.randn(D, device="cuda")
+        xo = torch.empty_like(x)
+        _prof(name + " plain", lambda: ops.gemm(a, w, b, out=xo, res=x, epi=ops.EPI_RES_BF16, cfg=8), T, D, K)
+        _prof(name + " + row sums", lambda: ops.gemm_res_rowstats(a, w, b, xo, x, part), T, D, K)

@@ -841,6 +841,57 @@ static hipError_t run_gemm(const GemmP& p, int cfg, hipStream_t s) {
 
 #define VL_CHECK_ARG(c, msg) do { if (!(c)) return vl_set_error(msg); } while (0)
 
+// ---- LayerNorm folded into the GEMMs either side of it (round 4; frozen pre-LN blocks on a bf16 residual stream) ----
+// LN(x) W^T + b = rstd (x (W gamma)^T - mean c) + (b + W beta),  c_n = sum_k (W gamma)[n, k]: the consuming GEMM reads the raw
+// residual rows and applies the row statistics in its epilogue; the GEMM that PRODUCED those rows (out-projection /
+// c_proj + residual) leaves their partial sums behind.  The normalised activations are never written or read: one
+// LayerNorm pass (2 x rows x D x 2 bytes at the HBM roofline) per LayerNorm disappears.  Persistent kernel only (whole
+// 256x256 tiles): the host code runs the rows vl_gemm_main_rows() reports through these entries and the leftover rows
+// through vl_layernorm_fwd + vl_gemm_bf16.
+extern "C" int vl_gemm_main_rows(int M, int N) {
+  const int G = num_cus() & ~7;
+  if (M <= 0 || N <= 0 || (N & 255)) return 0;
+  const int tiles_n = N / 256, full_m = M / 256;
+  if ((long)full_m * tiles_n < (G * 3) / 4) return 0;
+  const int step = G / gcd_i(G, tiles_n);
+  int main_m = (full_m / step) * step;
+  if (main_m == 0) main_m = full_m;
+  return main_m * 256;
+}
+
+extern "C" int vl_gemm_lnfold_bf16(const void* A, const void* Wg, const float* bias_f, const float* ln_c, const float* ln_mean,
+                                   const float* ln_rstd, void* out, void* out2, int M, int N, int K, int lda, int ldw, int ldo,
+                                   int act, hipStream_t stream) {
+  VL_CHECK_ARG(A && Wg && bias_f && ln_c && ln_mean && ln_rstd && out, "vl_gemm_lnfold_bf16: null operand");
+  VL_CHECK_ARG(act == VL_ACT_NONE || act == VL_ACT_GELU || act == VL_ACT_GELU_DSAVE, "vl_gemm_lnfold_bf16: act must be none, GELU or GELU_DSAVE");
+  VL_CHECK_ARG((act == VL_ACT_GELU_DSAVE) == (out2 != nullptr), "vl_gemm_lnfold_bf16: out2 goes with VL_ACT_GELU_DSAVE");
+  VL_CHECK_ARG((((uintptr_t)ln_c | (uintptr_t)bias_f) & 15) == 0, "vl_gemm_lnfold_bf16: column vectors must be 16-byte aligned");
+  GemmP p{};
+  p.A = (const bf16_t*)A; p.W = (const bf16_t*)Wg; p.bias = bias_f; p.out = out; p.out2 = out2;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.alpha = 1.0f; p.act = act; p.res_div = 1;
+  p.ln_mean = ln_mean; p.ln_rstd = ln_rstd; p.ln_c = ln_c;
+  const GemmP q = tuned(p);
+  VL_CHECK_ARG(q.mfma16 && vl_gemm_park_supported(EPI_BF16, &q), "vl_gemm_lnfold_bf16: whole 256x256 tiles, K >= 512, 16-byte aligned operands required");
+  const hipError_t e = (hipError_t)vl_gemm_park_launch(EPI_BF16, &q, num_cus(), stream);
+  if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int vl_gemm_res_rowstats_bf16(const void* A, const void* W, const float* bias, void* out, const void* res,
+                                         float* row_part, int M, int N, int K, int lda, int ldw, int ldo, hipStream_t stream) {
+  VL_CHECK_ARG(A && W && out && res && row_part, "vl_gemm_res_rowstats_bf16: null operand");
+  VL_CHECK_ARG((((uintptr_t)row_part) & 7) == 0, "vl_gemm_res_rowstats_bf16: row_part must be 8-byte aligned");
+  GemmP p{};
+  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = bias; p.out = out; p.res = res;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.alpha = 1.0f; p.res_div = 1;
+  p.row_part = row_part;
+  const GemmP q = tuned(p);
+  VL_CHECK_ARG(q.mfma16 && vl_gemm_park_supported(EPI_RES_BF16, &q), "vl_gemm_res_rowstats_bf16: whole 256x256 tiles, K >= 512, 16-byte aligned operands required");
+  const hipError_t e = (hipError_t)vl_gemm_park_launch(EPI_RES_BF16, &q, num_cus(), stream);
+  if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
+  return 0;
+}
+
 extern "C" int vl_gemm_bf16_ex(const void* A, const void* W, const float* bias, void* out, const void* res, void* out2,
                                int M, int N, int K, int lda, int ldw, int ldo, float alpha, int epi, int act,
                                int res_div, int cfg, hipStream_t stream);

@@ -39,6 +39,14 @@ struct GemmP {
   int pp_delay;
   int pk_gn;         // persistent kernel: N-tiles per group of the tile order (0 = the built-in 4)
   int mfma16;        // persistent kernel: main loop on v_mfma_f32_16x16x32_bf16 (tuning input, set by the dispatcher)
+  // LayerNorm folded into the GEMM (round 4, persistent kernel only; vl_gemm_lnfold_bf16 / vl_gemm_res_rowstats_bf16):
+  //   consumer: A = the RAW rows x, W = bf16(W * gamma), bias = b + W beta, ln_c[n] = sum_k W'[n, k]:
+  //             out = act(rstd_m * (acc - mean_m * c_n) + bias_n)  ==  act(LN(x) W^T + b)
+  //   producer: EPI_RES_BF16 also writes, per row and 64-column slice, (sum, sum of squares) of the bf16 values it stores
+  const float* ln_mean;   // [M] of the rows of A (consumer)
+  const float* ln_rstd;   // [M]
+  const float* ln_c;      // [N]
+  float* row_part;        // [M][N / 64][2] partial row statistics of the output (producer)
 };
 
 // acc * alpha + bias as four plain v_fma_f32.  Left to the compiler, the vector expression becomes v_pk_fma_f32, and in
@@ -53,6 +61,11 @@ struct GemmP {
 // issue slots per 256x256 tile.
 __device__ __forceinline__ void mfma_results_settled() {
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {      // cross-lane move inside a row of 16 lanes (DPP control CTRL)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 
 __device__ __forceinline__ f32x4 scale_bias(f32x4 v, float alpha, f32x4 b) {

@@ -74,6 +74,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     gemm_nt_pk_kernel(const GemmP p PK_PROF_ARG) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool HAS_AUX = (EPI == EPI_RES_BF16 || EPI == EPI_DGELU);   // second operand of the output's shape
+  // LayerNorm folding (round 4; GemmP::ln_*): ACT 10 / 11 / 14 = ACT 0 / 1 / 4 with the row-statistics epilogue
+  // rstd_m * (acc - mean_m * c_n) + bias_n on the raw residual rows; EPI_RES_BF16 with ACT 20 also emits the partial row
+  // statistics (sum, sum of squares per 64-column slice) of what it stores, for the LayerNorm that follows it
+  constexpr bool LNF = (EPI == EPI_BF16 && ACT >= 10 && ACT < 20);
+  constexpr int ACTB = LNF ? ACT - 10 : ACT;
+  constexpr bool STATS = (EPI == EPI_RES_BF16 && ACT == 20);
+  static_assert(!(LNF || STATS) || M16, "the LayerNorm-folding epilogues exist for the 16x16x32 main loop only");
   // GEGLU (Perceiver feed-forward, perceiver.py:85-102): rows of W interleaved (a_j, gate_j) -> out[M, N/2] = a * gelu(gate),
   // optionally the bf16 pre-activation [M, N] to out2 (row stride 2 * ldo).  DGEGLU (its backward): acc = dy[M, N], res =
   // the saved pre-activation h[M, 2N]: out[M, 2N] = (dy * gelu(g), dy * a * gelu'(g)) interleaved (ldo = row stride of h / out).
@@ -253,7 +260,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   // NST operations outstanding" retires exactly that DMA and leaves the NST stores of this wave draining under the first
   // k-step instead of in front of it (measured with vmcnt(0): 0.2-0.7 k cycles per k-step of store drain charged to the
   // k-loop, 11 k per tile behind the two-output GELU epilogue).  NST = the minimum number of stores a wave issues per tile.
-  constexpr int NST = (EPI == EPI_F32 || EPI == EPI_RES_F32 || IS_DGEGLU || (EPI == EPI_BF16 && (ACT == 3 || ACT == 4))) ? 32 : 16;
+  constexpr int NST = (EPI == EPI_F32 || EPI == EPI_RES_F32 || IS_DGEGLU || STATS || (EPI == EPI_BF16 && (ACTB == 3 || ACTB == 4))) ? 32 : 16;
   auto first_wait_and_barrier = [&]() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NST) : "memory");
   };
@@ -370,6 +377,19 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
           for (int e = 0; e < 4; ++e) bvq[c][e] = has_bias ? bvq[c][e] : 0.f;
         }
       }
+      // LayerNorm folding: c_n of this lane's columns and (rstd, -mean * rstd) of its 8 rows, once per tile
+      [[maybe_unused]] f32x4 cvq[4];
+      [[maybe_unused]] float ln_r[8], ln_nm[8];
+      if constexpr (LNF) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cvq[c] = *(const f32x4*)(pe.ln_c + ncol0 + c * 16 + fq * 4);
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb) {                       // row block rb = 2 * i + j: rows mrow0 + rb * 16 + fr16
+          const float mu = pe.ln_mean[mrow0 + rb * 16 + fr16];
+          ln_r[rb] = pe.ln_rstd[mrow0 + rb * 16 + fr16];
+          ln_nm[rb] = -mu * ln_r[rb];
+        }
+      }
       // destination of this lane's chunks
       unsigned char* const out_base = (unsigned char*)pe.out + ((size_t)mrow0 * pe.ldo + ncol0) * 2 + lo_out;
       // GEGLU / DGEGLU lane offsets (other strides than the plain outputs)
@@ -449,11 +469,18 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             f32x4 v;
             if constexpr (M16) v = acc16[M16 ? i * 2 + j : 0][M16 ? q : 0];
             else v = f32x4{acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 0], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 1], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 2], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 3]};
-            v = scale_bias(v, pe.alpha, M16 ? bvq[M16 ? q : 0] : bias_at(ncol0 + j * 32 + q * 8 + fg * 4));
-            if constexpr (EPI == EPI_BF16 && ACT == 1) {
+            if constexpr (LNF) {
+              // rstd * acc + (bias - mean * rstd * c): two FMAs per value (alpha is 1 on this path)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                v[e] = __builtin_fmaf(ln_r[i * 2 + j], v[e], __builtin_fmaf(ln_nm[i * 2 + j], cvq[M16 ? q : 0][e], bvq[M16 ? q : 0][e]));
+            } else {
+              v = scale_bias(v, pe.alpha, M16 ? bvq[M16 ? q : 0] : bias_at(ncol0 + j * 32 + q * 8 + fg * 4));
+            }
+            if constexpr (EPI == EPI_BF16 && ACTB == 1) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-            } else if constexpr (EPI == EPI_BF16 && ACT == 2) {
+            } else if constexpr (EPI == EPI_BF16 && ACTB == 2) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
@@ -467,6 +494,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        [[maybe_unused]] float st1[4], st2[4];                 // STATS: this lane's partial row sums of the four passes
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
           const int r = pass * 8 + prow;
@@ -503,12 +531,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             __builtin_nontemporal_store(o2[0], (u32x4*)dst);
             __builtin_nontemporal_store(o2[1], (u32x4*)(dst + 16));
             continue;
-          } else if constexpr (EPI == EPI_BF16 && ACT == 3) {
+          } else if constexpr (EPI == EPI_BF16 && ACTB == 3) {
             __builtin_nontemporal_store(w, (u32x4*)((unsigned char*)pe.out2 + ((size_t)(mrow0 + i * 32 + pass * 8) * pe.ldo + ncol0) * 2 + lo_out));
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               w[e] = pack2bf(gelu_erf(bf2f((bf16_t)(w[e] & 0xffff))), gelu_erf(bf2f((bf16_t)(w[e] >> 16))));
-          } else if constexpr (EPI == EPI_BF16 && ACT == 4) {
+          } else if constexpr (EPI == EPI_BF16 && ACTB == 4) {
             u32x4 d;                                              // out2 = gelu'(pre) for the dX GEMM of the backward
 #pragma unroll
             for (int e = 0; e < 4; ++e) { unsigned int y, g; gelu_and_grad_pk(w[e], y, g); w[e] = y; d[e] = g; }
@@ -520,6 +548,21 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
               const float hi = bf2f((bf16_t)(w[e] >> 16)) + bf2f((bf16_t)(rr[e] >> 16));
               w[e] = pack2bf(lo, hi);
             }
+            if constexpr (STATS) {
+              // (sum, sum of squares) of the 8 STORED values (bf16-rounded: what the next LayerNorm will read) of this lane:
+              // two bf16 dot products per dword; the cross-lane part waits for the end of the row block (below)
+              // (inline assembly: through __builtin_amdgcn_fdot2_f32_bf16 hipcc 7.2 fed all four dot products of this loop
+              //  the FIRST dword of w - found by tests/test_hip_lnfold.py, visible in the ISA)
+              const unsigned one2 = 0x3f803f80u;
+              float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const unsigned we = w[e];
+                asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s1) : "v"(we), "v"(one2));
+                asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s2) : "v"(we), "v"(we));
+              }
+              st1[pass] = s1; st2[pass] = s2;
+            }
           } else if constexpr (EPI == EPI_DGELU && ACT == 4) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) w[e] = mul_pk_bf16(w[e], rr[e]);     // aux = gelu' saved by the forward
@@ -530,6 +573,23 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                              bf2f((bf16_t)(w[e] >> 16)) * gelu_erf_grad(bf2f((bf16_t)(rr[e] >> 16))));
           }
           __builtin_nontemporal_store(w, (u32x4*)(out_base + (size_t)((i * 32 + pass * 8) * ldo2)));
+        }
+        if constexpr (STATS) {
+          // the 8 lanes that hold a row's 64 columns of this wave: eight independent three-step reductions (lanes ^1, ^2,
+          // mirror of the half row), then one 8-byte store per row and 64-column slice
+          asm volatile("s_nop 1" ::: "memory");     // the sums come out of inline assembly: the DPP read's wait states by hand
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) { st1[pass] += dpp_f<0xB1>(st1[pass]); st2[pass] += dpp_f<0xB1>(st2[pass]); }
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) { st1[pass] += dpp_f<0x4E>(st1[pass]); st2[pass] += dpp_f<0x4E>(st2[pass]); }
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) { st1[pass] += dpp_f<0x141>(st1[pass]); st2[pass] += dpp_f<0x141>(st2[pass]); }
+          if ((el & 7) == 0) {
+            float* dst = pe.row_part + ((size_t)(mrow0 + i * 32 + prow) * (pe.N >> 6) + (ncol0 >> 6)) * 2;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass)
+              *(vl_f32x2*)(dst + (size_t)pass * 8 * (pe.N >> 6) * 2) = vl_f32x2{st1[pass], st2[pass]};
+          }
         }
       };
       row_block(IC<0>{}); row_block(IC<1>{}); row_block(IC<2>{}); row_block(IC<3>{});
@@ -596,10 +656,18 @@ int vl_gemm_park_launch(int epi, const void* params, int ncu, hipStream_t s) {
   const GemmP& p = *(const GemmP*)params;
   switch (epi) {
     case EPI_BF16:
+      if (p.ln_mean) {        // LayerNorm folded into the epilogue (vl_gemm_lnfold_bf16 checked the rest)
+        if (!p.mfma16) return (int)hipErrorInvalidValue;
+        if (p.act == 1) return (int)launch_pk_v<EPI_BF16, 11, true>(p, ncu, s);
+        if (p.act == 4) return (int)launch_pk_v<EPI_BF16, 14, true>(p, ncu, s);
+        return p.act == 0 ? (int)launch_pk_v<EPI_BF16, 10, true>(p, ncu, s) : (int)hipErrorInvalidValue;
+      }
       if (p.act == 1) return p.out2 ? (int)launch_pk<EPI_BF16, 3>(p, ncu, s) : (int)launch_pk<EPI_BF16, 1>(p, ncu, s);
       if (p.act == 4) return (int)launch_pk<EPI_BF16, 4>(p, ncu, s);
       return p.act == 2 ? (int)launch_pk<EPI_BF16, 2>(p, ncu, s) : (int)launch_pk<EPI_BF16, 0>(p, ncu, s);
-    case EPI_RES_BF16: return (int)launch_pk<EPI_RES_BF16, 0>(p, ncu, s);
+    case EPI_RES_BF16:
+      if (p.row_part) return p.mfma16 ? (int)launch_pk_v<EPI_RES_BF16, 20, true>(p, ncu, s) : (int)hipErrorInvalidValue;
+      return (int)launch_pk<EPI_RES_BF16, 0>(p, ncu, s);
     case EPI_DGELU: return p.act == 4 ? (int)launch_pk<EPI_DGELU, 4>(p, ncu, s) : (int)launch_pk<EPI_DGELU, 0>(p, ncu, s);
     case EPI_GEGLU: return (int)launch_pk<EPI_GEGLU, 0>(p, ncu, s);
     case EPI_DGEGLU: return (int)launch_pk<EPI_DGEGLU, 0>(p, ncu, s);

@@ -251,6 +251,51 @@ extern "C" int vl_layernorm_fwd(const void* x, int x_dtype, long x_row_stride, c
   return 0;
 }
 
+// Row statistics (mean, rstd) for the LayerNorm folded into a GEMM epilogue (vl_gemm_lnfold_bf16): rows below m_main from the
+// partial (sum, sum of squares) pairs the producing GEMM left per 64-column slice (vl_gemm_res_rowstats_bf16; summed in slice
+// order: fixed), the remaining rows from the bf16 rows themselves (two-pass, as ln_rows_kernel).
+namespace {
+__global__ void __launch_bounds__(256) row_stats_kernel(const float* part, int P, const bf16_t* x, long xs, int D, int m_main,
+                                                        int rows, float eps, float* mean, float* rstd) {
+  const int nb_main = (m_main + 255) >> 8;
+  const float invD = 1.0f / (float)D;
+  if ((int)blockIdx.x < nb_main) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= m_main) return;
+    const vl_f32x2* pp = (const vl_f32x2*)part + (size_t)row * P;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < P; ++i) { const vl_f32x2 v = pp[i]; s1 += v[0]; s2 += v[1]; }
+    const float mu = s1 * invD;
+    const float var = fmaxf(fmaf(-mu, mu, s2 * invD), 0.f);
+    mean[row] = mu; rstd[row] = rsqrtf(var + eps);
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int row = m_main + ((int)blockIdx.x - nb_main) * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + (size_t)row * xs;
+  float s = 0.f;
+  for (int e = lane; e < D; e += 64) s += bf2f(xr[e]);
+  const float mu = wave_sum(s) * invD;
+  float q = 0.f;
+  for (int e = lane; e < D; e += 64) { const float d = bf2f(xr[e]) - mu; q = fmaf(d, d, q); }
+  const float rs = rsqrtf(wave_sum(q) * invD + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+}  // namespace
+
+extern "C" int vl_ln_row_stats(const float* row_part, int P, const void* x_bf16, long x_row_stride, int D, int m_main, int rows,
+                               float eps, float* mean, float* rstd, hipStream_t stream) {
+  if (rows <= 0 || D <= 0 || m_main < 0 || m_main > rows) return vl_set_error("vl_ln_row_stats: bad shape");
+  if (m_main > 0 && (!row_part || P <= 0 || (((uintptr_t)row_part) & 7))) return vl_set_error("vl_ln_row_stats: partial statistics missing");
+  if (m_main < rows && !x_bf16) return vl_set_error("vl_ln_row_stats: rows missing");
+  const int nb = ((m_main + 255) >> 8) + (rows - m_main + 3) / 4;
+  hipLaunchKernelGGL(row_stats_kernel, dim3(nb), dim3(256), 0, stream, row_part, P, (const bf16_t*)x_bf16, x_row_stride, D, m_main,
+                     rows, eps, mean, rstd);
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}
+
 extern "C" int vl_assemble_ln_pre(const void* tokens, int tok_dtype, const float* cls, const float* pos, const float* pos2,
                                   const float* w, const float* b, void* y, int y_dtype, float* xpre, float* mean, float* rstd,
                                   int B, int T, int D, float eps, hipStream_t stream) {

@@ -25,6 +25,10 @@ SIGNATURES = {
     "vl_gemm_tn_splitk_accum_f32": [P, P, P, I, I, I, I, I, L, F, I, P, P],
     "vl_attn_fwd_bf16": [P, P, P, P, P, P, I, I, I, I, I, F, I, P],
     "vl_layernorm_fwd": [P, I, L, P, L, P, P, P, I, L, P, P, I, I, F, P],
+    "vl_gemm_main_rows": [I, I],
+    "vl_gemm_lnfold_bf16": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "vl_gemm_res_rowstats_bf16": [P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "vl_ln_row_stats": [P, I, P, L, I, I, I, F, P, P, P],
     "vl_assemble_ln_pre": [P, I, P, P, P, P, P, P, I, P, P, P, I, I, I, F, P],
     "vl_l2_normalize": [P, P, P, P, I, I, F, P],
     "vl_l2_normalize_bwd": [P, P, P, P, I, I, F, P],

@@ -11,6 +11,8 @@ LayerNorm / softmax statistics / residual stream / final features fp32 (residual
 from dataclasses import dataclass
 from typing import Dict, Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -50,7 +52,17 @@ def _dev(t, device, dtype=torch.float32):
 
 
 def prep_block(sd: Dict[str, torch.Tensor], p: str, device) -> Dict[str, torch.Tensor]:
-    """Device copies of one ResidualAttentionBlock: GEMM weights bf16, the rest f32."""
+    """Device copies of one ResidualAttentionBlock: GEMM weights bf16, the rest f32; plus the operands of the two
+    LayerNorm -> Linear pairs with the LayerNorm folded in (ops.fold_ln_linear; used for frozen blocks on a bf16 stream)."""
+    bf = torch.bfloat16
+    dv = lambda k: sd[p + k].detach().to(device)
+    blk = _prep_block_plain(sd, p, device)
+    blk["in_f"] = ops.fold_ln_linear(dv("attn.in_proj_weight"), dv("attn.in_proj_bias"), dv("ln_1.weight"), dv("ln_1.bias"))
+    blk["fc_f"] = ops.fold_ln_linear(dv("mlp.c_fc.weight"), dv("mlp.c_fc.bias"), dv("ln_2.weight"), dv("ln_2.bias"))
+    return blk
+
+
+def _prep_block_plain(sd: Dict[str, torch.Tensor], p: str, device) -> Dict[str, torch.Tensor]:
     bf = torch.bfloat16
     return {
         "ln1_w": _dev(sd[p + "ln_1.weight"], device), "ln1_b": _dev(sd[p + "ln_1.bias"], device),
@@ -98,12 +110,36 @@ class _Workspace:
         self.q, self.k, self.v = hv(0), hv(1), hv(2)
         self.a = torch.empty(B * L, D, device=device, dtype=bf)
         self.hid = torch.empty(B * L, hidden, device=device, dtype=bf)
+        # LayerNorm folding: row statistics of the residual rows and the producing GEMMs' partial sums
+        self.mean = torch.empty(B * L, device=device, dtype=torch.float32)
+        self.rstd = torch.empty(B * L, device=device, dtype=torch.float32)
+        self.part = torch.empty(B * L * (D // 64) * 2, device=device, dtype=torch.float32) if D % 64 == 0 else None
 
 
-def run_blocks(blocks, ws: _Workspace, B, L, D, H, causal=False, cfg=-1):
-    """x (ws.x, residual stream) <- N pre-LN transformer blocks (transformer.py:254-272, 364-371)."""
+LN_FOLD = os.environ.get("VL_LN_FOLD", "1") != "0"      # measurement switch (bench.py --ln-fold off)
+
+
+def run_blocks(blocks, ws: _Workspace, B, L, D, H, causal=False, cfg=-1, fold=None):
+    """x (ws.x, residual stream) <- N pre-LN transformer blocks (transformer.py:254-272, 364-371).
+    fold (default: on for a bf16 stream): the LayerNorms folded into the GEMMs either side of them - ln_1 / ln_2 are never
+    materialised, the in-projection and c_fc read the residual rows and apply (mean, rstd) in their epilogues, the
+    out-projection and c_proj leave the partial row sums of what they store (ops.gemm_lnfold / gemm_res_rowstats)."""
     dh = D // H
     res_epi = ops.EPI_RES_F32 if ws.x.dtype == torch.float32 else ops.EPI_RES_BF16
+    if fold is None:
+        fold = LN_FOLD
+    if fold and ws.x.dtype == torch.bfloat16 and ws.part is not None and blocks and "in_f" in blocks[0]:
+        mm = 0                                            # rows of ws.x whose partial sums are in ws.part
+        for w in blocks:
+            ops.ln_row_stats(ws.part, ws.x, mm, ws.mean, ws.rstd)
+            ops.gemm_lnfold(ws.x, w["in_f"], ws.mean, ws.rstd, ws.qkv, w["in_w"], w["in_b"], w["ln1_w"], w["ln1_b"], ws.h, cfg=cfg)
+            ops.attn_fwd(ws.q, ws.k, ws.v, ws.a, causal=causal, qscale=dh ** -0.5 * ops.LOG2E)
+            mm = ops.gemm_res_rowstats(ws.a, w["out_w"], w["out_b"], ws.x, ws.x, ws.part, cfg=cfg)
+            ops.ln_row_stats(ws.part, ws.x, mm, ws.mean, ws.rstd)
+            ops.gemm_lnfold(ws.x, w["fc_f"], ws.mean, ws.rstd, ws.hid, w["fc_w"], w["fc_b"], w["ln2_w"], w["ln2_b"], ws.h,
+                            act=ops.ACT_GELU, cfg=cfg)
+            mm = ops.gemm_res_rowstats(ws.hid, w["proj_w"], w["proj_b"], ws.x, ws.x, ws.part, cfg=cfg)
+        return
     for w in blocks:
         ops.layernorm(ws.x, w["ln1_w"], w["ln1_b"], ws.h, B * L, D)
         ops.gemm(ws.h, w["in_w"], w["in_b"], out=ws.qkv, epi=ops.EPI_BF16, cfg=cfg)

@@ -76,6 +76,78 @@ def gemm(a, w, bias=None, out=None, res=None, epi=EPI_BF16, act=ACT_NONE, alpha=
     return out
 
 
+# ---- LayerNorm folded into the GEMMs either side of it (frozen pre-LN blocks, bf16 residual stream; include/vitlens_hip.h) ----
+def fold_ln_linear(w, b, gamma, beta):
+    """Operands of  LN(x; gamma, beta) @ w.T + b  for vl_gemm_lnfold_bf16: (Wg bf16 [N,K] = bf16(w * gamma), bias_f f32 [N] =
+    b + w @ beta, c f32 [N] = row sums of the ROUNDED Wg - the mean term must cancel against exactly what the MFMAs add up)."""
+    w = w.detach().float()
+    wg = (w * gamma.detach().float()[None, :]).to(torch.bfloat16).contiguous()
+    c = wg.float().sum(1).contiguous()
+    d = (b.detach().float() + w @ beta.detach().float()).contiguous()
+    return wg, d, c
+
+
+def _fold_rows(x, out, N, K):
+    """Rows of this problem that take the folded path (0: the shape does not fit the persistent kernel)."""
+    M = x.shape[0]
+    if x.dtype != torch.bfloat16 or out.dtype != torch.bfloat16 or K < 512 or K % 64 or N % 256 or x.stride(0) % 8 or out.stride(0) % 8:
+        return 0
+    if x.data_ptr() % 16 or out.data_ptr() % 16:
+        return 0
+    return int(_lib.vl_gemm_main_rows(M, N))
+
+
+def _leftover_cfg(rows, N, cfg):
+    """Kernel of the leftover rows of a row-split GEMM, as vl_gemm.hip's run_gemm picks it (64x64 LDS-DMA tiles when they fill
+    most of the chip, else the split-K tail kernel); a standalone call of that size would get 128x128 tiles and a serial K."""
+    if cfg >= 0 or rows > 512:
+        return cfg
+    return 11 if ((rows + 63) // 64) * ((N + 63) // 64) >= 192 else 9
+
+
+def gemm_lnfold(x, fold, mean, rstd, out, w, b, ln_w, ln_b, h_ws, act=ACT_NONE, out2=None, eps=1e-5, cfg=-1):
+    """out = act(LN(x) @ w.T + b) with the LayerNorm folded into the GEMM's epilogue for the rows the persistent kernel takes
+    (x raw bf16 rows, mean / rstd their statistics, fold = fold_ln_linear(...)); the leftover rows - and every row of a shape
+    that kernel refuses - go through layernorm + gemm on the plain operands (h_ws: a bf16 [>= leftover rows, K] buffer)."""
+    wg, d, c = fold
+    M, K = x.shape
+    N = wg.shape[0]
+    mm = _fold_rows(x, out, N, K)
+    if mm:
+        check(_lib.vl_gemm_lnfold_bf16(_p(x), _p(wg), _p(d), _p(c), _p(mean), _p(rstd), _p(out), _p(out2), mm, N, K,
+                                       x.stride(0), wg.stride(0), out.stride(0), act, _stream()))
+    if mm < M:
+        r = M - mm
+        h = h_ws[:r]
+        layernorm(x[mm:], ln_w, ln_b, h, r, K, x_row_stride=x.stride(0), mean=mean[mm:], rstd=rstd[mm:], eps=eps)
+        gemm(h, w, b, out=out[mm:], epi=EPI_BF16, act=act, cfg=_leftover_cfg(r, N, cfg) if mm else cfg,
+             out2=None if out2 is None else out2[mm:])
+    return out
+
+
+def gemm_res_rowstats(a, w, b, out, res, part, cfg=-1):
+    """out = res + a @ w.T + b (bf16 residual stream, in place allowed); for the rows the persistent kernel takes it also leaves
+    (sum, sum of squares) per row and 64-column slice in part f32 [rows, N/64, 2].  Returns that row count (0: none)."""
+    M, K = a.shape
+    N = w.shape[0]
+    mm = _fold_rows(a, out, N, K) if (res.dtype == torch.bfloat16 and res.stride(0) == out.stride(0) and res.data_ptr() % 16 == 0
+                                      and part.numel() >= M * (N // 64) * 2) else 0
+    if mm:
+        check(_lib.vl_gemm_res_rowstats_bf16(_p(a), _p(w), _p(b), _p(out), _p(res), _p(part), mm, N, K, a.stride(0), w.stride(0),
+                                             out.stride(0), _stream()))
+    if mm < M:
+        gemm(a[mm:], w, b, out=out[mm:], res=res[mm:], epi=EPI_RES_BF16, cfg=_leftover_cfg(M - mm, N, cfg) if mm else cfg)
+    return mm
+
+
+def ln_row_stats(part, x, m_main, mean, rstd, eps=1e-5):
+    """mean / rstd of the rows of x (bf16 [rows, D]): rows < m_main from the partial sums `part` of gemm_res_rowstats, the
+    others from the rows themselves."""
+    rows, D = x.shape
+    check(_lib.vl_ln_row_stats(_p(part) if m_main else None, D // 64, _p(x), x.stride(0), D, m_main, rows, float(eps), _p(mean),
+                               _p(rstd), _stream()))
+
+
 def logits_gemm(xb, yb, scale):
     """scale * xb @ yb^T as f32 [R, C] for ANY number of columns (a partial last batch, a batch of 6 ...): the GEMM wants
     N % 4 == 0, so the column operand is zero-padded to a multiple of 4 rows and a [R, C] view of the padded result is

@@ -14,7 +14,7 @@ from typing import Dict, Iterable, Optional
 import torch
 
 from . import ops
-from .engine import VitEngine
+from .engine import LN_FOLD, VitEngine
 
 BF = torch.bfloat16
 
@@ -63,6 +63,9 @@ class _Saved:
         else:
             self.h1 = {l: bf(T, D) for l in keep_blocks}; self.h2 = {l: bf(T, D) for l in keep_blocks}
             self.hidk = {l: bf(T, hidden) for l in keep_blocks}
+        # LayerNorm folding (frozen blocks, bf16 stream): partial row sums left by the GEMM that wrote `part_of`
+        self.part = f32(T * (D // 64) * 2) if (D % 64 == 0 and res_dtype == BF) else None
+        self.part_of, self.part_rows = None, 0
         self.xpre = f32(T, D); self.pre_stats = [f32(T), f32(T)]
         self.post_stats = [f32(B), f32(B)]
         self.pooled = bf(B, D)
@@ -157,16 +160,39 @@ class TowerTrainer:
         w = e.blocks[l]
         m1, r1, m2, r2 = S.stats[l]
         h1, h2, hid = S.h1.get(l, S.h), S.h2.get(l, S.h), S.hidk.get(l, S.hid)
-        ops.layernorm(S.X[2 * l], w["ln1_w"], w["ln1_b"], h1, B * L, D, mean=m1, rstd=r1)
-        ops.gemm(h1, w["in_w"], w["in_b"], out=S.qkv[l], epi=ops.EPI_BF16, cfg=cfg)
-        ops.attn_fwd(S.q[l], S.k[l], S.v[l], S.a[l], lse=S.lse[l], qscale=dh ** -0.5 * ops.LOG2E)
-        ops.gemm(S.a[l], w["out_w"], w["out_b"], out=S.X[2 * l + 1], res=S.X[2 * l], epi=res_epi, cfg=cfg)
-        ops.layernorm(S.X[2 * l + 1], w["ln2_w"], w["ln2_b"], h2, B * L, D, mean=m2, rstd=r2)
-        # S.u[l] = gelu'(fc output): all the backward needs of the pre-activation, evaluated next to gelu() from the same
-        # exp / rational pieces (+3 VALU per element here) - the dX GEMM's epilogue is then one multiplication
-        ops.gemm(h2, w["fc_w"], w["fc_b"], out=hid, epi=ops.EPI_BF16, act=ops.ACT_GELU_DSAVE, cfg=cfg, out2=S.u[l])
+        # LayerNorm folding (engine.run_blocks; round 4): a FROZEN block never materialises ln_1 / ln_2 - its backward needs
+        # only (mean, rstd), which ln_row_stats leaves in S.stats; a trainable block keeps its LayerNorm outputs (the operands
+        # of its weight gradients).  Either kind leaves the partial row sums of its output when the next block is folded.
+        fold_ok = LN_FOLD and S.part is not None and "in_f" in w
+        folded = fold_ok and l not in self.train_blocks
+        next_folded = fold_ok and l + 1 < self.layers and (l + 1) not in self.train_blocks
+        if folded:
+            x0, x1 = S.X[2 * l], S.X[2 * l + 1]
+            mm0 = S.part_rows if S.part_of is x0 else 0      # (a recompute in front of the backward finds none: from the rows)
+            S.part_of = None
+            ops.ln_row_stats(S.part, x0, mm0, m1, r1)
+            ops.gemm_lnfold(x0, w["in_f"], m1, r1, S.qkv[l], w["in_w"], w["in_b"], w["ln1_w"], w["ln1_b"], S.h, cfg=cfg)
+            ops.attn_fwd(S.q[l], S.k[l], S.v[l], S.a[l], lse=S.lse[l], qscale=dh ** -0.5 * ops.LOG2E)
+            mm = ops.gemm_res_rowstats(S.a[l], w["out_w"], w["out_b"], x1, x0, S.part, cfg=cfg)
+            ops.ln_row_stats(S.part, x1, mm, m2, r2)
+            ops.gemm_lnfold(x1, w["fc_f"], m2, r2, hid, w["fc_w"], w["fc_b"], w["ln2_w"], w["ln2_b"], S.h,
+                            act=ops.ACT_GELU_DSAVE, out2=S.u[l], cfg=cfg)
+        else:
+            ops.layernorm(S.X[2 * l], w["ln1_w"], w["ln1_b"], h1, B * L, D, mean=m1, rstd=r1)
+            ops.gemm(h1, w["in_w"], w["in_b"], out=S.qkv[l], epi=ops.EPI_BF16, cfg=cfg)
+            ops.attn_fwd(S.q[l], S.k[l], S.v[l], S.a[l], lse=S.lse[l], qscale=dh ** -0.5 * ops.LOG2E)
+            ops.gemm(S.a[l], w["out_w"], w["out_b"], out=S.X[2 * l + 1], res=S.X[2 * l], epi=res_epi, cfg=cfg)
+            ops.layernorm(S.X[2 * l + 1], w["ln2_w"], w["ln2_b"], h2, B * L, D, mean=m2, rstd=r2)
+            # S.u[l] = gelu'(fc output): all the backward needs of the pre-activation, evaluated next to gelu() from the same
+            # exp / rational pieces (+3 VALU per element here) - the dX GEMM's epilogue is then one multiplication
+            ops.gemm(h2, w["fc_w"], w["fc_b"], out=hid, epi=ops.EPI_BF16, act=ops.ACT_GELU_DSAVE, cfg=cfg, out2=S.u[l])
         if write_out:
-            ops.gemm(hid, w["proj_w"], w["proj_b"], out=S.X[2 * l + 2], res=S.X[2 * l + 1], epi=res_epi, cfg=cfg)
+            S.part_of, S.part_rows = None, 0
+            if next_folded:
+                S.part_rows = ops.gemm_res_rowstats(hid, w["proj_w"], w["proj_b"], S.X[2 * l + 2], S.X[2 * l + 1], S.part, cfg=cfg)
+                S.part_of = S.X[2 * l + 2]
+            else:
+                ops.gemm(hid, w["proj_w"], w["proj_b"], out=S.X[2 * l + 2], res=S.X[2 * l + 1], epi=res_epi, cfg=cfg)
 
     # ------------------------------------------------------------------------------------------ backward
     def _dw(self, name, dy, x, rows, bias_name=None):
