@@ -101,8 +101,13 @@ def _worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     d = _data()
-    lo, hi = (0, 20) if rank == 0 else (20, 57)                                   # ragged split: the gathers must handle unequal shares
-    ret[rank] = _norm(_mine({k: (v[lo:hi] if v.shape[0] == 57 else v) for k, v in d.items()}, cuts=(0, 7, hi - lo)))
+    if world == 2:
+        lo, hi = (0, 20) if rank == 0 else (20, 57)                               # ragged split: the gathers must handle unequal shares
+        cuts = (0, 7, hi - lo)
+    else:                                                                         # world 3: the last rank has NO batch at all
+        lo, hi = ((0, 20), (20, 57), (57, 57))[rank]
+        cuts = (0, 7, hi - lo) if hi > lo else (0,)
+    ret[rank] = _norm(_mine({k: (v[lo:hi] if v.shape[0] == 57 else v) for k, v in d.items()}, cuts=cuts))
     dist.destroy_process_group()
 
 
@@ -113,3 +118,25 @@ def test_metrics_merge_across_ranks_on_gloo():
     one = _norm(_mine(_data()))
     for r in range(world):
         assert ret[r] == one, r
+
+
+def test_metrics_merge_with_a_rank_that_saw_no_batch():
+    """Fewer batches than ranks (the tail of an evaluation set): the empty rank learns dtype / trailing shape of every gathered
+    tensor from its peers (BaseMetric._collected) instead of offering a 1-d int64 placeholder to a 2-d float gather."""
+    world = 3
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, 30170 + os.getpid() % 100, ret), nprocs=world, join=True)
+    one = _norm(_mine(_data()))
+    for r in range(world):
+        assert ret[r] == one, r
+
+
+def test_multi_hot_accuracy_counts_the_target_value():
+    """Soft / weighted multi-hot targets: the reference adds up `targets.gather(1, pred)` (metrics/accuracy.py:22-23), not a 0/1 hit."""
+    from open_clip.metrics import Accuracy
+    logits = torch.tensor([[0.1, 0.9, 0.0], [0.8, 0.1, 0.1], [0.2, 0.3, 0.5]])
+    targets = torch.tensor([[0.0, 0.5, 1.0], [2.0, 0.0, 0.0], [1.0, 0.0, 0.0]])
+    a = Accuracy(); a.initialize()
+    a.compute(torch.arange(3), logits, targets)
+    r = a.merge_results()
+    assert r["score_sum"] == 2.5 and r["score_cnt"] == 3 and abs(r["accuracy"] - 2.5 / 3) < 1e-12

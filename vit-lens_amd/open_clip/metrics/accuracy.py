@@ -13,17 +13,20 @@ class Accuracy(BaseMetric):
 
     def compute(self, ids, logits, targets):
         pred = logits.argmax(dim=1)
-        if targets.dim() == 2:                     # multi-hot targets: right if the predicted label is one of the set ones
-            hit = targets[torch.arange(pred.numel(), device=pred.device), pred] != 0
+        if targets.dim() == 2:
+            # multi-hot (or soft) targets: the VALUE at the predicted label counts, as the reference's
+            # `targets.gather(1, predict_labels.unsqueeze(1)).sum()` (metrics/accuracy.py:22-23)
+            hit = targets.gather(1, pred.unsqueeze(1)).squeeze(1).to(torch.float64)
         else:
-            hit = pred == targets
-        self._push(ids=ids, pred=pred, hit=hit.to(torch.int64))
+            hit = (pred == targets).to(torch.float64)
+        self._push(ids=ids, pred=pred, hit=hit)
 
     def merge_results(self, output_predict=False):
         local_hits = self.__dict__.get("_batches", {}).get("hit", [])
-        dev = self.device or (local_hits[0].device if local_hits else torch.device("cpu"))
-        dev = torch.device(dev)
-        n_hit = self._global_sum(sum(int(h.sum()) for h in local_hits), dev)
+        # the counters travel on the communicator's device (a rank without batches has no tensor to take one from)
+        dev = torch.device(self.device) if self.device is not None else (self.comm_device() if self.multi_rank() else
+                                                                          (local_hits[0].device if local_hits else torch.device("cpu")))
+        n_hit = self._global_sum(sum(float(h.sum()) for h in local_hits), dev)
         n_all = self._global_sum(sum(h.numel() for h in local_hits), dev)
         table = self._prediction_table(self._collected("ids"), self._collected("pred"), output_predict)
         return {"accuracy": n_hit / n_all, "score_sum": n_hit, "score_cnt": int(n_all), "predict_results": table}

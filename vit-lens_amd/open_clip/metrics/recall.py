@@ -2,10 +2,8 @@
 video) features are collected per batch and gathered across ranks; the similarity matrix against the text features is
 one GEMM on the HIP kernel (fp32-accurate bf16 hi/lo split, `zero_shot_logits`), the ranking is top-10 + id matching."""
 import torch
-import torch.distributed as dist
 
 from .base_metric import BaseMetric
-from ..utils import all_gather
 
 
 class Recall(BaseMetric):
@@ -14,19 +12,15 @@ class Recall(BaseMetric):
 
     def initialize(self, text_ids, text_logits):
         self.text_ids, self.text_logits = text_ids, text_logits
-        self.image_ids_list, self.image_logits_list = [], []
+        self._reset()
 
     def compute(self, image_ids, image_logits):
-        self.image_ids_list.append(image_ids)
-        self.image_logits_list.append(image_logits)
+        self._push(image_ids=image_ids, image_logits=image_logits)
 
     def gathered(self):
-        """All ranks' (ids, features), rank-major."""
-        image_ids = torch.cat(self.image_ids_list, dim=0)
-        image_logits = torch.cat(self.image_logits_list, dim=0)
-        if dist.is_available() and dist.is_initialized():
-            image_ids, image_logits = all_gather(image_ids), all_gather(image_logits)
-        return image_ids, image_logits
+        """All ranks' (ids, features), rank-major (a rank without batches contributes zero rows: BaseMetric._collected)."""
+        like = self.text_logits.new_zeros((0,) + tuple(self.text_logits.shape[1:]))
+        return self._collected("image_ids", like=self.text_ids[:0]), self._collected("image_logits", like=like)
 
     def merge_results(self, output_predict=False):
         from ..zero_shot_classifier import zero_shot_logits

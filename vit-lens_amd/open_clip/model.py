@@ -367,6 +367,10 @@ class VisionTransformer(nn.Module):
             raise RuntimeError("the ViT-Lens towers run on the MI355X kernels only: move the model to a GPU")
         key = (str(dev), self.training, self.res_dtype)
         vers = {n: p._version for n, p in self.named_parameters()}
+        if not self.training:
+            # eval engines also follow the BUFFERS (BatchNorm running statistics edited in place); in train mode the trainer owns
+            # and updates those every forward, which must not look like a parameter change
+            vers.update({"buffer:" + n: b._version for n, b in self.named_buffers()})
         if self._engine is None or key != self._engine_key:
             sd = {("t." + k): v for k, v in self.state_dict().items()}
             tower, lens = self._cfgs()
@@ -376,7 +380,7 @@ class VisionTransformer(nn.Module):
                 self._engine = E.LensEngine(sd, "t.", tower, lens, dev, res_dtype=self.res_dtype)
             self._engine_key, self._engine_vers = key, vers
         elif vers != self._engine_vers:
-            changed = [n for n, v in vers.items() if self._engine_vers.get(n) != v]
+            changed = [n[7:] if n.startswith("buffer:") else n for n, v in vers.items() if self._engine_vers.get(n) != v]
             sd = {("t." + k): v for k, v in self.state_dict().items()}
             if isinstance(self._engine, E.VitEngine):
                 self._engine.update_params(sd, changed)

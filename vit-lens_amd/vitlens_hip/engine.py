@@ -476,6 +476,7 @@ class LensEngine:
         self.tower, self.lens, self.device, self.gemm_cfg = tower, lens, torch.device(device), gemm_cfg
         self.vit = VitEngine(sd, prefix, tower, device, res_dtype=res_dtype, gemm_cfg=gemm_cfg)
         a = prefix + "visual_adapter."
+        self.prefix_adapter = a
         self.adapter_pos = None
         if lens.modality in ("depth", "audio"):
             self.conv_w = conv_weight_as_gemm(sd[a + "conv1.weight"], device)
@@ -514,8 +515,9 @@ class LensEngine:
                 if L.pc_tokenizer == "pnsa":
                     self.points.load_params(sd)
                 else:
-                    from .points import PointTokenizerEngine
-                    self.points = PointTokenizerEngine(sd, a, L, self.device, gemm_cfg=self.gemm_cfg)
+                    # the inference tokenizer (BatchNorm folded into the convolutions, a host round trip) is rebuilt at its next
+                    # USE: while training every optimizer step lands here and the trainer runs its own tokenizer copy
+                    self._points_pending = {k: v for k, v in sd.items() if k.startswith(a)}
         if self.perceiver is not None and any(n.startswith("perceiver.") for n in names):
             self.perceiver.update_params(sd, prefix + "perceiver.")
 
@@ -544,6 +546,11 @@ class LensEngine:
     def encode(self, x: torch.Tensor, normalize: bool = False, **kw) -> torch.Tensor:
         B = x.shape[0]
         if self.lens.modality == "pc":
+            pend = getattr(self, "_points_pending", None)
+            if pend is not None:
+                from .points import PointTokenizerEngine
+                self.points = PointTokenizerEngine(pend, self.prefix_adapter, self.lens, self.device, gemm_cfg=self.gemm_cfg)
+                self._points_pending = None
             tok = self.points.forward(x, **kw)                 # already x + pos, [B*G, C] bf16
             lat = self.perceiver.forward(tok, B)
             f = self.vit.trunk(lat, B, use_orig_pos=self.lens.use_orig_pos)
