@@ -31,6 +31,14 @@ def main():
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         resb = torch.randn(M, N, device="cuda").bfloat16()
         u2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        if label == "res_stats":
+            part = torch.empty(M * (N // 64) * 2, device="cuda")
+        if label.startswith("ln_"):
+            gam, bet = 1 + 0.2 * torch.randn(K, device="cuda"), 0.1 * torch.randn(K, device="cuda")
+            fold = ops.fold_ln_linear(w.float(), bias, gam, bet)
+            mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+            ops.ln_row_stats(None, a, 0, mean, rstd)
+            hws = torch.empty(1, K, device="cuda", dtype=torch.bfloat16)
 
         def fn(cfg):
             if label == "bf16":
@@ -45,6 +53,12 @@ def main():
                 return lambda: ops.gemm(a, w, None, out=out, res=resb, epi=ops.EPI_DGELU, act=ops.ACT_GELU_DSAVE, cfg=cfg)
             if label == "res_bf16":
                 return lambda: ops.gemm(a, w, bias, out=resb, res=resb, epi=ops.EPI_RES_BF16, cfg=cfg)
+            if label == "res_stats":       # round 4: + the partial row sums for the LayerNorm that follows (ACT 20)
+                return lambda: ops.gemm_res_rowstats(a, w, bias, resb, resb, part)
+            if label in ("ln_bf16", "ln_gelu", "ln_dsave"):      # round 4: the LayerNorm folded into the epilogue (ACT 10 / 11 / 14)
+                act = {"ln_bf16": ops.ACT_NONE, "ln_gelu": ops.ACT_GELU, "ln_dsave": ops.ACT_GELU_DSAVE}[label]
+                return lambda: ops.gemm_lnfold(a, fold, mean, rstd, out, w, bias, gam, bet, hws, act=act,
+                                               out2=u2 if act == ops.ACT_GELU_DSAVE else None)
             return lambda: ops.gemm(a, w, None, out=out, res=resb, epi=ops.EPI_DGELU, cfg=cfg)
         fns = {c: fn(c) for c in cfgs}
         for f in fns.values():
