@@ -23,3 +23,37 @@ def test_layernorm_fold_operands_are_the_algebra_of_ln_then_linear():
     ref = torch.nn.functional.layer_norm(x, (K,), gamma.double(), beta.double(), 1e-5) @ w.double().t() + b.double()
     assert float((folded - ref).norm() / ref.norm()) < 4e-3                  # bf16 rounding of W * gamma only
     assert float((d.double() - (b.double() + w.double() @ beta.double())).abs().max()) < 1e-5
+
+
+def test_row_split_of_the_folded_gemms_follows_the_dispatcher():
+    """vl_gemm_main_rows = the rows vl_gemm_bf16 (cfg -1) hands to the persistent 256x256 kernel (no GPU needed: 256 CUs are
+    assumed without a device): whole rounds of the 256 workgroups where they exist, every full row tile otherwise, nothing for
+    problems below 3/4 of one round or widths that are not whole tiles; ops._leftover_cfg picks the leftover rows' kernel the
+    way the dispatcher does (64x64 LDS-DMA tiles when they fill most of the chip, else the split-K tail kernel)."""
+    from vitlens_hip import _lib, ops
+    lib = _lib.load_library()
+    T = 257 * 256                                   # 256 images x 257 tokens
+    assert lib.vl_gemm_main_rows(T, 3072) == 65536 and lib.vl_gemm_main_rows(T, 1024) == 65536 and lib.vl_gemm_main_rows(T, 4096) == 65536
+    assert lib.vl_gemm_main_rows(4 * T, 1024) == 4 * 65536                      # 1028 row tiles: 1024 in whole rounds
+    assert lib.vl_gemm_main_rows(65 * 256, 1024) == 64 * 256                    # 260 tiles: one round of 64 row tiles
+    assert lib.vl_gemm_main_rows(49 * 256, 1024) == 49 * 256                    # 196 tiles: no whole round, every full row tile
+    assert lib.vl_gemm_main_rows(17 * 256, 1024) == 0                           # 68 tiles < 192: small-tile kernels
+    assert lib.vl_gemm_main_rows(T, 1664 * 3) == 0 and lib.vl_gemm_main_rows(0, 1024) == 0 and lib.vl_gemm_main_rows(T, 0) == 0
+    assert lib.vl_gemm_main_rows(65536 + 40, 1024) == 65536
+    assert ops._leftover_cfg(256, 3072, -1) == 11 and ops._leftover_cfg(256, 4096, -1) == 11      # 4 x 48 / 4 x 64 tiles of 64 x 64
+    assert ops._leftover_cfg(256, 1024, -1) == 9                                                  # 64 tiles: split-K tail kernel
+    assert ops._leftover_cfg(256, 1024, 5) == 5 and ops._leftover_cfg(4096, 1024, -1) == -1       # explicit cfg / many rows: untouched
+
+
+def test_folding_entries_refuse_bad_arguments_without_touching_the_gpu():
+    """Argument checks of the round-4 entries run before any HIP call: status 1 + a message from vl_last_error()."""
+    from vitlens_hip import _lib
+    lib = _lib.load_library()
+    assert lib.vl_ln_row_stats(None, 0, None, 0, 0, 0, 0, 1e-5, None, None, None) == 1
+    assert b"bad shape" in lib.vl_last_error()
+    assert lib.vl_ln_row_stats(None, 16, None, 1024, 1024, 256, 512, 1e-5, None, None, None) == 1
+    assert b"partial statistics missing" in lib.vl_last_error()
+    assert lib.vl_gemm_lnfold_bf16(None, None, None, None, None, None, None, None, 256, 256, 512, 512, 512, 256, 0, None) == 1
+    assert b"null operand" in lib.vl_last_error()
+    assert lib.vl_gemm_res_rowstats_bf16(None, None, None, None, None, None, 256, 256, 512, 512, 512, 256, None) == 1
+    assert b"null operand" in lib.vl_last_error()

@@ -288,6 +288,8 @@ extern "C" int vl_ln_row_stats(const float* row_part, int P, const void* x_bf16,
                                float eps, float* mean, float* rstd, hipStream_t stream) {
   if (rows <= 0 || D <= 0 || m_main < 0 || m_main > rows) return vl_set_error("vl_ln_row_stats: bad shape");
   if (m_main > 0 && (!row_part || P <= 0 || (((uintptr_t)row_part) & 7))) return vl_set_error("vl_ln_row_stats: partial statistics missing");
+  if (m_main > 0 && P * 64 != D) return vl_set_error("vl_ln_row_stats: P must be D / 64 (one partial pair per 64-column slice of the row)");
+  if (!mean || !rstd) return vl_set_error("vl_ln_row_stats: outputs missing");
   if (m_main < rows && !x_bf16) return vl_set_error("vl_ln_row_stats: rows missing");
   const int nb = ((m_main + 255) >> 8) + (rows - m_main + 3) / 4;
   hipLaunchKernelGGL(row_stats_kernel, dim3(nb), dim3(256), 0, stream, row_part, P, (const bf16_t*)x_bf16, x_row_stride, D, m_main,
