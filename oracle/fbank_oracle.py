@@ -6,12 +6,16 @@ snip_edges, remove_dc_offset, preemphasis 0.97, round_to_power_of_two, low_freq 
 spectrum, natural log floored at float32 epsilon), plus the processor's pad / truncate to target_length rows and
 transforms.Normalize(mean, std).
 
-PARITY UNPINNED: torchaudio is a third-party dependency of the reference that is absent from /root/reference and from this
-image (requirements: torchaudio matching torch >= 1.9, README pins 0.11 / 0.12), so this file restates the PUBLISHED
-algorithm (Kaldi feature-fbank / torchaudio.compliance.kaldi source) instead of being checked against the library; the
-reference holds no spectrogram fixture either.  What IS pinned here: numpy's FFT as the spectrum, and the closed-form
-properties the tests check (a pure tone peaks in the right mel bin, Parseval on the power spectrum, shift invariance of
-the framing)."""
+PARITY: torchaudio is a third-party dependency of the reference that is absent from /root/reference and from this image
+(requirements: torchaudio matching torch >= 1.9, README pins 0.11 / 0.12), so this file restates the PUBLISHED algorithm
+(Kaldi feature-fbank / torchaudio.compliance.kaldi source) and cannot be run against the library itself: by the letter of
+the contract it stays "parity unpinned" against the reference's dependency.  Since round 4 it is CROSS-PINNED against an
+independent implementation of the same call that IS in the image: Hugging Face transformers 5.15.0, whose
+ASTFeatureExtractor falls back to its own numpy `spectrogram` / kaldi-scale `mel_filter_bank` when torchaudio is missing -
+written by its authors to replace `ta_kaldi.fbank(waveform, sample_frequency=16000, window_type="hanning", num_mel_bins=128)`,
+the reference's call.  tests/test_fbank_oracle.py: agreement within 1e-4 (log domain) on noise, tones, a modulated signal
+and near-silence.  Also pinned: numpy's FFT as the spectrum, and the closed-form properties the tests check (a pure tone
+peaks in the right mel bin, Parseval on the power spectrum, shift invariance of the framing)."""
 import math
 
 import numpy as np

@@ -1,10 +1,11 @@
 """CPU: the numpy restatement of the Kaldi log-mel filterbank (oracle/fbank_oracle.py; reference call site
-open_clip/modal_audio/processors/at_processor.py:854-873).  torchaudio is not installed (parity UNPINNED - see the oracle's
-header), so what is checked here is the algorithm's own closed-form behaviour and the agreement of the product's
-host-built tables with the oracle's independent formulation."""
+open_clip/modal_audio/processors/at_processor.py:854-873).  torchaudio is not installed, so the restatement cannot meet the
+library itself; it is checked against the algorithm's own closed-form behaviour, against the product's host-built tables,
+and (round 4) against the independent numpy implementation of the same call that ships with transformers."""
 import math
 
 import numpy as np
+import pytest
 
 import fbank_oracle as F
 
@@ -51,3 +52,39 @@ def test_energy_scales_quadratically():
     a, b = F.fbank(w), F.fbank(2.0 * w)
     live = a > -10.0
     assert np.allclose((b - a)[live], math.log(4.0), atol=2e-4)
+
+
+def test_oracle_equals_an_independent_kaldi_fbank_implementation():
+    """torchaudio (the reference's dependency for this call, at_processor.py:854-873) is not in the image; Hugging Face
+    transformers (5.15.0 here) ships its own numpy implementation of the SAME computation for exactly this case:
+    ASTFeatureExtractor without torchaudio evaluates `spectrogram(..., frame_length=400, hop_length=160, fft_length=512,
+    power=2.0, center=False, preemphasis=0.97, mel_filters=kaldi-scale triangles from 20 Hz, log_mel="log",
+    mel_floor=1.192092955078125e-07, remove_dc_offset=True)` with a non-periodic Hann window - its authors' replacement for
+    `ta_kaldi.fbank(waveform, sample_frequency=16000, window_type="hanning", num_mel_bins=128)`, the reference's call
+    (htk_compat only matters with use_energy; dither 0 and frame_shift 10 are the defaults).  The restatement in
+    oracle/fbank_oracle.py was written from the Kaldi / torchaudio source without looking at it: two independent readings
+    that agree to 1e-4 in the log domain on noise, tones, a slowly modulated signal and near-silence."""
+    tr = pytest.importorskip("transformers")
+    from transformers.models.audio_spectrogram_transformer.feature_extraction_audio_spectrogram_transformer import ASTFeatureExtractor
+    from transformers.utils import is_speech_available
+    if is_speech_available():
+        pytest.skip("torchaudio present: the extractor would call it instead of its own implementation")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fe = ASTFeatureExtractor(num_mel_bins=128, max_length=1024, do_normalize=False)
+    rs = np.random.RandomState(0)
+    cases = []
+    for n in (16000, 48000, 20000 + 37):
+        t = np.arange(n) / 16000.0
+        cases += [(rs.randn(n) * 0.1).astype(np.float32),
+                  (0.3 * np.sin(2 * math.pi * 440 * t) + 0.1 * np.sin(2 * math.pi * 3000 * t)).astype(np.float32),
+                  (rs.randn(n).cumsum() * 1e-3 * np.sin(2 * math.pi * 3 * t)).astype(np.float32),
+                  (rs.randn(n) * 1e-6).astype(np.float32)]
+    worst = 0.0
+    for x in cases:
+        a = F.fbank(x)
+        b = fe._extract_fbank_features(x, max_length=a.shape[0])
+        assert a.shape == b.shape == (1 + (len(x) - 400) // 160, 128)
+        worst = max(worst, float(np.abs(a - b).max()))
+    assert worst < 2e-4, worst
