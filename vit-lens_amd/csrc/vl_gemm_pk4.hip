@@ -1,0 +1,226 @@
+// EXPERIMENTAL (round 4, built without a GPU in reach - NOT dispatched by cfg -1, NOT used by any product path): the persistent
+// bf16 NT GEMM with ONE wave per SIMD and a 128x128 wave tile.
+//
+// Why: the 8-wave kernel of vl_gemm_park.hip (2 x 4 waves of 128 x 64) reads 12 fragments per 32 MFMAs from LDS; an LDS-fed
+// loop of that shape with nothing else in it tops out at 1 529 TF/s on this power-limited part against 2 024 TF/s from
+// registers: the LDS reads are a quarter of the energy.  A 128 x 128 wave tile needs 16 fragments per 64 MFMAs
+// (8 per 32): a third fewer reads per flop.  It takes four waves per 256 x 256 tile, i.e. one wave per SIMD with 256
+// accumulator registers (AGPRs) + up to 256 others, and a software-pipelined stream because no second wave hides latency.
+//
+// What is here: the main loop (LDS-DMA two k-steps ahead and across tile boundaries, one barrier per k-step, fragments of
+// the next half k-step in flight under the 64 MFMAs of the current one) and the plainest possible epilogue (bias, bf16,
+// 8-byte stores straight from the accumulator layout).  Reachable only through vl_gemm_bf16(..., cfg = 14) for
+// VL_EPI_BF16 / VL_ACT_NONE on whole 256x256 tiles with K >= 512; tools/pk4_probe.py checks it against the shipped kernel and
+// times both.  First thing to do with it on a GPU: that probe; then the phase counters (k-loop cycles per step against the 8-wave
+// kernel's 2 460), then the LDS-transposed 16-byte store epilogue of vl_gemm_park.hip.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+
+#include "vl_gemm_common.h"
+
+namespace {
+
+constexpr int P4_STAGE = 65536, P4_ABYTES = 32768;
+constexpr int P4_LDS = 2 * P4_STAGE;                      // 128 KB: two operand stages (A 256 x 64, W 256 x 64, bf16)
+constexpr int P4_GN = 8;                                  // N-tiles per group of the tile order (as the 8-wave kernel)
+
+typedef __attribute__((address_space(3))) void* lds_ptr4_t;
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) gemm_nt_pk4_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tiles_n = p.N >> 8, tiles_m = p.M >> 8;
+  const int nk = p.K >> 6;
+  const int ntiles = tiles_m * tiles_n;
+  const int G = gridDim.x;
+  const int slot = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);        // each XCD a contiguous run of the tile order
+  if (slot >= ntiles) return;
+  const int my_tiles = (ntiles - slot + G - 1) / G;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wid & 1, wave_n = wid >> 1;            // 2 x 2 waves of 128 x 128
+
+  auto tile_origin = [&](int ti, int& m0, int& n0) {
+    const int v = ti * G + slot;
+    const int GN = p.pk_gn > 0 ? p.pk_gn : P4_GN;
+    const int gsz = GN * tiles_m;
+    const int gid = v / gsz, rem = v - gid * gsz;
+    const int first_n = gid * GN;
+    const int gn = min(tiles_n - first_n, GN);
+    const int tm = rem / gn;
+    m0 = tm << 8; n0 = (first_n + (rem - tm * gn)) << 8;
+  };
+
+  // ---- LDS-DMA: unit i (0..7) of an operand = rows i*32 + wid*8 + (lane>>3), 16-byte chunk (lane&7) ^ swizzle(row) ----
+  const int drow = wid * 8 + (lane >> 3);
+  const int dsw = ((lane & 7) ^ ((drow >> 1) & 7)) * 16;   // (i*32 >> 1) is a multiple of 8: the swizzle does not depend on i
+  const unsigned voffA = (unsigned)(drow * p.lda * 2 + dsw), voffW = (unsigned)(drow * p.ldw * 2 + dsw);
+  const int a_unit = p.lda * 64, w_unit = p.ldw * 64;      // bytes between units (32 rows)
+  __amdgpu_buffer_rsrc_t rsA, rsW;
+  auto make_rsrc = [&](int m0, int n0, __amdgpu_buffer_rsrc_t& ra, __amdgpu_buffer_rsrc_t& rw) {
+    ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)m0 * p.lda), 0, 0x7ffffff0, 0x00020000);
+    rw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)n0 * p.ldw), 0, 0x7ffffff0, 0x00020000);
+  };
+
+  // ---- fragments: 16 rows x 32 k (lane: row lane&15, 8-wide k chunk lane>>4); accumulator block [ia][jb]: the lane owns output
+  // row ia*16 + (lane&15) and the four columns jb*16 + (lane>>4)*4 .. +3 (operands swapped, as the 8-wave kernel) ----
+  const int fr16 = lane & 15, fq = lane >> 4;
+  const int fsw16 = (fr16 >> 1) & 7;
+  const int fa16 = (wave_m * 128 + fr16) * 128, fw16 = P4_ABYTES + (wave_n * 128 + fr16) * 128;
+  bf16x8 af[2][8], wf[2][8];
+  f32x4 acc[8][8];
+  // one fragment (W: jb, A: ia) of k half h of a stage into set c
+  auto ldW = [&](const unsigned char* stage, int h, int c, int jb) {
+    wf[c][jb] = *(const bf16x8*)(stage + fw16 + jb * 2048 + ((h * 4 + fq) ^ fsw16) * 16);
+  };
+  auto ldA = [&](const unsigned char* stage, int h, int c, int ia) {
+    af[c][ia] = *(const bf16x8*)(stage + fa16 + ia * 2048 + ((h * 4 + fq) ^ fsw16) * 16);
+  };
+  auto ldfrags = [&](const unsigned char* stage, int h, int c) {
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) ldW(stage, h, c, jb);
+#pragma unroll
+    for (int ia = 0; ia < 8; ++ia) ldA(stage, h, c, ia);
+  };
+  // The 8 MFMAs of accumulator row ia from fragment set c.  Inline assembly with the accumulator TIED to an AGPR operand:
+  // through the builtin hipcc 7.2 allocated C and D of many of these MFMAs to different registers and, with all 256 AGPRs
+  // holding the tile, rotated them through VGPRs - 328 v_accvgpr moves per k-step (ISA inspection).  Every accumulator block
+  // is written once per 64 MFMAs: no MFMA -> MFMA hazard to pad by hand; the fragments are ordinary operands (the compiler
+  // places the lgkmcnt waits).  ZC: the first k half of a tile accumulates onto the inline constant 0 - no zeroing pass.
+  auto mma_row = [&](int c, int ia) {
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[ia][jb]) : "v"(wf[c][jb]), "v"(af[c][ia]));
+  };
+  auto mma_row_zc = [&](int c, int ia) {
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[ia][jb]) : "v"(wf[c][jb]), "v"(af[c][ia]));
+  };
+
+  int cur_m0, cur_n0;
+  tile_origin(0, cur_m0, cur_n0);
+  make_rsrc(cur_m0, cur_n0, rsA, rsW);
+  __amdgpu_buffer_rsrc_t rsA_n = rsA, rsW_n = rsW;
+  int dti = 0, dkt = 0;                                     // DMA position: runs two k-steps ahead of the MFMAs, across tile boundaries
+  // unit i (0..7) of both operands of the k-step at the DMA position; 8 pieces = one k-step, then dma_advance()
+  auto dma_piece = [&](unsigned char* stage, int i) {
+    const int kbyte = dkt << 7;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr4_t)(stage + (i * 4 + wid) * 1024), 16, voffA, kbyte + i * a_unit, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr4_t)(stage + P4_ABYTES + (i * 4 + wid) * 1024), 16, voffW, kbyte + i * w_unit, 0, 0);
+  };
+  auto dma_advance = [&]() {
+    ++dkt;
+    if (dkt == nk) { dkt = 0; ++dti; rsA = rsA_n; rsW = rsW_n; }
+  };
+  auto dma_step = [&](unsigned char* stage) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_piece(stage, i);
+    dma_advance();
+  };
+  // (hipcc does not model the LDS write of the DMA builtin: wait by hand; raw barrier, no fence - vl_gemm_park.hip)
+  auto dma_wait_and_barrier = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  dma_step(smem);
+  dma_step(smem + P4_STAGE);                                // nk >= 8: still inside tile 0
+  dma_wait_and_barrier();
+  ldfrags(smem, 0, 0);
+
+  // One k-step = two phases of 64 MFMAs on ONE wave per SIMD: nothing else hides latency, so every phase carries its share of the
+  // other work BETWEEN its MFMA rows (sched_barrier keeps the hand order):
+  //   phase A (k half 0, set 0): the 16 fragment reads of half 1 (set 1), 8 in front of each 32 MFMAs - never more than 15 LDS
+  //           operations outstanding, or the wait in front of the first MFMA could not be encoded without stalling (lgkmcnt is
+  //           4 bits: with 16 reads up front hipcc emitted lgkmcnt(14), i.e. a stall on two of the NEW reads);
+  //   barrier (every wave holds its last fragments of `cur`; the DMA of the next k-step, issued one k-step ago, has landed);
+  //   phase B (k half 1, set 1): per MFMA row one DMA piece of the k-step after next (into `cur`) and two fragment reads of
+  //           the next k-step's half 0 (set 0, from `oth`).
+  int par = 0;
+  auto kstep = [&](auto FIRST, auto LAST) {
+    constexpr bool last = decltype(LAST)::value, first = decltype(FIRST)::value;
+    unsigned char* cur = smem + par * P4_STAGE;
+    unsigned char* oth = smem + (par ^ 1) * P4_STAGE;
+    auto& row_acc = mma_row; auto& row_new = mma_row_zc;    // (named outside the discarded branches of this generic lambda)
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) ldW(cur, 1, 1, jb);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ia = 0; ia < 4; ++ia) { if constexpr (first) row_new(0, ia); else row_acc(0, ia); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ia = 0; ia < 8; ++ia) ldA(cur, 1, 1, ia);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ia = 4; ia < 8; ++ia) { if constexpr (first) row_new(0, ia); else row_acc(0, ia); }
+    __builtin_amdgcn_sched_barrier(0);
+    dma_wait_and_barrier();
+    const bool more = dti < my_tiles;                       // (wave-uniform) operands left to fetch
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      if (more) dma_piece(cur, g);
+      if constexpr (!last) { ldW(oth, 0, 0, g); ldA(oth, 0, 0, g); }     // (at a tile boundary the fragments would sit in registers through the epilogue)
+      __builtin_amdgcn_sched_barrier(0);
+      row_acc(1, g);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (more) dma_advance();
+    par ^= 1;
+  };
+
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    if (ti + 1 < my_tiles) {
+      int nm0, nn0;
+      tile_origin(ti + 1, nm0, nn0);
+      make_rsrc(nm0, nn0, rsA_n, rsW_n);
+    }
+    kstep(std::true_type{}, std::false_type{});
+    for (int kt = 1; kt < nk - 1; ++kt) kstep(std::false_type{}, std::false_type{});
+    kstep(std::false_type{}, std::true_type{});
+    {
+      // ---------------- tile finished: bias, bf16, 8-byte stores from the accumulator layout (first version) ----------------
+      const GemmP pe = reload_params();
+      mfma_results_settled();
+      int el = lane;
+      asm volatile("" : "+v"(el));                          // (the epilogue's lane constants must not be hoisted above the k-loop)
+      const int er = el & 15, eq = el >> 4;
+      const int mrow0 = cur_m0 + wave_m * 128, ncol0 = cur_n0 + wave_n * 128;
+      const bool has_bias = pe.bias != nullptr;
+      const float* const bsrc = has_bias ? pe.bias : (const float*)pe.W;
+      unsigned char* const obase = (unsigned char*)pe.out + ((size_t)(mrow0 + er) * pe.ldo + ncol0 + eq * 4) * 2;
+#pragma unroll
+      for (int jb = 0; jb < 8; ++jb) {
+        f32x4 bv = *(const f32x4*)(bsrc + ncol0 + jb * 16 + eq * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = has_bias ? bv[e] : 0.f;
+#pragma unroll
+        for (int ia = 0; ia < 8; ++ia) {
+          const f32x4 v = scale_bias(acc[ia][jb], pe.alpha, bv);
+          u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+          __builtin_nontemporal_store(o, (u32x2*)(obase + ((size_t)(ia * 16) * pe.ldo + jb * 16) * 2));
+        }
+      }
+      if (ti + 1 < my_tiles) { tile_origin(ti + 1, cur_m0, cur_n0); ldfrags(smem + par * P4_STAGE, 0, 0); }
+    }
+  }
+}
+
+}  // namespace
+
+// Internal entries used by vl_gemm.hip's dispatcher for cfg = 14 (not part of the public C ABI).
+bool vl_gemm_pk4_supported(int epi, const void* params) {
+  const GemmP& p = *(const GemmP*)params;
+  if (epi != EPI_BF16 || p.act != 0 || p.out2 || p.res || p.ksplit_len || p.res_div != 1) return false;
+  if ((p.M & 255) || (p.N & 255) || (p.K & 63) || p.K < 512 || p.M <= 0 || p.N <= 0 || (p.ldo & 3)) return false;
+  return !((((uintptr_t)p.A | (uintptr_t)p.W) & 15) || (((uintptr_t)p.out) & 7) || (p.bias && (((uintptr_t)p.bias) & 15)));
+}
+
+int vl_gemm_pk4_launch(const void* params, int ncu, hipStream_t s) {
+  const GemmP& p = *(const GemmP*)params;
+  static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_nt_pk4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P4_LDS);
+  if (attr != hipSuccess) return (int)attr;
+  const int tiles = (p.M >> 8) * (p.N >> 8);
+  int G = ncu & ~7;
+  if (tiles < G) G = (tiles + 7) & ~7;
+  hipLaunchKernelGGL(gemm_nt_pk4_kernel, dim3(G), dim3(256), P4_LDS, s, p);
+  return (int)hipGetLastError();
+}
