@@ -8,11 +8,11 @@
 // accumulator registers (AGPRs) + up to 256 others, and a software-pipelined stream because no second wave hides latency.
 //
 // What is here: the main loop (LDS-DMA two k-steps ahead and across tile boundaries, one barrier per k-step, fragments of
-// the next half k-step in flight under the 64 MFMAs of the current one) and the plainest possible epilogue (bias, bf16,
-// 8-byte stores straight from the accumulator layout).  Reachable only through vl_gemm_bf16(..., cfg = 14) for
+// the next half k-step in flight under the 64 MFMAs of the current one) and the plain bf16 epilogue of the 8-wave kernel
+// (bias, wave-private LDS transpose, 16-byte non-temporal stores), run once per 64-column half of the wave's sub-tile.  Reachable only through vl_gemm_bf16(..., cfg = 14) for
 // VL_EPI_BF16 / VL_ACT_NONE on whole 256x256 tiles with K >= 512; tools/pk4_probe.py checks it against the shipped kernel and
 // times both.  First thing to do with it on a GPU: that probe; then the phase counters (k-loop cycles per step against the 8-wave
-// kernel's 2 460), then the LDS-transposed 16-byte store epilogue of vl_gemm_park.hip.
+// kernel's 2 460), then the other epilogues.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
@@ -21,7 +21,7 @@
 namespace {
 
 constexpr int P4_STAGE = 65536, P4_ABYTES = 32768;
-constexpr int P4_LDS = 2 * P4_STAGE;                      // 128 KB: two operand stages (A 256 x 64, W 256 x 64, bf16)
+constexpr int P4_LDS = 2 * P4_STAGE + 4 * 4096;           // 144 KB: two operand stages (A 256 x 64, W 256 x 64, bf16) + four 4 KB transpose slabs
 constexpr int P4_GN = 8;                                  // N-tiles per group of the tile order (as the 8-wave kernel)
 
 typedef __attribute__((address_space(3))) void* lds_ptr4_t;
@@ -177,26 +177,47 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     for (int kt = 1; kt < nk - 1; ++kt) kstep(std::false_type{}, std::false_type{});
     kstep(std::false_type{}, std::true_type{});
     {
-      // ---------------- tile finished: bias, bf16, 8-byte stores from the accumulator layout (first version) ----------------
+      // ---------------- tile finished: bias, bf16, wave-private LDS transpose, 16-byte non-temporal stores ----------------
+      // (the plain-bf16 epilogue of vl_gemm_park.hip, run once per 64-column half of the wave's 128 x 128 sub-tile)
       const GemmP pe = reload_params();
       mfma_results_settled();
       int el = lane;
       asm volatile("" : "+v"(el));                          // (the epilogue's lane constants must not be hoisted above the k-loop)
-      const int er = el & 15, eq = el >> 4;
+      const int er = el & 15, eq = el >> 4;                 // accumulator layout: row er of a 16-row block, columns eq*4 .. +3 of a 16-column block
+      const int prow = el >> 3, pchunk = el & 7;            // store layout: row prow of an 8-row pass, 16-byte chunk pchunk of the 128-byte row
       const int mrow0 = cur_m0 + wave_m * 128, ncol0 = cur_n0 + wave_n * 128;
       const bool has_bias = pe.bias != nullptr;
-      const float* const bsrc = has_bias ? pe.bias : (const float*)pe.W;
-      unsigned char* const obase = (unsigned char*)pe.out + ((size_t)(mrow0 + er) * pe.ldo + ncol0 + eq * 4) * 2;
+      const float* const bsrc = has_bias ? pe.bias : (const float*)pe.W;     // branch-free optional bias: read something valid, select zero
+      unsigned char* const slab = smem + 2 * P4_STAGE + wid * 4096;          // 32 rows x 64 columns bf16, 16-byte chunks XOR-swizzled by row & 7
+      const size_t ldo2 = (size_t)pe.ldo * 2;
 #pragma unroll
-      for (int jb = 0; jb < 8; ++jb) {
-        f32x4 bv = *(const f32x4*)(bsrc + ncol0 + jb * 16 + eq * 4);
+      for (int ch = 0; ch < 2; ++ch) {
+        f32x4 bvq[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = has_bias ? bv[e] : 0.f;
+        for (int q = 0; q < 4; ++q) {
+          bvq[q] = *(const f32x4*)(bsrc + ncol0 + ch * 64 + q * 16 + eq * 4);
 #pragma unroll
-        for (int ia = 0; ia < 8; ++ia) {
-          const f32x4 v = scale_bias(acc[ia][jb], pe.alpha, bv);
-          u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-          __builtin_nontemporal_store(o, (u32x2*)(obase + ((size_t)(ia * 16) * pe.ldo + jb * 16) * 2));
+          for (int e = 0; e < 4; ++e) bvq[q][e] = has_bias ? bvq[q][e] : 0.f;
+        }
+        unsigned char* const obase = (unsigned char*)pe.out + ((size_t)(mrow0 + prow) * pe.ldo + ncol0 + ch * 64 + pchunk * 8) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                       // 32-row blocks
+#pragma unroll
+          for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x4 v = scale_bias(acc[i * 2 + jh][ch * 4 + q], pe.alpha, bvq[q]);
+              u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+              const int row = jh * 16 + er;
+              *(u32x2*)(slab + row * 128 + (((q * 2 + (eq >> 1)) ^ (row & 7)) << 4) + (eq & 1) * 8) = o;
+            }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) {
+            const int r = pass * 8 + prow;
+            const u32x4 w = *(const u32x4*)(slab + r * 128 + ((pchunk ^ (r & 7)) << 4));
+            __builtin_nontemporal_store(w, (u32x4*)(obase + (size_t)(i * 32 + pass * 8) * ldo2));
+          }
         }
       }
       if (ti + 1 < my_tiles) { tile_origin(ti + 1, cur_m0, cur_n0); ldfrags(smem + par * P4_STAGE, 0, 0); }
@@ -211,7 +232,8 @@ bool vl_gemm_pk4_supported(int epi, const void* params) {
   const GemmP& p = *(const GemmP*)params;
   if (epi != EPI_BF16 || p.act != 0 || p.out2 || p.res || p.ksplit_len || p.res_div != 1) return false;
   if ((p.M & 255) || (p.N & 255) || (p.K & 63) || p.K < 512 || p.M <= 0 || p.N <= 0 || (p.ldo & 3)) return false;
-  return !((((uintptr_t)p.A | (uintptr_t)p.W) & 15) || (((uintptr_t)p.out) & 7) || (p.bias && (((uintptr_t)p.bias) & 15)));
+  if (p.ldo & 7) return false;
+  return !((((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.out) & 15) || (p.bias && (((uintptr_t)p.bias) & 15)));
 }
 
 int vl_gemm_pk4_launch(const void* params, int ncu, hipStream_t s) {
