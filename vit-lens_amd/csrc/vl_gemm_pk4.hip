@@ -133,8 +133,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   //           operations outstanding, or the wait in front of the first MFMA could not be encoded without stalling (lgkmcnt is
   //           4 bits: with 16 reads up front hipcc emitted lgkmcnt(14), i.e. a stall on two of the NEW reads);
   //   barrier (every wave holds its last fragments of `cur`; the DMA of the next k-step, issued one k-step ago, has landed);
-  //   phase B (k half 1, set 1): per MFMA row one DMA piece of the k-step after next (into `cur`) and two fragment reads of
-  //           the next k-step's half 0 (set 0, from `oth`).
+  //   phase B (k half 1, set 1): per MFMA row two fragment reads of the next k-step's half 0 (set 0, from `oth`) in front of it
+  //           and one DMA piece of the k-step after next (into `cur`) behind it.
   int par = 0;
   auto kstep = [&](auto FIRST, auto LAST) {
     constexpr bool last = decltype(LAST)::value, first = decltype(FIRST)::value;
@@ -157,10 +157,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const bool more = dti < my_tiles;                       // (wave-uniform) operands left to fetch
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
-      if (more) dma_piece(cur, g);
       if constexpr (!last) { ldW(oth, 0, 0, g); ldA(oth, 0, 0, g); }     // (at a tile boundary the fragments would sit in registers through the epilogue)
       __builtin_amdgcn_sched_barrier(0);
-      row_acc(1, g);
+      row_acc(1, g);                                        // MFMAs first behind the barrier: the matrix pipe drained while the wave waited
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) dma_piece(cur, g);                          // issued (M0 write, wait state, two 1 KB pieces) while the row executes
       __builtin_amdgcn_sched_barrier(0);
     }
     if (more) dma_advance();
