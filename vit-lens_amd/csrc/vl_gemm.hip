@@ -733,7 +733,7 @@ bool vl_gemm_pp_supported(int epi, const void* params);
 int vl_gemm_pp_launch(int epi, const void* params, int ncu, hipStream_t s);
 // vl_gemm_pk4.hip: EXPERIMENTAL one-wave-per-SIMD kernel (128x128 wave tiles), cfg = 14 only
 bool vl_gemm_pk4_supported(int epi, const void* params);
-int vl_gemm_pk4_launch(const void* params, int ncu, hipStream_t s);
+int vl_gemm_pk4_launch(int epi, const void* params, int ncu, hipStream_t s);
 namespace {
 
 // Kernel selection / tuning inputs of the persistent kernels.  Read once from the environment so that one build can be
@@ -778,9 +778,9 @@ hipError_t dispatch(const GemmP& p0, int cfg, hipStream_t s) {
     if (!vl_gemm_pp_supported(EPI, &p)) return hipErrorInvalidValue;
     return (hipError_t)vl_gemm_pp_launch(EPI, &p, num_cus(), s);
   }
-  if (cfg == 14) {      // experimental (vl_gemm_pk4.hip): explicit request only, plain bf16 epilogue only
+  if (cfg == 14) {      // experimental (vl_gemm_pk4.hip): explicit request only
     if (!vl_gemm_pk4_supported(EPI, &p)) return hipErrorInvalidValue;
-    return (hipError_t)vl_gemm_pk4_launch(&p, num_cus(), s);
+    return (hipError_t)vl_gemm_pk4_launch(EPI, &p, num_cus(), s);
   }
   // cfg bit0: 0 = 256x256 tile (8 waves), 1 = 128x128 tile (4 waves); bit1: 1 = register staging
   if (cfg == 4 || cfg == 5) return launch_persist<EPI>(p, s);       // 4: historical alias

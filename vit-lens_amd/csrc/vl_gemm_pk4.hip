@@ -8,11 +8,12 @@
 // accumulator registers (AGPRs) + up to 256 others, and a software-pipelined stream because no second wave hides latency.
 //
 // What is here: the main loop (LDS-DMA two k-steps ahead and across tile boundaries, one barrier per k-step, fragments of
-// the next half k-step in flight under the 64 MFMAs of the current one) and the plain bf16 epilogue of the 8-wave kernel
-// (bias, wave-private LDS transpose, 16-byte non-temporal stores), run once per 64-column half of the wave's sub-tile.  Reachable only through vl_gemm_bf16(..., cfg = 14) for
-// VL_EPI_BF16 / VL_ACT_NONE on whole 256x256 tiles with K >= 512; tools/pk4_probe.py checks it against the shipped kernel and
-// times both.  First thing to do with it on a GPU: that probe; then the phase counters (k-loop cycles per step against the 8-wave
-// kernel's 2 460), then the other epilogues.
+// the next half k-step in flight under the 64 MFMAs of the current one, hand-ordered) and the epilogues of the 8-wave kernel
+// that carry the C3 step (plain bf16, GELU, GELU + gelu', bf16 residual, dGELU from the saved gelu': bias, wave-private LDS
+// transpose, 16-byte non-temporal stores), run once per 64-column half of the wave's sub-tile.  Reachable only through
+// vl_gemm_bf16(..., cfg = 14) on whole 256x256 tiles with K >= 512; tools/pk4_probe.py checks every variant against the
+// shipped kernel and times both.  First thing to do with it on a GPU: that probe; then the phase counters (k-loop cycles per
+// step against the 8-wave kernel's 2 460).  If it wins: launch_best_persist() in vl_gemm.hip is where to prefer it.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
@@ -26,7 +27,13 @@ constexpr int P4_GN = 8;                                  // N-tiles per group o
 
 typedef __attribute__((address_space(3))) void* lds_ptr4_t;
 
+// EPI / ACT as in vl_gemm_park.hip, the subset that carries the C3 step: EPI_BF16 with ACT 0 (plain), 1 (GELU), 4 (GELU, gelu' of
+// the bf16-rounded pre-activation to out2); EPI_RES_BF16 (bf16 residual, in place allowed); EPI_DGELU with ACT 4 (times the
+// saved gelu').
+template <int EPI, int ACT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) gemm_nt_pk4_kernel(const GemmP p) {
+  constexpr bool HAS_AUX = (EPI == EPI_RES_BF16 || EPI == EPI_DGELU);       // second operand of the output's shape
+  constexpr bool OUT2 = (EPI == EPI_BF16 && ACT == 4);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tiles_n = p.N >> 8, tiles_m = p.M >> 8;
   const int nk = p.K >> 6;
@@ -200,14 +207,32 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
           for (int e = 0; e < 4; ++e) bvq[q][e] = has_bias ? bvq[q][e] : 0.f;
         }
-        unsigned char* const obase = (unsigned char*)pe.out + ((size_t)(mrow0 + prow) * pe.ldo + ncol0 + ch * 64 + pchunk * 8) * 2;
+        const size_t lane_off = ((size_t)prow * pe.ldo + ncol0 + ch * 64 + pchunk * 8) * 2;       // this lane's 16 bytes of a pass
+        unsigned char* const obase = (unsigned char*)pe.out + (size_t)mrow0 * ldo2 + lane_off;
+        [[maybe_unused]] unsigned char* const o2base = (unsigned char*)pe.out2 + (size_t)mrow0 * ldo2 + lane_off;
+        // EPI_RES_BF16 indexes its residual by the absolute row (m + m_off) with an un-offset pointer (vl_gemm.hip run_gemm)
+        [[maybe_unused]] const unsigned char* const abase =
+            (const unsigned char*)pe.res + (size_t)(mrow0 + (EPI == EPI_RES_BF16 ? pe.m_off : 0)) * ldo2 + lane_off;
+        [[maybe_unused]] u32x4 aux[2][4];                   // second operand of row block i in aux[i & 1], requested one block ahead
+        auto load_aux = [&](int i) {
+          if constexpr (HAS_AUX) {
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) aux[i & 1][pass] = *(const u32x4*)(abase + (size_t)(i * 32 + pass * 8) * ldo2);
+          }
+        };
+        load_aux(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                       // 32-row blocks
+          if (i < 3) load_aux(i + 1);
 #pragma unroll
           for (int jh = 0; jh < 2; ++jh)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const f32x4 v = scale_bias(acc[i * 2 + jh][ch * 4 + q], pe.alpha, bvq[q]);
+              f32x4 v = scale_bias(acc[i * 2 + jh][ch * 4 + q], pe.alpha, bvq[q]);
+              if constexpr (EPI == EPI_BF16 && ACT == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+              }
               u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
               const int row = jh * 16 + er;
               *(u32x2*)(slab + row * 128 + (((q * 2 + (eq >> 1)) ^ (row & 7)) << 4) + (eq & 1) * 8) = o;
@@ -216,8 +241,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
           for (int pass = 0; pass < 4; ++pass) {
             const int r = pass * 8 + prow;
-            const u32x4 w = *(const u32x4*)(slab + r * 128 + ((pchunk ^ (r & 7)) << 4));
-            __builtin_nontemporal_store(w, (u32x4*)(obase + (size_t)(i * 32 + pass * 8) * ldo2));
+            u32x4 w = *(const u32x4*)(slab + r * 128 + ((pchunk ^ (r & 7)) << 4));
+            const size_t roff = (size_t)(i * 32 + pass * 8) * ldo2;
+            if constexpr (OUT2) {                           // out = gelu(pre), out2 = gelu'(pre), both of the bf16-rounded pre-activation
+              u32x4 d;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { unsigned int y, g; gelu_and_grad_pk(w[e], y, g); w[e] = y; d[e] = g; }
+              __builtin_nontemporal_store(d, (u32x4*)(o2base + roff));
+            } else if constexpr (EPI == EPI_RES_BF16) {
+              const u32x4 rr = aux[i & 1][pass];
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                w[e] = pack2bf(bf2f((bf16_t)(w[e] & 0xffff)) + bf2f((bf16_t)(rr[e] & 0xffff)), bf2f((bf16_t)(w[e] >> 16)) + bf2f((bf16_t)(rr[e] >> 16)));
+            } else if constexpr (EPI == EPI_DGELU) {
+              const u32x4 rr = aux[i & 1][pass];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) w[e] = mul_pk_bf16(w[e], rr[e]);      // aux = gelu' saved by the forward
+            }
+            __builtin_nontemporal_store(w, (u32x4*)(obase + roff));
           }
         }
       }
@@ -228,22 +269,34 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 
 }  // namespace
 
-// Internal entries used by vl_gemm.hip's dispatcher for cfg = 14 (not part of the public C ABI).
-bool vl_gemm_pk4_supported(int epi, const void* params) {
-  const GemmP& p = *(const GemmP*)params;
-  if (epi != EPI_BF16 || p.act != 0 || p.out2 || p.res || p.ksplit_len || p.res_div != 1) return false;
-  if ((p.M & 255) || (p.N & 255) || (p.K & 63) || p.K < 512 || p.M <= 0 || p.N <= 0 || (p.ldo & 3)) return false;
-  if (p.ldo & 7) return false;
-  return !((((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.out) & 15) || (p.bias && (((uintptr_t)p.bias) & 15)));
-}
-
-int vl_gemm_pk4_launch(const void* params, int ncu, hipStream_t s) {
-  const GemmP& p = *(const GemmP*)params;
-  static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_nt_pk4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P4_LDS);
+template <int EPI, int ACT>
+static int launch_pk4(const GemmP& p, int ncu, hipStream_t s) {
+  auto kern = gemm_nt_pk4_kernel<EPI, ACT>;
+  static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P4_LDS);
   if (attr != hipSuccess) return (int)attr;
   const int tiles = (p.M >> 8) * (p.N >> 8);
   int G = ncu & ~7;
   if (tiles < G) G = (tiles + 7) & ~7;
-  hipLaunchKernelGGL(gemm_nt_pk4_kernel, dim3(G), dim3(256), P4_LDS, s, p);
+  hipLaunchKernelGGL(kern, dim3(G), dim3(256), P4_LDS, s, p);
   return (int)hipGetLastError();
+}
+
+// Internal entries used by vl_gemm.hip's dispatcher for cfg = 14 (not part of the public C ABI).
+bool vl_gemm_pk4_supported(int epi, const void* params) {
+  const GemmP& p = *(const GemmP*)params;
+  if (p.ksplit_len || p.res_div != 1 || p.ln_mean || p.row_part) return false;
+  if ((p.M & 255) || (p.N & 255) || (p.K & 63) || p.K < 512 || p.M <= 0 || p.N <= 0 || (p.ldo & 7)) return false;
+  if ((((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.out | (uintptr_t)p.res | (uintptr_t)p.out2) & 15) || (p.bias && (((uintptr_t)p.bias) & 15))) return false;
+  if (epi == EPI_BF16) return !p.res && ((p.act == 0 && !p.out2) || (p.act == 1 && !p.out2) || (p.act == 4 && p.out2));
+  if (epi == EPI_RES_BF16) return p.res && p.act == 0 && !p.out2;
+  if (epi == EPI_DGELU) return p.res && p.act == 4 && !p.out2 && !p.bias;
+  return false;
+}
+
+int vl_gemm_pk4_launch(int epi, const void* params, int ncu, hipStream_t s) {
+  const GemmP& p = *(const GemmP*)params;
+  if (epi == EPI_BF16) return p.act == 1 ? launch_pk4<EPI_BF16, 1>(p, ncu, s) : (p.act == 4 ? launch_pk4<EPI_BF16, 4>(p, ncu, s) : launch_pk4<EPI_BF16, 0>(p, ncu, s));
+  if (epi == EPI_RES_BF16) return launch_pk4<EPI_RES_BF16, 0>(p, ncu, s);
+  if (epi == EPI_DGELU) return launch_pk4<EPI_DGELU, 4>(p, ncu, s);
+  return (int)hipErrorInvalidValue;
 }
