@@ -738,13 +738,14 @@ namespace {
 
 // Kernel selection / tuning inputs of the persistent kernels.  Read once from the environment so that one build can be
 // A/B-measured on the GPU box (tools/kernel_bench.py, bench.py); the defaults are the measured best.
-struct GemmTune { int prefer_pp, pp_delay, mfma16, pk_gn; };
+struct GemmTune { int prefer_pp, pp_delay, mfma16, pk_gn, prefer_pk4; };
 inline int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }
 inline const GemmTune& gemm_tune() {
-  static const GemmTune t{env_int("VL_GEMM_PP", 0), env_int("VL_PP_DELAY", 4), env_int("VL_GEMM_MFMA16", 1), env_int("VL_GEMM_GN", 0)};
+  static const GemmTune t{env_int("VL_GEMM_PP", 0), env_int("VL_PP_DELAY", 4), env_int("VL_GEMM_MFMA16", 1), env_int("VL_GEMM_GN", 0),
+                          env_int("VL_GEMM_PK4", 0)};
   return t;
 }
 inline GemmP tuned(const GemmP& p) {
@@ -762,6 +763,8 @@ hipError_t launch_best_persist(const GemmP& p0, hipStream_t s) {
   // 256x256 tiles where N allows them (fewer operand bytes per flop: the chip is power-bound on these GEMMs, DESIGN.md
   // section 7); the ping-pong kernel's 256x128 tiles take N % 256 == 128 (ViT-bigG: 1664 = 13 x 128)
   if (gemm_tune().prefer_pp && vl_gemm_pp_supported(EPI, &p)) return (hipError_t)vl_gemm_pp_launch(EPI, &p, num_cus(), s);
+  // VL_GEMM_PK4=1 (measurement switch, default off): the experimental one-wave-per-SIMD kernel wherever it has the epilogue
+  if (gemm_tune().prefer_pk4 && vl_gemm_pk4_supported(EPI, &p)) return (hipError_t)vl_gemm_pk4_launch(EPI, &p, num_cus(), s);
   if (vl_gemm_park_supported(EPI, &p)) return (hipError_t)vl_gemm_park_launch(EPI, &p, num_cus(), s);
   if (vl_gemm_pp_supported(EPI, &p)) return (hipError_t)vl_gemm_pp_launch(EPI, &p, num_cus(), s);
   return launch_persist<EPI>(p, s);
