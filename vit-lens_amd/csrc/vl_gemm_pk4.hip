@@ -128,6 +128,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   };
   // (hipcc does not model the LDS write of the DMA builtin: wait by hand; raw barrier, no fence - vl_gemm_park.hip)
   auto dma_wait_and_barrier = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  // the FIRST barrier of a tile behind an epilogue: the DMA it needs was issued in front of the epilogue, i.e. it is older than
+  // the epilogue's NST output stores in the in-order vmcnt queue - those keep draining under the first k-step (vl_gemm_park.hip)
+  constexpr int NST = OUT2 ? 63 : 32;                       // (vmcnt is 6 bits on gfx9: 63 is the most that can be left outstanding)
+  auto first_wait_and_barrier = [&]() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NST) : "memory"); };
+  bool after_epi = false;                                   // (wave-uniform) the next barrier is the first one behind an epilogue
 
   dma_step(smem);
   dma_step(smem + P4_STAGE);                                // nk >= 8: still inside tile 0
@@ -160,7 +165,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
     for (int ia = 4; ia < 8; ++ia) { if constexpr (first) row_new(0, ia); else row_acc(0, ia); }
     __builtin_amdgcn_sched_barrier(0);
-    dma_wait_and_barrier();
+    if (after_epi) { first_wait_and_barrier(); after_epi = false; } else dma_wait_and_barrier();
     const bool more = dti < my_tiles;                       // (wave-uniform) operands left to fetch
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
@@ -181,6 +186,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
       tile_origin(ti + 1, nm0, nn0);
       make_rsrc(nm0, nn0, rsA_n, rsW_n);
     }
+    after_epi = ti > 0;
     kstep(std::true_type{}, std::false_type{});
     for (int kt = 1; kt < nk - 1; ++kt) kstep(std::false_type{}, std::false_type{});
     kstep(std::false_type{}, std::true_type{});
