@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   //           4 bits: with 16 reads up front hipcc emitted lgkmcnt(14), i.e. a stall on two of the NEW reads);
   //   barrier (every wave holds its last fragments of `cur`; the DMA of the next k-step, issued one k-step ago, has landed);
   //   phase B (k half 1, set 1): per MFMA row two fragment reads of the next k-step's half 0 (set 0, from `oth`) in front of it
-  //           and one DMA piece of the k-step after next (into `cur`) behind it.
+  //           and, behind each of the first four rows, two DMA pieces of the k-step after next (into `cur`).
   int par = 0;
   auto kstep = [&](auto FIRST, auto LAST) {
     constexpr bool last = decltype(LAST)::value, first = decltype(FIRST)::value;
@@ -173,7 +173,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
       __builtin_amdgcn_sched_barrier(0);
       row_acc(1, g);                                        // MFMAs first behind the barrier: the matrix pipe drained while the wave waited
       __builtin_amdgcn_sched_barrier(0);
-      if (more) dma_piece(cur, g);                          // issued (M0 write, wait state, two 1 KB pieces) while the row executes
+      // the eight DMA pieces go behind the FIRST four rows, two each (M0 write, wait state, 2 x 2 KB issued while the row
+      // executes): the data is read one k-step later, and the last piece should have more than one phase (~1 100 cycles,
+      // about one loaded HBM round trip) to land before that barrier's vmcnt(0)
+      if (g < 4 && more) { dma_piece(cur, 2 * g); dma_piece(cur, 2 * g + 1); }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (more) dma_advance();
