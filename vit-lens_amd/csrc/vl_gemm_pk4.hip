@@ -141,9 +141,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 
   // One k-step = two phases of 64 MFMAs on ONE wave per SIMD: nothing else hides latency, so every phase carries its share of the
   // other work BETWEEN its MFMA rows (sched_barrier keeps the hand order):
-  //   phase A (k half 0, set 0): the 16 fragment reads of half 1 (set 1), 8 in front of each 32 MFMAs - never more than 15 LDS
-  //           operations outstanding, or the wait in front of the first MFMA could not be encoded without stalling (lgkmcnt is
-  //           4 bits: with 16 reads up front hipcc emitted lgkmcnt(14), i.e. a stall on two of the NEW reads);
+  //   phase A (k half 0, set 0): per MFMA row (8 MFMAs, ~136 cycles) two of the 16 fragment reads of half 1 (set 1) in front of
+  //           it.  (All 16 reads up front cannot be waited for without a stall: lgkmcnt is 4 bits, hipcc emitted lgkmcnt(14),
+  //           i.e. a wait on two of the NEW reads; and eight reads in a row leave the matrix pipe idle behind the last MFMA);
   //   barrier (every wave holds its last fragments of `cur`; the DMA of the next k-step, issued one k-step ago, has landed);
   //   phase B (k half 1, set 1): per MFMA row two fragment reads of the next k-step's half 0 (set 0, from `oth`) in front of it
   //           and, behind each of the first four rows, two DMA pieces of the k-step after next (into `cur`).
@@ -154,17 +154,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     unsigned char* oth = smem + (par ^ 1) * P4_STAGE;
     auto& row_acc = mma_row; auto& row_new = mma_row_zc;    // (named outside the discarded branches of this generic lambda)
 #pragma unroll
-    for (int jb = 0; jb < 8; ++jb) ldW(cur, 1, 1, jb);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ia = 0; ia < 4; ++ia) { if constexpr (first) row_new(0, ia); else row_acc(0, ia); }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ia = 0; ia < 8; ++ia) ldA(cur, 1, 1, ia);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ia = 4; ia < 8; ++ia) { if constexpr (first) row_new(0, ia); else row_acc(0, ia); }
-    __builtin_amdgcn_sched_barrier(0);
+    for (int g = 0; g < 8; ++g) {
+      ldW(cur, 1, 1, g); ldA(cur, 1, 1, g);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (first) row_new(0, g); else row_acc(0, g);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (after_epi) { first_wait_and_barrier(); after_epi = false; } else dma_wait_and_barrier();
     const bool more = dti < my_tiles;                       // (wave-uniform) operands left to fetch
 #pragma unroll
