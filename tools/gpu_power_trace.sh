@@ -9,8 +9,9 @@ import sys, json
 try:
     d = json.load(sys.stdin); c = d[sorted(d)[0]]
     pw = [v for k, v in c.items() if 'ower' in k and 'W' in k]
-    sc = [v for k, v in c.items() if k.startswith('sclk')]
-    mc = [v for k, v in c.items() if k.startswith('mclk')]
+    pick = lambda pre: ([v for k, v in c.items() if k.startswith(pre) and 'speed' in k] or [v for k, v in c.items() if k.startswith(pre)])
+    sc = pick('sclk')
+    mc = pick('mclk')
     print(pw[0] if pw else '?', sc[0] if sc else '?', mc[0] if mc else '?')
 except Exception as e:
     print('?', '?', '?')
