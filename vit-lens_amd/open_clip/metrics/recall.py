@@ -1,8 +1,6 @@
 """Retrieval recall@{1,5,10} in both directions (reference: open_clip/metrics/recall.py:8-78).  The image (or audio /
 video) features are collected per batch and gathered across ranks; the similarity matrix against the text features is
 one GEMM on the HIP kernel (fp32-accurate bf16 hi/lo split, `zero_shot_logits`), the ranking is top-10 + id matching."""
-import torch
-
 from .base_metric import BaseMetric
 
 
