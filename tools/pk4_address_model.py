@@ -50,3 +50,43 @@ for l in range(64):
             bad2 += slab[a + e * 2] != (r, pchunk * 8 + e)
 print("slab reads that hit the wrong (row, column):", bad2)
 assert bad == 0 and worst == 1 and bad2 == 0
+
+
+# ---- schedule model of the main loop: which (tile, k-step) a stage holds when it is read, and that no DMA batch overwrites
+# data still to be read (two stages, DMA two k-steps ahead of the MFMAs and across tile boundaries) ----
+def run_schedule(my_tiles, nk):
+    stage = [None, None]
+    unread = [set(), set()]                               # k halves of the held data the MFMA stream has not fetched yet
+    pos = [0, 0]                                          # DMA position (tile, k-step)
+
+    def dma(st):
+        assert not unread[st], ("DMA overwrites unread data", st, stage[st], unread[st])
+        stage[st] = tuple(pos); unread[st] = {0, 1}
+        pos[1] += 1
+        if pos[1] == nk:
+            pos[1] = 0; pos[0] += 1
+
+    def read(st, h, want):
+        assert stage[st] == want and h in unread[st], ("wrong or repeated read", st, h, stage[st], want)
+        unread[st].discard(h)
+    dma(0); dma(1)
+    par = 0
+    read(0, 0, (0, 0))                                    # ldfrags(smem, 0, 0)
+    for ti in range(my_tiles):
+        for kt in range(nk):
+            cur, oth = par, par ^ 1
+            read(cur, 1, (ti, kt))                        # phase A: the fragments of half 1
+            if pos[0] < my_tiles:                         # (barrier) phase B: DMA of k-step kt + 2 into cur ...
+                dma(cur)
+            if kt != nk - 1:
+                read(oth, 0, (ti, kt + 1))                # ... and the next k-step's half 0
+            par ^= 1
+        if ti + 1 < my_tiles:
+            read(par, 0, (ti + 1, 0))                     # behind the epilogue: first fragments of the next tile
+    assert not unread[0] and not unread[1]
+
+
+for mt in (1, 2, 3, 5):
+    for nk_ in (8, 9, 16, 64):
+        run_schedule(mt, nk_)
+print("schedule: every read finds its (tile, k-step), no DMA overwrites unread data, nothing is left unread")
