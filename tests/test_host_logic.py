@@ -57,3 +57,33 @@ def test_folding_entries_refuse_bad_arguments_without_touching_the_gpu():
     assert b"null operand" in lib.vl_last_error()
     assert lib.vl_gemm_res_rowstats_bf16(None, None, None, None, None, None, 256, 256, 512, 512, 512, 256, None) == 1
     assert b"null operand" in lib.vl_last_error()
+
+
+def test_layernorm_fold_on_rows_with_massive_channels():
+    """The arithmetic of the folded path, emulated on the CPU (bf16-rounded operands, fp32 accumulation as the MFMAs do), on
+    rows shaped like the residual stream of a TRAINED ViT: two channels hundreds of standard deviations out, per-row offsets,
+    gamma spread over 0.05 .. 3.  Against an fp64 LayerNorm + Linear the folded evaluation rstd * (x Wg^T - mean * c) + d is no
+    worse than the path it replaces (bf16(LN(x)) bf16(W)^T + b): the subtraction of the mean term happens in fp32 on exact
+    products, and the LayerNorm output is never rounded to bf16."""
+    import torch
+    from vitlens_hip import ops
+    g = torch.Generator().manual_seed(3)
+    M, K, N = 512, 1024, 256
+    x = torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g) * 2) + torch.randn(M, 1, generator=g) * 0.7
+    x[:, 7] += 300.0; x[:, 500] -= 180.0
+    x = x.bfloat16().float()                                  # the residual stream IS bf16
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g) * 0.1
+    gamma = 0.05 + 2.95 * torch.rand(K, generator=g)
+    beta = torch.randn(K, generator=g)
+    ref = torch.nn.functional.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-5) @ w.double().t() + b.double()
+    mu = x.mean(1, keepdim=True); rstd = (x.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    # the path it replaces: LayerNorm in fp32, output rounded to bf16, bf16 weight, fp32 accumulation
+    h = torch.nn.functional.layer_norm(x, (K,), gamma, beta, 1e-5).bfloat16().float()
+    plain = h @ w.bfloat16().float().t() + b
+    # the folded path: raw bf16 rows against bf16(W gamma), row statistics and column vectors applied in fp32
+    wg, d, c = ops.fold_ln_linear(w, b, gamma, beta)
+    folded = rstd * (x @ wg.float().t()) + ((-mu * rstd) * c[None, :] + d[None, :])
+    e_plain = float((plain.double() - ref).norm() / ref.norm())
+    e_fold = float((folded.double() - ref).norm() / ref.norm())
+    assert e_fold < 4e-3 and e_fold < 1.2 * e_plain, (e_fold, e_plain)
