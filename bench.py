@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--text-wsplit", default="on", choices=["on", "off"],
                     help="text tower weights as two bf16 terms (on: cosine matrices within 1e-3 of the fp32 CPU path; off: the "
                          "reference's amp_bf16 arithmetic, 1.3-1.5e-3)")
-    ap.add_argument("--ln-fold", default="off", choices=["on", "off"],
+    ap.add_argument("--ln-fold", default=None, choices=["on", "off"],
                     help="LayerNorms of the frozen ViT blocks folded into the GEMMs either side of them (on) or run as their own "
                          "passes (off): A/B switch, sets VL_LN_FOLD before the package is imported")
     ap.add_argument("--force-dist", action="store_true",
@@ -479,7 +479,8 @@ def selftest_main(a, rank, world):
 
 def main():
     a = parse()
-    os.environ["VL_LN_FOLD"] = "1" if a.ln_fold == "on" else "0"      # read when vitlens_hip.engine is imported
+    if a.ln_fold is not None:            # (not given: the environment / the library default decides)
+        os.environ["VL_LN_FOLD"] = "1" if a.ln_fold == "on" else "0"      # read when vitlens_hip.engine is imported
     have_rank = "RANK" in os.environ
     if a.gpus > 1 and not have_rank:
         sys.exit(spawn_ranks(a.gpus))
@@ -665,7 +666,7 @@ def main():
                           "global_batch": world * a.batch, "residual_dtype": a.res_dtype,
                           "accumulate": "fp32", "parallelism": f"dp{world}", "gemm_cfg": a.gemm_cfg, "via": a.via,
                           "text_tower_weights": "bf16 x 2 terms" if (a.text_wsplit == "on" and a.workload != "c2") else "bf16",
-                          "layernorm": "folded into the GEMMs (frozen blocks)" if a.ln_fold == "on" else "own passes",
+                          "layernorm": "folded into the GEMMs (frozen blocks)" if os.environ.get("VL_LN_FOLD", "0") != "0" else "own passes",
                           **({"force_dist": True} if a.force_dist else {})},
                "roofline": roof}
         if use_dist:         # diagnosis of a scaling run: per-rank step time (stragglers) and the exchange's share of the step

@@ -239,3 +239,114 @@ def test_fp32_residual_epilogue_on_the_persistent_kernel(M, N, K):
     # what the auto dispatch does with it (whole rounds persistent + leftover rows)
     auto = ops.gemm(a, w, bias, res=res, epi=ops.EPI_RES_F32)
     assert relerr(auto, acc + bias + res) < 1e-5
+
+
+def test_many_tiles_every_epilogue_variant():
+    """The first barrier of a tile behind an epilogue waits `vmcnt(NST)`, NST = the stores a wave issues per tile (derived from
+    the epilogue's constants in vl_gemm_park.hip): an instantiation that issued fewer stores than its NST would let the barrier
+    pass before the tile's second k-step has landed in LDS - silently wrong products, only with several tiles per workgroup.
+    Every epilogue variant of the 8-wave kernel that the plain / GELU / residual gate above does not launch, 16 tiles per
+    workgroup (8 for the half-width outputs), element-wise against fp32 torch and bit-identical over three launches."""
+    ops = _ops()
+    M, N, K = 65536, 4096, 1024
+    a = rnd(M, K, seed=71).bfloat16().cuda(); w = rnd(N, K, seed=72, scale=K ** -0.5).bfloat16().cuda()
+    bias = rnd(N, seed=73).cuda()
+    acc = a.float() @ w.float().t()
+    pre = (acc + bias).bfloat16().float()                    # the two-output GELU variants act on the bf16-rounded pre-activation
+    g = rnd(M, N, seed=74, scale=0.5).bfloat16().cuda()
+    resf = rnd(M, N, seed=75).cuda()
+    h2 = rnd(M, 2 * N, seed=76, scale=1.2).bfloat16().cuda()
+
+    def close(out, ref, tol=2.0 ** -6):
+        return int(((out.float() - ref).abs() > ref.abs() * tol + 2e-2).sum())
+
+    def gelu_grad(x):
+        x = x.clone().requires_grad_(True)
+        torch.nn.functional.gelu(x).sum().backward()
+        return x.grad
+
+    def launch():
+        o = {}
+        u = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        o["gelu+save"] = ops.gemm(a, w, bias, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=8, out2=u); o["gelu+save:pre"] = u
+        d = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        o["gelu+dsave"] = ops.gemm(a, w, bias, epi=ops.EPI_BF16, act=ops.ACT_GELU_DSAVE, cfg=8, out2=d); o["gelu+dsave:d"] = d
+        o["relu"] = ops.gemm(a, w, bias, epi=ops.EPI_BF16, act=ops.ACT_RELU, cfg=8)
+        o["dgelu"] = ops.gemm(a, w, None, out=torch.empty_like(g), res=g, epi=ops.EPI_DGELU, cfg=8)
+        o["dgelu_saved"] = ops.gemm(a, w, None, out=torch.empty_like(g), res=g, epi=ops.EPI_DGELU, act=ops.ACT_GELU_DSAVE, cfg=8)
+        o["res_f32"] = ops.gemm(a, w, bias, res=resf, epi=ops.EPI_RES_F32, cfg=8)
+        hs = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        o["geglu"] = ops.gemm(a, w, bias, epi=ops.EPI_GEGLU, cfg=8, out2=hs); o["geglu:pre"] = hs
+        o["geglu_nosave"] = ops.gemm(a, w, bias, epi=ops.EPI_GEGLU, cfg=8)
+        dh = torch.empty(M, 2 * N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(a, w, None, out=dh, res=h2, epi=ops.EPI_DGEGLU, cfg=8); o["dgeglu"] = dh
+        return o
+    first = launch()
+    hf = first["geglu:pre"].float()
+    refs = {"gelu+save": torch.nn.functional.gelu(pre), "gelu+save:pre": acc + bias,
+            "gelu+dsave": torch.nn.functional.gelu(pre), "gelu+dsave:d": gelu_grad(pre), "relu": torch.relu(acc + bias),
+            "dgelu": acc * gelu_grad(g.float()), "dgelu_saved": acc * g.float(), "res_f32": acc + bias + resf,
+            "geglu:pre": acc + bias, "geglu": hf[:, 0::2] * torch.nn.functional.gelu(hf[:, 1::2])}
+    refs["geglu_nosave"] = refs["geglu"]
+    hq = h2.float().requires_grad_(True)
+    (hq[:, 0::2] * torch.nn.functional.gelu(hq[:, 1::2]) * acc).sum().backward()
+    refs["dgeglu"] = hq.grad
+    for k, ref in refs.items():
+        assert close(first[k], ref) == 0, (k, close(first[k], ref))
+    del refs, hq, hf
+    for rep in range(2):
+        again = launch()
+        for k, v in again.items():
+            assert torch.equal(v, first[k]), (k, rep)
+
+
+def test_many_tiles_lnfold_variants():
+    """The same gate for the LayerNorm-folding instantiations (consumer ACT 10 / 11 / 14, producer ACT 20 with its extra
+    partial-sum stores): bit-identical over three launches and against the un-folded kernel on the same operands."""
+    ops = _ops()
+    M, N, K = 65536, 4096, 1024
+    x = rnd(M, K, seed=81).bfloat16().cuda(); w = rnd(N, K, seed=82, scale=K ** -0.5).cuda()
+    b = rnd(N, seed=83).cuda()
+    gam, bet = (1 + 0.2 * rnd(K, seed=84)).cuda(), (0.1 * rnd(K, seed=85)).cuda()
+    fold = ops.fold_ln_linear(w, b, gam, bet)
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    ops.ln_row_stats(None, x, 0, mean, rstd)
+    hws = torch.empty(1, K, device="cuda", dtype=torch.bfloat16)
+    ln = torch.nn.functional.layer_norm(x.float(), (K,), gam, bet)
+    ref = ln @ w.t() + b
+
+    def launch():
+        o = {}
+        for name, act in (("ln", ops.ACT_NONE), ("ln_gelu", ops.ACT_GELU), ("ln_dsave", ops.ACT_GELU_DSAVE)):
+            out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            d = torch.empty(M, N, device="cuda", dtype=torch.bfloat16) if act == ops.ACT_GELU_DSAVE else None
+            ops.gemm_lnfold(x, fold, mean, rstd, out, w.bfloat16(), b, gam, bet, hws, act=act, out2=d)
+            o[name] = out
+            if d is not None:
+                o[name + ":d"] = d
+        return o
+    first = launch()
+    assert relerr(first["ln"], ref) < 6e-3
+    assert relerr(first["ln_gelu"], torch.nn.functional.gelu(ref)) < 8e-3
+    assert relerr(first["ln_dsave"], torch.nn.functional.gelu(ref)) < 8e-3
+    assert bool(torch.isfinite(first["ln_dsave:d"]).all())
+    for rep in range(2):
+        for k, v in launch().items():
+            assert torch.equal(v, first[k]), (k, rep)
+    # producer: residual + partial row sums (two stores per chunk)
+    a2 = rnd(M, K, seed=86).bfloat16().cuda(); w2 = rnd(1024, K, seed=87, scale=K ** -0.5).bfloat16().cuda()
+    b2 = rnd(1024, seed=88).cuda()
+    res = rnd(M, 1024, seed=89).bfloat16().cuda()
+    plain = ops.gemm(a2, w2, b2, res=res, epi=ops.EPI_RES_BF16, cfg=8)
+    parts = []
+    for rep in range(3):
+        part = torch.full((M * 16 * 2,), float("nan"), device="cuda")
+        out = torch.empty_like(res)
+        mm = ops.gemm_res_rowstats(a2, w2, b2, out, res, part)
+        assert mm == M and torch.equal(out, plain)
+        parts.append(part)
+    assert torch.equal(parts[0], parts[1]) and torch.equal(parts[0], parts[2])
+    s = parts[0].view(M, 16, 2)
+    of = plain.float()
+    assert float((s[:, :, 0].sum(1) - of.sum(1)).abs().max()) < 2e-2 * float(of.abs().sum(1).max())
+    assert relerr(s[:, :, 1].sum(1), (of * of).sum(1)) < 1e-4

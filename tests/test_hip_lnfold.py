@@ -136,10 +136,10 @@ def test_tower_forward_and_backward_with_and_without_folding():
     tok = (rnd(B * 256, 1024, seed=11) * 0.5).bfloat16().cuda()
     dfeat = rnd(B, 768, seed=12).cuda()
     res = {}
-    keep = (E.LN_FOLD, T.LN_FOLD)
+    keep = E.LN_FOLD                       # (train.py reads engine.LN_FOLD through the module)
     try:
         for fold in (True, False):
-            E.LN_FOLD = fold; T.LN_FOLD = fold
+            E.LN_FOLD = fold
             eng = E.VitEngine(sd, "visual.", cfg, "cuda", res_dtype=torch.bfloat16)
             f_inf = eng.trunk(tok, B).clone()
             tr = T.TowerTrainer(eng, train_blocks=[0])
@@ -148,7 +148,7 @@ def test_tower_forward_and_backward_with_and_without_folding():
             S = tr.saved(B, 257)
             res[fold] = (f_inf, f_tr, dtok, {k: v.clone() for k, v in tr.grads.items()}, [[t.clone() for t in st] for st in S.stats])
     finally:
-        E.LN_FOLD, T.LN_FOLD = keep
+        E.LN_FOLD = keep
     (fi1, ft1, d1, g1, s1), (fi0, ft0, d0, g0, s0) = res[True], res[False]
     assert torch.isfinite(fi1).all() and torch.isfinite(d1).all()
     assert relerr(fi1, fi0) < 1e-2 and relerr(ft1, ft0) < 1e-2, (relerr(fi1, fi0), relerr(ft1, ft0))

@@ -260,7 +260,21 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   // NST operations outstanding" retires exactly that DMA and leaves the NST stores of this wave draining under the first
   // k-step instead of in front of it (measured with vmcnt(0): 0.2-0.7 k cycles per k-step of store drain charged to the
   // k-loop, 11 k per tile behind the two-output GELU epilogue).  NST = the minimum number of stores a wave issues per tile.
-  constexpr int NST = (EPI == EPI_F32 || EPI == EPI_RES_F32 || IS_DGEGLU || STATS || (EPI == EPI_BF16 && (ACTB == 3 || ACTB == 4))) ? 32 : 16;
+  // Derived from the constants that generate the stores: every epilogue walks NCH = 16 chunks (4 row blocks x 4 passes) and
+  // issues ST_PER_CHUNK vector-memory stores per chunk on EVERY lane-uniform path - fp32 outputs two 32-column halves, DGEGLU
+  // two 16-byte halves, the two-output GELU variants out + out2, STATS the bf16 chunk + one 8-byte partial-sum store per pass
+  // (issued by the wave even where only lanes 0, 8, .. are active), GEGLU one (its optional pre-activation output does not
+  // count: NST is a MINIMUM).  An epilogue that issued fewer stores than NST would let this barrier pass before k-step 1 of
+  // the tile has landed; -DVL_GEMM_SAFE_WAIT builds wait for everything (debug A/B of exactly that failure).
+  constexpr int ST_PER_CHUNK = (EPI == EPI_F32 || EPI == EPI_RES_F32) ? NTL
+                               : (IS_DGEGLU || STATS || (EPI == EPI_BF16 && (ACTB == 3 || ACTB == 4))) ? 2 : 1;
+#ifdef VL_GEMM_SAFE_WAIT
+  constexpr int NST = 0;
+#else
+  constexpr int NST = NCH * ST_PER_CHUNK;
+#endif
+  static_assert(NCH == 4 * 4 && NST <= 63, "NST = stores per wave and tile; vmcnt is a 6-bit counter");
+  static_assert(!(EPI == EPI_BF16 && (ACTB == 3 || ACTB == 4)) || ST_PER_CHUNK == 2, "two-output epilogues store twice per chunk");
   auto first_wait_and_barrier = [&]() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NST) : "memory");
   };

@@ -80,7 +80,9 @@ class BaseMetric:
         """Sum of a per-rank scalar over the ranks (one all-reduce), as a Python float."""
         if not self.multi_rank():
             return float(value)
-        t = torch.tensor([float(value)], device=device, dtype=torch.float64 if device.type == "cpu" else torch.float32)
+        # float64 on every backend (RCCL reduces doubles): counts beyond 2^24 and soft-target sums stay exact, and the GPU
+        # communicator reports the same accuracy as gloo
+        t = torch.tensor([float(value)], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 

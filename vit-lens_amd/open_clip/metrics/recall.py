@@ -1,6 +1,8 @@
 """Retrieval recall@{1,5,10} in both directions (reference: open_clip/metrics/recall.py:8-78).  The image (or audio /
 video) features are collected per batch and gathered across ranks; the similarity matrix against the text features is
 one GEMM on the HIP kernel (fp32-accurate bf16 hi/lo split, `zero_shot_logits`), the ranking is top-10 + id matching."""
+import torch
+
 from .base_metric import BaseMetric
 
 
@@ -18,7 +20,8 @@ class Recall(BaseMetric):
     def gathered(self):
         """All ranks' (ids, features), rank-major (a rank without batches contributes zero rows: BaseMetric._collected)."""
         like = self.text_logits.new_zeros((0,) + tuple(self.text_logits.shape[1:]))
-        return self._collected("image_ids", like=self.text_ids[:0]), self._collected("image_logits", like=like)
+        ids_like = torch.as_tensor(self.text_ids)[:0]       # (text_ids may be a Python list: the placeholder of a rank that pushed nothing)
+        return self._collected("image_ids", like=ids_like), self._collected("image_logits", like=like)
 
     def merge_results(self, output_predict=False):
         from ..zero_shot_classifier import zero_shot_logits

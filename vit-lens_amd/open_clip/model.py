@@ -579,21 +579,29 @@ class TriCLIP(nn.Module):
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
         self._text_engine, self._text_key = None, None
         self._res_dtype = torch.float32
+        self._text_wsplit = True
 
-    def set_precision(self, precision: str):
+    def set_precision(self, precision: str, text_wsplit: bool = True):
         """`precision` of tri_create_model (factory.py:164): the GEMMs always run bf16 x bf16 -> f32 (what the reference's
         amp_bf16 autocast computes); "fp32" keeps the residual stream and its gradient in f32 (more precise than the
-        reference's autocast), "amp" / "amp_bf16" / "bf16" carry them in bf16 exactly as autocast does."""
+        reference's autocast), "amp" / "amp_bf16" / "bf16" carry them in bf16 exactly as autocast does.
+        text_wsplit (default on): the TEXT tower's weights as the sum of two bf16 terms on an fp32 residual stream - more
+        precise than the reference's autocast, needed for the 1e-3 bound on its cosine matrix; off = the
+        reference's amp_bf16 arithmetic for the text tower as well (half the text GEMM flops)."""
         import warnings
         dt = torch.float32 if precision == "fp32" else torch.bfloat16
         self._res_dtype = self.image.res_dtype = self.visual.res_dtype = dt
+        self._text_wsplit = bool(text_wsplit)
         self._text_engine = None
         # what actually runs, stated where the caller asked for something else (reference: factory.py:260-295 converts the
         # model / sets up autocast; training/precision.py:5-12)
         self.precision_requested = precision
-        self.precision_effective = ("bf16 x bf16 -> fp32 matrix products (text tower: two-term bf16 weights); LayerNorm / softmax "
-                                    "statistics, features, logits, loss in fp32; residual stream "
-                                    + ("fp32" if dt == torch.float32 else "bf16"))
+        self.precision_effective = ("image / modality towers: bf16 x bf16 -> fp32 matrix products, residual stream "
+                                    + ("fp32" if dt == torch.float32 else "bf16")
+                                    + "; text tower: " + ("two-term bf16 weights x bf16 activations -> fp32, residual stream fp32"
+                                                          if self._text_wsplit else
+                                                          "bf16 x bf16 -> fp32, residual stream " + ("fp32" if dt == torch.float32 else "bf16"))
+                                    + "; LayerNorm / softmax statistics, features, logits, loss in fp32")
         if precision == "fp32":
             warnings.warn("precision='fp32': the MI355X path has no fp32-arithmetic mode - matrix products take bf16 operands with "
                           "fp32 accumulation (cosine matrices within 1e-3 of the fp32 CPU path); 'fp32' selects the fp32 residual "
@@ -632,13 +640,14 @@ class TriCLIP(nn.Module):
         # (logit_scale is not a text-tower operand: it changes every step and must not invalidate the frozen tower's engine)
         prm = dict(self.named_parameters())
         names = [n for n in prm if not n.startswith(("image.", "visual.")) and n != "logit_scale"]
-        key = (str(dev), self._res_dtype, tuple(prm[n]._version for n in names))
+        key = (str(dev), self._res_dtype, self._text_wsplit, tuple(prm[n]._version for n in names))
         if self._text_engine is None or key != self._text_key:
             sd = {k: v for k, v in self.state_dict().items() if not k.startswith(("image.", "visual."))}
             t = self.text_cfg
             self._text_engine = E.TextEngine(sd, E.TextCfg(context_length=t.context_length, vocab_size=t.vocab_size,
                                                            width=t.width, heads=t.heads, layers=t.layers,
-                                                           embed_dim=self.text_projection.shape[1]), dev, res_dtype=self._res_dtype)
+                                                           embed_dim=self.text_projection.shape[1]), dev, res_dtype=self._res_dtype,
+                                                wsplit=self._text_wsplit)
             self._text_key = key
         return self._text_engine
 

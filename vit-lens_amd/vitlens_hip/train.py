@@ -14,7 +14,8 @@ from typing import Dict, Iterable, Optional
 import torch
 
 from . import ops
-from .engine import LN_FOLD, VitEngine
+from . import engine as _engine
+from .engine import VitEngine
 
 BF = torch.bfloat16
 
@@ -163,7 +164,7 @@ class TowerTrainer:
         # LayerNorm folding (engine.run_blocks; round 4): a FROZEN block never materialises ln_1 / ln_2 - its backward needs
         # only (mean, rstd), which ln_row_stats leaves in S.stats; a trainable block keeps its LayerNorm outputs (the operands
         # of its weight gradients).  Either kind leaves the partial row sums of its output when the next block is folded.
-        fold_ok = LN_FOLD and S.part is not None and "in_f" in w
+        fold_ok = _engine.LN_FOLD and S.part is not None and "in_f" in w
         folded = fold_ok and l not in self.train_blocks
         next_folded = fold_ok and l + 1 < self.layers and (l + 1) not in self.train_blocks
         if folded:
