@@ -27,6 +27,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+LN_FOLDED = True          # set in main() from vitlens_hip.engine.LN_FOLD / --ln-fold
 for p in (os.path.join(ROOT, "vit-lens_amd"), os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
@@ -60,12 +61,13 @@ def parse():
                          "recipe, out = model(image, text, visual_x); loss(**out).backward(); torch.optim.AdamW.step(); clamp")
     ap.add_argument("--gemm-cfg", type=int, default=-1)
     ap.add_argument("--bn-sync", action="store_true", help="c5 with --gpus N: SyncBatchNorm in the point tokenizer (--use-bn-sync)")
-    ap.add_argument("--text-wsplit", default="on", choices=["on", "off"],
-                    help="text tower weights as two bf16 terms (on: cosine matrices within 1e-3 of the fp32 CPU path; off: the "
-                         "reference's amp_bf16 arithmetic, 1.3-1.5e-3)")
+    ap.add_argument("--text-arith", default="f16", choices=["f16", "bf16x2", "bf16"],
+                    help="operands of the frozen text tower: f16 (default: IEEE half, cosine matrices 1-2e-4 from the fp32 CPU path at "
+                         "the bf16 rate), bf16x2 (round 4: two-term bf16 weights, 6-8e-4 at twice the flops), bf16 (the reference's "
+                         "amp_bf16 arithmetic, 0.8-1.9e-3)")
     ap.add_argument("--ln-fold", default=None, choices=["on", "off"],
                     help="LayerNorms of the frozen ViT blocks folded into the GEMMs either side of them (on) or run as their own "
-                         "passes (off): A/B switch, sets VL_LN_FOLD before the package is imported")
+                         "passes (off); default: the library's (on since round 5)")
     ap.add_argument("--force-dist", action="store_true",
                     help="--gpus 1 only: initialise a ONE-rank RCCL communicator and run the step's multi-rank code path on it "
                          "(packed all-gather, bucketed async all-reduce; prints collective_ms_per_step) - the API / stream "
@@ -233,7 +235,7 @@ def pmc_mfma_busy(dom):
            (4096, 1024, 0, 4): "gemm_nt_pk_kernel<0, 4, true>", (4096, 1024, 6, 4): "gemm_nt_pk_kernel<6, 4, true>",
            (3072, 1024, 0, 0): "gemm_nt_pk_kernel<0, 0, true>"}.get((dom["N"], dom["K"], dom["epi"], dom["act"]))
     plain = key
-    if key and os.environ.get("VL_LN_FOLD", "0") != "0":
+    if key and LN_FOLDED:
         # with the LayerNorm folding most launches of these shapes are the folding instantiations of the same kernel
         key = {"gemm_nt_pk_kernel<3, 0, true>": "gemm_nt_pk_kernel<3, 20, true>", "gemm_nt_pk_kernel<0, 1, true>": "gemm_nt_pk_kernel<0, 11, true>",
                "gemm_nt_pk_kernel<0, 4, true>": "gemm_nt_pk_kernel<0, 14, true>", "gemm_nt_pk_kernel<0, 0, true>": "gemm_nt_pk_kernel<0, 10, true>"}.get(key, key)
@@ -479,8 +481,6 @@ def selftest_main(a, rank, world):
 
 def main():
     a = parse()
-    if a.ln_fold is not None:            # (not given: the environment / the library default decides)
-        os.environ["VL_LN_FOLD"] = "1" if a.ln_fold == "on" else "0"      # read when vitlens_hip.engine is imported
     have_rank = "RANK" in os.environ
     if a.gpus > 1 and not have_rank:
         sys.exit(spawn_ranks(a.gpus))
@@ -495,6 +495,11 @@ def main():
         a.micro_batch = 128 if a.workload == "c5" else 256
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    from vitlens_hip import engine as _engine
+    if a.ln_fold is not None:            # (not given: the library default - folded - decides)
+        _engine.LN_FOLD = a.ln_fold == "on"
+    global LN_FOLDED
+    LN_FOLDED = bool(_engine.LN_FOLD)
     dist = None
     use_dist = world > 1 or a.force_dist
     if use_dist:
@@ -542,7 +547,7 @@ def main():
             audio = (torch.randn(a.batch, 512, 128, generator=g) * 0.5).to(dev)
             trainer = vstep.DualAudioStep(sd, tower_cfg, engine.TextCfg(), lens_cfg, dev, micro_batch=a.micro_batch,
                                           rank=rank, world_size=world, gemm_cfg=a.gemm_cfg, frozen_res_dtype=res_dtype, train_res_dtype=res_dtype, comm=comm,
-                                          force_comm=a.force_dist, text_wsplit=a.text_wsplit == "on")
+                                          force_comm=a.force_dist, text_arith=a.text_arith)
 
             def step():
                 return trainer.step(audio, texts)
@@ -553,7 +558,7 @@ def main():
             start = torch.randint(0, 8192, (a.batch,), generator=g).to(dev)
             trainer = vstep.TriModalPCStep(sd, tower_cfg, engine.TextCfg(), lens_cfg, dev, micro_batch=a.micro_batch,
                                            rank=rank, world_size=world, gemm_cfg=a.gemm_cfg, bn_training=True, frozen_res_dtype=res_dtype, train_res_dtype=res_dtype, comm=comm,
-                                           bn_sync=a.bn_sync, force_comm=a.force_dist, text_wsplit=a.text_wsplit == "on")
+                                           bn_sync=a.bn_sync, force_comm=a.force_dist, text_arith=a.text_arith)
 
             def step():
                 return trainer.step(images, texts, pts, start)
@@ -591,7 +596,7 @@ def main():
         texts = synth_text(a.batch, g).to(dev)
         trainer = vstep.TriModalDepthStep(sd, engine.TowerCfg(), engine.TextCfg(), dev, micro_batch=a.micro_batch,
                                           unlock_first_n=4, rank=rank, world_size=world, gemm_cfg=a.gemm_cfg, frozen_res_dtype=res_dtype, train_res_dtype=res_dtype, comm=comm,
-                                          force_comm=a.force_dist, text_wsplit=a.text_wsplit == "on")
+                                          force_comm=a.force_dist, text_arith=a.text_arith)
 
         def step():
             return trainer.step(images, texts, depths)
@@ -665,8 +670,8 @@ def main():
                            + (", packed RCCL embedding all-gather + flat gradient all-reduce" if world > 1 else "")),
                           "global_batch": world * a.batch, "residual_dtype": a.res_dtype,
                           "accumulate": "fp32", "parallelism": f"dp{world}", "gemm_cfg": a.gemm_cfg, "via": a.via,
-                          "text_tower_weights": "bf16 x 2 terms" if (a.text_wsplit == "on" and a.workload != "c2") else "bf16",
-                          "layernorm": "folded into the GEMMs (frozen blocks)" if os.environ.get("VL_LN_FOLD", "0") != "0" else "own passes",
+                          "text_tower_operands": {"f16": "fp16", "bf16x2": "bf16 x 2 weight terms", "bf16": "bf16"}[a.text_arith] if a.workload != "c2" else "n/a",
+                          "layernorm": "folded into the GEMMs (frozen blocks)" if LN_FOLDED else "own passes",
                           **({"force_dist": True} if a.force_dist else {})},
                "roofline": roof}
         if use_dist:         # diagnosis of a scaling run: per-rank step time (stragglers) and the exchange's share of the step

@@ -49,17 +49,27 @@ typedef struct ihipStream_t* hipStream_t;
 /* dtype tags for mixed-dtype entry points */
 #define VL_F32 0
 #define VL_BF16 1
+#define VL_F16 2          /* IEEE half: output of vl_layernorm_fwd (from f32 rows) feeding vl_gemm_f16 */
+
+#define VL_GEMM_AUTO (-1)
+#define VL_GEMM_PERSIST 8
+#define VL_GEMM_PINGPONG 10
 
 const char* vl_last_error(void);
 int vl_version(void);
 
 /* C[M,N] = A[M,K] · W[N,K]^T with fused epilogue.  A, W bf16.  K % 64 == 0, N % 4 == 0.
- * cfg: -1 auto (persistent 256x256 kernel on the whole rounds of row tiles + tail kernel on the leftover rows;
- *      128x128 tiles for small problems) | 0: 256x256 tile LDS-DMA | 1: 128x128 LDS-DMA | 2/3: same, register
- *      staging | 5 (4 = alias): round-1 persistent kernel | 6: the same on 256x128 tiles | 8: round-2 persistent kernel
- *      (vl_gemm_park.hip: staggered LDS-DMA issue, barrier in front of the last k-substep, burst of non-temporal stores;
- *      bf16-output epilogues, M % 256 == N % 256 == 0, K >= 512; what "auto" uses for the whole rounds of row tiles when
- *      it applies) | 9: tail kernel.
+ * cfg selects the kernel family - the ONE selector of this library: nothing else (no environment variable, no global
+ * setter) changes which code runs.  VL_GEMM_AUTO (-1) is what every product path passes; the explicit values exist for the
+ * parity tests (every family against fp32 and against each other) and the probes under tools/:
+ *   -1 VL_GEMM_AUTO     whole rounds of 256-row tiles on the persistent 256x256 kernel (8; 10 where N % 256 == 128), the
+ *                       leftover rows on 64x64 tiles or the split-K tail kernel, small problems on 128x128 tiles
+ *    8 VL_GEMM_PERSIST  vl_gemm_park.hip: persistent, 256x256 tiles, LDS-DMA two k-steps ahead, 16x16x32 MFMA, burst of
+ *                       non-temporal stores; M % 256 == N % 256 == 0, K >= 512
+ *   10 VL_GEMM_PINGPONG vl_gemm_pp.hip: two 4-wave workgroups per CU on 256x128 tiles (widths that are multiples of 128 only)
+ *    5 (4 = alias)      round-1 persistent kernel (any shape) | 6: the same on 256x128 tiles
+ *    0 / 1              one 256x256 / 128x128 LDS-DMA tile per workgroup | 2 / 3: the same with register staging
+ *    9                  split-K tail kernel (32x32 tile per workgroup) | 11 / 12: 64x64 / 128x64 tiles
  * Replaces nn.Linear / out_proj / mlp.c_fc(+GELU) / mlp.c_proj(+residual)
  * (open_clip/transformer.py:226-234,268-271), Perceiver to_q/to_kv/to_out/FeedForward
  * (open_clip/perceiver.py:85-123), pooled @ proj (transformer.py:786-787) and
@@ -92,6 +102,26 @@ int vl_gemm_bf16_ex(const void* A, const void* W, const float* bias, void* out, 
                     int M, int N, int K, int lda, int ldw, int ldo, float alpha, int epi, int act,
                     int res_div, int cfg, hipStream_t stream);
 
+/* The FROZEN text tower on IEEE-half operands (round 5).  TriCLIP.encode_text (open_clip/model.py:528-540) is forward-only in
+ * every recipe and its cosine-similarity MATRIX amplifies operand rounding (text features share a mutual cosine of ~0.6):
+ * bf16 operands leave it 0.8-1.9e-3 from the fp32 CPU path, above BASELINE.json's 1e-3; rounds 4's two-term bf16 weights
+ * brought it to 6-8e-4 at twice the products.  fp16 carries three more mantissa bits on EVERY operand (weights, GEMM inputs,
+ * q / k / v, attention probabilities) at the bf16 MFMA rate: 1-2e-4 at one product per weight.  The reference itself converts
+ * CLIP to fp16 (`convert_weights_to_fp16`, open_clip/model.py:393-419; precision "fp16", factory.py:260-295).  The residual
+ * stream stays fp32, 16-bit stores saturate at +-65504.
+ *   vl_gemm_f16      C = A . W^T with A [M,K], W [N,K] fp16; epi = VL_EPI_BF16 (here: out fp16 [M,N] = act(alpha*acc + bias),
+ *                    act none / GELU) or VL_EPI_RES_F32 (out f32 = res f32 + alpha*acc + bias, in place allowed).  The
+ *                    persistent 256x256 kernel only: M % 256 == N % 256 == 0, K % 64 == 0, K >= 512, 16-byte aligned
+ *                    operands - the caller pads its rows to whole tiles (replaces in_proj / out_proj / c_fc / c_proj of
+ *                    the text tower's ResidualAttentionBlocks, transformer.py:226-234,254-272)
+ *   vl_attn_fwd_f16  vl_attn_fwd_bf16 on fp16 q, k, v -> fp16 out: head dim 64, <= 288 keys, causal or not
+ *                    (F.multi_head_attention_forward with the additive causal mask, transformer.py:241-252,870-876)
+ *   vl_layernorm_fwd with y_dtype = VL_F16 writes the GEMM inputs. */
+int vl_gemm_f16(const void* A, const void* W, const float* bias, void* out, const void* res, int M, int N, int K,
+                int lda, int ldw, int ldo, float alpha, int epi, int act, hipStream_t stream);
+int vl_attn_fwd_f16(const void* q, const void* k, const void* v, const long* strides, void* out, float* lse,
+                    int B, int H, int Lq, int Lk, int dh, float qscale, int causal, hipStream_t stream);
+
 int vl_device_info(int device, char* arch, int arch_len, int* cus, int* clock_khz, long* hbm_bytes);
 
 /* Fused attention forward: softmax(q k^T [+ causal mask]) v without materialising the scores.
@@ -121,7 +151,9 @@ int vl_attn_fwd_bf16(const void* q, const void* k, const void* v, const long* st
  *   vl_gemm_res_rowstats_bf16  out bf16 = res + A W^T + bias (VL_EPI_RES_BF16, in place allowed) and row_part f32
  *                              [M][N/64][2] = (sum, sum of squares) of the STORED bf16 values per row and 64-column slice
  *   vl_ln_row_stats            mean / rstd [rows]: rows < m_main from row_part (P = N/64 slices, summed in slice order),
- *                              rows >= m_main from the bf16 rows themselves (the leftover rows of a row-split GEMM)
+ *                              rows >= m_main from the bf16 rows themselves (the leftover rows of a row-split GEMM); a row
+ *                              whose E[x^2] - mean^2 would cancel (variance below 1e-3 of E[x^2], |mean| > ~30 sigma) is
+ *                              also recomputed two-pass from its stored values: x_bf16 is always required
  * Whole 256x256 tiles, K >= 512, 16-byte aligned operands; anything else is refused (the caller keeps vl_layernorm_fwd +
  * vl_gemm_bf16 for it). */
 int vl_gemm_main_rows(int M, int N);

@@ -53,8 +53,10 @@ struct AttnP {
 
 // MULTI: more keys than one LDS chunk (the chunk loop restages inside the accumulation; kept out of the common
 // single-chunk instantiations, where its 12 loads in flight would push the tile loop's registers to scratch)
-template <int DH, bool TAILQ, bool MULTI>
+// F16: q, k, v and the output are IEEE half (vl_attn_fwd_f16; the frozen text tower), P is rounded to half for the P.V product
+template <int DH, bool TAILQ, bool MULTI, bool F16 = false>
 __global__ void __launch_bounds__(NWMAX * 64, DH == 128 ? 2 : 4) attn_fwd_kernel(const AttnP p) {
+  static_assert(!F16 || (!TAILQ && DH == 64), "half operands: head dim 64, no shared last row (the text tower's shape)");
   constexpr int RB = DH * 2;          // K row bytes in LDS
   constexpr int CH = RB / 16;         // 16-byte chunks per row
   constexpr int RSH = Rsh<DH>::v;     // rows per 256-B bank row = 2^RSH
@@ -111,7 +113,7 @@ __global__ void __launch_bounds__(NWMAX * 64, DH == 128 ? 2 : 4) attn_fwd_kernel
   bf16x8 qf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
-    qf[ks] = __builtin_bit_cast(bf16x8, p.qscale != 1.0f ? scale_bf16x8(qraw[ks], p.qscale) : qraw[ks]);
+    qf[ks] = __builtin_bit_cast(bf16x8, p.qscale != 1.0f ? scale_x8<F16>(qraw[ks], p.qscale) : qraw[ks]);
 
   float m_run = 0.f;               // the running maximum (valid after the first tile)
   vl_f32x2 l2 = {0.f, 0.f};        // running sum, two partial accumulators
@@ -151,9 +153,9 @@ __global__ void __launch_bounds__(NWMAX * 64, DH == 128 ? 2 : 4) attn_fwd_kernel
       bf16x8 kf[KS];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8*)(kbase + (((ks * 2 + fg) ^ ksw) * 16));
-      f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], negm, 0, 0, 0);
+      f32x16 s = mfma32<F16>(kf[0], qf[0], negm);
 #pragma unroll
-      for (int ks = 1; ks < KS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+      for (int ks = 1; ks < KS; ++ks) s = mfma32<F16>(kf[ks], qf[ks], s);
       // V^T fragments of the first 16-key slice: issued before the softmax arithmetic so that they land under it
       // (the second slice is fetched after the exponentials, into the registers the scores vacate)
       bf16x8 vf0[DT];
@@ -202,14 +204,14 @@ __global__ void __launch_bounds__(NWMAX * 64, DH == 128 ? 2 : 4) attn_fwd_kernel
 #pragma unroll
       for (int t = 0; t < DT; ++t) vf1[t] = *(const bf16x8*)(sV + (t * 32 + fr) * VSP + kt * 32 + 16 + fg * 8);
       {
-        const bf16x8 pf = pack8(pv);
+        const bf16x8 pf = pack8x<F16>(pv);
 #pragma unroll
-        for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[t], pf, o[t], 0, 0, 0);
+        for (int t = 0; t < DT; ++t) o[t] = mfma32<F16>(vf0[t], pf, o[t]);
       }
       {
-        const bf16x8 pf = pack8(pv + 8);
+        const bf16x8 pf = pack8x<F16>(pv + 8);
 #pragma unroll
-        for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[t], pf, o[t], 0, 0, 0);
+        for (int t = 0; t < DT; ++t) o[t] = mfma32<F16>(vf1[t], pf, o[t]);
       }
     }
   }
@@ -218,7 +220,7 @@ __global__ void __launch_bounds__(NWMAX * 64, DH == 128 ? 2 : 4) attn_fwd_kernel
   if (wave_active) {
     const float l_tot = xhalf_sum(l2[0] + l2[1]);
     const float inv = 1.0f / l_tot;
-    store_rows_t<DT>(o, inv, p.out + ((size_t)b * p.Lq + qrow) * (p.H * dhr) + h * dhr, fg, qidx < p.lq_main, nch);
+    store_rows_t<DT, F16>(o, inv, p.out + ((size_t)b * p.Lq + qrow) * (p.H * dhr) + h * dhr, fg, qidx < p.lq_main, nch);
     if (p.lse && fg == 0 && qidx < p.lq_main)
       p.lse[bh * p.Lq + qidx] = (m_run + __log2f(l_tot)) * 0.6931471805599453f;
   }
@@ -312,14 +314,14 @@ __global__ void __launch_bounds__(NWMAX * 64, DH == 128 ? 2 : 4) attn_fwd_kernel
 
 extern "C" int vl_set_error(const char* msg);
 
-template <int DH, bool TAILQ, bool MULTI>
+template <int DH, bool TAILQ, bool MULTI, bool F16 = false>
 static int launch_fwd(const AttnP& p, int gx, int nwq, hipStream_t stream) {
   const size_t smem = (size_t)KC * DH * 2 + (size_t)DH * VSP * 2 + (size_t)NWMAX * 32 * 4 + (size_t)(KC / 32) * (2 + DH) * 4 +
                       (size_t)DH * 2;
-  static const hipError_t attr = hipFuncSetAttribute((const void*)attn_fwd_kernel<DH, TAILQ, MULTI>,
+  static const hipError_t attr = hipFuncSetAttribute((const void*)attn_fwd_kernel<DH, TAILQ, MULTI, F16>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (attr != hipSuccess) return vl_set_error(hipGetErrorString(attr));
-  hipLaunchKernelGGL((attn_fwd_kernel<DH, TAILQ, MULTI>), dim3(gx, p.H, p.B), dim3(nwq * 64), smem, stream, p);
+  hipLaunchKernelGGL((attn_fwd_kernel<DH, TAILQ, MULTI, F16>), dim3(gx, p.H, p.B), dim3(nwq * 64), smem, stream, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : vl_set_error(hipGetErrorString(e));
 }
@@ -351,4 +353,27 @@ extern "C" int vl_attn_fwd_bf16(const void* q, const void* k, const void* v, con
          : (multi ? launch_fwd<DHV, false, true>(p, gx, nwq, stream) : launch_fwd<DHV, false, false>(p, gx, nwq, stream)))
   return dh == 64 ? VL_FWD(64) : (dh == 32 ? VL_FWD(32) : VL_FWD(128));
 #undef VL_FWD
+}
+
+// The same kernel on IEEE-half operands (q, k, v, out fp16; lse fp32): head dim 64, at most one LDS chunk of keys (288), any
+// mask mode - the frozen text tower (77 tokens, causal; open_clip/model.py:528-540, transformer.py:241-252, 870-876).
+extern "C" int vl_attn_fwd_f16(const void* q, const void* k, const void* v, const long* strides, void* out, float* lse,
+                               int B, int H, int Lq, int Lk, int dh, float qscale, int causal, hipStream_t stream) {
+  if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return vl_set_error("vl_attn_fwd_f16: empty problem");
+  if (dh != 64) return vl_set_error("vl_attn_fwd_f16: head dim must be 64");
+  if (Lk > KC) return vl_set_error("vl_attn_fwd_f16: at most 288 keys");
+  if (!strides) return vl_set_error("vl_attn_fwd_f16: strides required");
+  for (int i = 0; i < 9; ++i)
+    if (strides[i] & 7) return vl_set_error("vl_attn_fwd_f16: operand strides must be multiples of 8 elements (16-byte rows)");
+  if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) return vl_set_error("vl_attn_fwd_f16: operands must be 16-byte aligned");
+  AttnP p{TV{(const bf16_t*)q, strides[0], strides[1], strides[2]}, TV{(const bf16_t*)k, strides[3], strides[4], strides[5]},
+          TV{(const bf16_t*)v, strides[6], strides[7], strides[8]}, qscale, (bf16_t*)out, lse, B, H, Lq, Lk, causal, dh,
+#ifdef VL_ATTN_PROF
+          vl_attn_prof_buf,
+#endif
+          Lq};
+  const int qtiles = (Lq + 31) / 32;
+  const int nwq = qtiles < NWMAX ? qtiles : NWMAX;
+  const int gx = (qtiles + nwq - 1) / nwq;
+  return launch_fwd<64, false, false, true>(p, gx, nwq, stream);
 }

@@ -47,6 +47,24 @@ __device__ __forceinline__ u32x4 scale_bf16x8(u32x4 v, float s) {
   return v;
 }
 
+// The forward kernel also runs on IEEE-half operands (F16: the frozen text tower, vl_attn_fwd_f16): fragments stay raw 16-byte
+// values typed bf16x8, the three places that interpret the bits are below.
+template <bool F16>
+__device__ __forceinline__ u32x4 scale_x8(u32x4 v, float s) {
+  if constexpr (F16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = pack2h(h2f((uint16_t)(v[e] & 0xffffu)) * s, h2f((uint16_t)(v[e] >> 16)) * s);
+    return v;
+  } else {
+    return scale_bf16x8(v, s);
+  }
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // Staging of a chunk: rows [row0, row0+NR) of ONE or TWO strided [L, DH] matrices (rows >= L zero-filled) into their row
 // image and / or transposed image.  One work item = one 16-byte chunk of TWO consecutive rows (the pair becomes one
 // dword per d in the T image).  ALL the loads of a round (U items x 2 rows x up to 2 matrices = 12 x 16 bytes per
@@ -156,8 +174,9 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 // dword gives every lane whole 8-element (16-byte) pieces: 4 stores of 16 bytes instead of 16 of 8 (the forward spent
 // 50 of 222 us in its 8-byte epilogue stores).  dst = the row of lane fr (d = 0); `valid` masks padded rows.
 // npiece: number of valid 16-byte pieces per row (padded head dims store only the real columns)
-template <int DT>
+template <int DT, bool F16 = false>
 __device__ __forceinline__ void store_rows_t(const f32x16* acc, float mul, bf16_t* dst, int fg, bool valid, int npiece = 4 * DT) {
+  auto pk = [](float a, float b) { if constexpr (F16) return pack2h(a, b); else return pack2bf(a, b); };
 #pragma unroll
   for (int t = 0; t < DT; ++t)
 #pragma unroll
@@ -165,8 +184,8 @@ __device__ __forceinline__ void store_rows_t(const f32x16* acc, float mul, bf16_
       unsigned ev[2], od[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        ev[j] = pack2bf(acc[t][(2 * pp) * 4 + 2 * j] * mul, acc[t][(2 * pp) * 4 + 2 * j + 1] * mul);
-        od[j] = pack2bf(acc[t][(2 * pp + 1) * 4 + 2 * j] * mul, acc[t][(2 * pp + 1) * 4 + 2 * j + 1] * mul);
+        ev[j] = pk(acc[t][(2 * pp) * 4 + 2 * j] * mul, acc[t][(2 * pp) * 4 + 2 * j + 1] * mul);
+        od[j] = pk(acc[t][(2 * pp + 1) * 4 + 2 * j] * mul, acc[t][(2 * pp + 1) * 4 + 2 * j + 1] * mul);
       }
       auto r0 = __builtin_amdgcn_permlane32_swap(ev[0], od[0], false, false);
       auto r1 = __builtin_amdgcn_permlane32_swap(ev[1], od[1], false, false);
@@ -206,6 +225,17 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) r[e] = (__bf16)v[e];
   return r;
+}
+template <bool F16>
+__device__ __forceinline__ bf16x8 pack8x(const float* v) {
+  if constexpr (F16) {
+    f16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (_Float16)v[e];      // probabilities relative to a running maximum: <= 2^8, no clamp needed
+    return __builtin_bit_cast(bf16x8, r);
+  } else {
+    return pack8(v);
+  }
 }
 // dot product of two bf16x8 fragments in fp32
 __device__ __forceinline__ float dot8(bf16x8 a, bf16x8 b, float acc) {

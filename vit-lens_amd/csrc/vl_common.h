@@ -10,6 +10,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef uint16_t bf16_t;  // storage type for bf16 in global memory
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 #define VL_WAVE 64
 
@@ -27,6 +28,18 @@ __device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
   const vl_f32x2 v = {lo, hi};
   return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, vl_bf16x2));
 }
+
+// IEEE half (the frozen text tower's operands): round-to-nearest-even, SATURATING at the largest finite half - fp16 has five
+// exponent bits and an activation outlier must not become an infinity (bf16 shares fp32's range and needs no clamp)
+typedef __attribute__((ext_vector_type(2))) _Float16 vl_f16x2;
+__device__ __forceinline__ unsigned int pack2h(float lo, float hi) {
+  const vl_f32x2 v = {__builtin_amdgcn_fmed3f(lo, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(hi, -65504.0f, 65504.0f)};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, vl_f16x2));
+}
+__device__ __forceinline__ uint16_t f2h(float f) {
+  return __builtin_bit_cast(uint16_t, (_Float16)__builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f));
+}
+__device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -731,48 +731,21 @@ int vl_gemm_park_launch(int epi, const void* params, int ncu, hipStream_t s);
 // vl_gemm_pp.hip: the round-3 ping-pong kernel (two 4-wave workgroups per CU, 256x128 tiles, K >= 128)
 bool vl_gemm_pp_supported(int epi, const void* params);
 int vl_gemm_pp_launch(int epi, const void* params, int ncu, hipStream_t s);
-// vl_gemm_pk4.hip: EXPERIMENTAL one-wave-per-SIMD kernel (128x128 wave tiles), cfg = 14 only
-bool vl_gemm_pk4_supported(int epi, const void* params);
-int vl_gemm_pk4_launch(int epi, const void* params, int ncu, hipStream_t s);
 namespace {
-
-// Kernel selection / tuning inputs of the persistent kernels.  Read once from the environment so that one build can be
-// A/B-measured on the GPU box (tools/kernel_bench.py, bench.py); the defaults are the measured best.
-struct GemmTune { int prefer_pp, pp_delay, mfma16, pk_gn, prefer_pk4; };
-inline int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
-inline const GemmTune& gemm_tune() {
-  static const GemmTune t{env_int("VL_GEMM_PP", 0), env_int("VL_PP_DELAY", 4), env_int("VL_GEMM_MFMA16", 1), env_int("VL_GEMM_GN", 0),
-                          env_int("VL_GEMM_PK4", 0)};
-  return t;
-}
-inline GemmP tuned(const GemmP& p) {
-  GemmP q = p;
-  q.pp_delay = gemm_tune().pp_delay;
-  q.mfma16 = gemm_tune().mfma16;
-  q.pk_gn = gemm_tune().pk_gn;
-  return q;
-}
 
 // the persistent kernel for a problem whose M is a whole number of tiles: the round-3 / round-2 kernels where they apply
 template <int EPI>
 hipError_t launch_best_persist(const GemmP& p0, hipStream_t s) {
-  const GemmP p = tuned(p0);
+  const GemmP& p = p0;
   // 256x256 tiles where N allows them (fewer operand bytes per flop: the chip is power-bound on these GEMMs, DESIGN.md
   // section 7); the ping-pong kernel's 256x128 tiles take N % 256 == 128 (ViT-bigG: 1664 = 13 x 128)
-  if (gemm_tune().prefer_pp && vl_gemm_pp_supported(EPI, &p)) return (hipError_t)vl_gemm_pp_launch(EPI, &p, num_cus(), s);
-  // VL_GEMM_PK4=1 (measurement switch, default off): the experimental one-wave-per-SIMD kernel wherever it has the epilogue
-  if (gemm_tune().prefer_pk4 && vl_gemm_pk4_supported(EPI, &p)) return (hipError_t)vl_gemm_pk4_launch(EPI, &p, num_cus(), s);
   if (vl_gemm_park_supported(EPI, &p)) return (hipError_t)vl_gemm_park_launch(EPI, &p, num_cus(), s);
   if (vl_gemm_pp_supported(EPI, &p)) return (hipError_t)vl_gemm_pp_launch(EPI, &p, num_cus(), s);
   return launch_persist<EPI>(p, s);
 }
 
 template <int EPI>
-hipError_t dispatch(const GemmP& p0, int cfg, hipStream_t s) {
-  const GemmP p = tuned(p0);
+hipError_t dispatch(const GemmP& p, int cfg, hipStream_t s) {
   if (cfg == 8) {
     if (!vl_gemm_park_supported(EPI, &p)) return hipErrorInvalidValue;
     return (hipError_t)vl_gemm_park_launch(EPI, &p, num_cus(), s);
@@ -780,10 +753,6 @@ hipError_t dispatch(const GemmP& p0, int cfg, hipStream_t s) {
   if (cfg == 10) {
     if (!vl_gemm_pp_supported(EPI, &p)) return hipErrorInvalidValue;
     return (hipError_t)vl_gemm_pp_launch(EPI, &p, num_cus(), s);
-  }
-  if (cfg == 14) {      // experimental (vl_gemm_pk4.hip): explicit request only
-    if (!vl_gemm_pk4_supported(EPI, &p)) return hipErrorInvalidValue;
-    return (hipError_t)vl_gemm_pk4_launch(EPI, &p, num_cus(), s);
   }
   // cfg bit0: 0 = 256x256 tile (8 waves), 1 = 128x128 tile (4 waves); bit1: 1 = register staging
   if (cfg == 4 || cfg == 5) return launch_persist<EPI>(p, s);       // 4: historical alias
@@ -880,8 +849,8 @@ extern "C" int vl_gemm_lnfold_bf16(const void* A, const void* Wg, const float* b
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)Wg; p.bias = bias_f; p.out = out; p.out2 = out2;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.alpha = 1.0f; p.act = act; p.res_div = 1;
   p.ln_mean = ln_mean; p.ln_rstd = ln_rstd; p.ln_c = ln_c;
-  const GemmP q = tuned(p);
-  VL_CHECK_ARG(q.mfma16 && vl_gemm_park_supported(EPI_BF16, &q), "vl_gemm_lnfold_bf16: whole 256x256 tiles, K >= 512, 16-byte aligned operands required");
+  const GemmP& q = p;
+  VL_CHECK_ARG(vl_gemm_park_supported(EPI_BF16, &q), "vl_gemm_lnfold_bf16: whole 256x256 tiles, K >= 512, 16-byte aligned operands required");
   const hipError_t e = (hipError_t)vl_gemm_park_launch(EPI_BF16, &q, num_cus(), stream);
   if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
   return 0;
@@ -895,8 +864,8 @@ extern "C" int vl_gemm_res_rowstats_bf16(const void* A, const void* W, const flo
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = bias; p.out = out; p.res = res;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.alpha = 1.0f; p.res_div = 1;
   p.row_part = row_part;
-  const GemmP q = tuned(p);
-  VL_CHECK_ARG(q.mfma16 && vl_gemm_park_supported(EPI_RES_BF16, &q), "vl_gemm_res_rowstats_bf16: whole 256x256 tiles, K >= 512, 16-byte aligned operands required");
+  const GemmP& q = p;
+  VL_CHECK_ARG(vl_gemm_park_supported(EPI_RES_BF16, &q), "vl_gemm_res_rowstats_bf16: whole 256x256 tiles, K >= 512, 16-byte aligned operands required");
   const hipError_t e = (hipError_t)vl_gemm_park_launch(EPI_RES_BF16, &q, num_cus(), stream);
   if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
   return 0;
@@ -937,6 +906,24 @@ extern "C" int vl_gemm_bf16_ex(const void* A, const void* W, const float* bias, 
     case VL_EPI_DGEGLU: VL_CHECK_ARG(res, "vl_gemm_bf16: pre-activation tensor missing"); VL_CHECK_ARG((ldo & 7) == 0, "vl_gemm_bf16: DGEGLU needs ldo % 8 == 0"); e = run_gemm<EPI_DGEGLU>(p, cfg, stream); break;
     default: return vl_set_error("vl_gemm_bf16: unknown epilogue");
   }
+  if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
+  return 0;
+}
+
+// IEEE-half operands on the persistent 256x256 kernel (frozen text tower).  No other kernel family carries the type: the caller
+// pads its row count to whole tiles (zero rows cost nothing downstream) instead of this entry growing a tail path.
+extern "C" int vl_gemm_f16(const void* A, const void* W, const float* bias, void* out, const void* res, int M, int N, int K,
+                           int lda, int ldw, int ldo, float alpha, int epi, int act, hipStream_t stream) {
+  VL_CHECK_ARG(A && W && out, "vl_gemm_f16: null operand");
+  VL_CHECK_ARG(epi == VL_EPI_BF16 || epi == VL_EPI_RES_F32, "vl_gemm_f16: VL_EPI_BF16 (16-bit output, here fp16) or VL_EPI_RES_F32");
+  VL_CHECK_ARG(epi != VL_EPI_RES_F32 || (res && act == VL_ACT_NONE), "vl_gemm_f16: VL_EPI_RES_F32 needs res and takes no activation");
+  VL_CHECK_ARG(act == VL_ACT_NONE || act == VL_ACT_GELU, "vl_gemm_f16: act must be none or GELU");
+  GemmP p{};
+  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = bias; p.out = out; p.res = res;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.alpha = alpha; p.act = act; p.res_div = 1; p.f16 = 1;
+  const int e_ = epi == VL_EPI_BF16 ? (int)EPI_BF16 : (int)EPI_RES_F32;
+  VL_CHECK_ARG(vl_gemm_park_supported(e_, &p), "vl_gemm_f16: whole 256x256 tiles (M % 256 == N % 256 == 0), K % 64 == 0, K >= 512, 16-byte aligned operands required");
+  const hipError_t e = (hipError_t)vl_gemm_park_launch(e_, &p, num_cus(), stream);
   if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
   return 0;
 }
@@ -984,11 +971,8 @@ extern "C" int vl_gemm_splitk_accum_f32(const void* A, const void* W, float* out
   p.split_stride = (long)M * N;
   if (nk % splits == 0) {       // whole 256x256 tiles and equal slices: the persistent kernels write the partials
     p.ksplit_len = nk / splits;
-    p = tuned(p);
-    const bool use_pp = gemm_tune().prefer_pp && vl_gemm_pp_supported(EPI_F32, &p);
-    if (use_pp || vl_gemm_park_supported(EPI_F32, &p)) {
-      hipError_t e = use_pp ? (hipError_t)vl_gemm_pp_launch(EPI_F32, &p, num_cus(), stream)
-                            : (hipError_t)vl_gemm_park_launch(EPI_F32, &p, num_cus(), stream);
+    if (vl_gemm_park_supported(EPI_F32, &p)) {
+      hipError_t e = (hipError_t)vl_gemm_park_launch(EPI_F32, &p, num_cus(), stream);
       if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)M * (N >> 2) + 255) / 256)), dim3(256), 0, stream, ws, splits, M, N, out, ldo);
       e = hipGetLastError();

@@ -1,5 +1,5 @@
-// Shared definitions of the bf16 NT GEMM kernels (vl_gemm.hip: 8-wave tile / tail / split-K kernels,
-// vl_gemm_p4.hip: 4-wave persistent kernel with the store-hidden epilogue).
+// Shared definitions of the NT GEMM kernels (vl_gemm.hip: tile / tail / split-K kernels and the dispatcher, vl_gemm_park.hip:
+// the persistent 256x256 kernel, vl_gemm_pp.hip: 256x128 tiles, vl_gemm_tn.hip: token-major weight gradients).
 #pragma once
 #include "vl_common.h"
 #include "vitlens_hip.h"
@@ -34,11 +34,7 @@ struct GemmP {
   // partial product to out + y*split_stride (f32 elements); ksplit_len == 0 -> whole K, no offset
   int ksplit_len;
   long split_stride;
-  // kernel tuning input set by the dispatcher (not part of the C ABI): start-up phase shift of the second workgroup of a
-  // CU (vl_gemm_pp.hip, units of 4096 cycles)
-  int pp_delay;
-  int pk_gn;         // persistent kernel: N-tiles per group of the tile order (0 = the built-in 4)
-  int mfma16;        // persistent kernel: main loop on v_mfma_f32_16x16x32_bf16 (tuning input, set by the dispatcher)
+  int f16;           // operands A, W (and a 16-bit output) are IEEE half instead of bf16 (persistent 256x256 kernel only: vl_gemm_f16)
   // LayerNorm folded into the GEMM (round 4, persistent kernel only; vl_gemm_lnfold_bf16 / vl_gemm_res_rowstats_bf16):
   //   consumer: A = the RAW rows x, W = bf16(W * gamma), bias = b + W beta, ln_c[n] = sum_k W'[n, k]:
   //             out = act(rstd_m * (acc - mean_m * c_n) + bias_n)  ==  act(LN(x) W^T + b)

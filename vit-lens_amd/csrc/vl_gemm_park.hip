@@ -35,9 +35,6 @@ namespace {
 
 constexpr int PK_STAGE = 65536, PK_ABYTES = 32768;
 constexpr int PK_LDS = 2 * PK_STAGE + 32768;            // 160 KB: two operand stages + 8 x 4 KB transpose slabs
-#ifndef VL_PK_VARIANT
-#define VL_PK_VARIANT 0          // measurement builds only (tools/build_pk_variants.sh): bit 0 = MFMA order, bit 1 = static wave priority
-#endif
 constexpr int PK_GN = 8;                                 // N-tiles per group (tile order, see tile_origin; in-step A/B of 2 / 4 / 8 / 16: profiles/r04_gemm_tile_order_ab.log)
 
 // Measurement build only (tools/build_gemm_prof.sh, -DVL_GEMM_PROF): wave 0 of every workgroup adds up the shader-clock cycles
@@ -64,12 +61,16 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // ACT (EPI_BF16 only): 0 none, 1 GELU, 2 ReLU, 3 GELU with the pre-activation also written to out2 (saved for backward),
 // 4 GELU with gelu'(pre-activation) written to out2.  EPI_DGELU: ACT 4 = the aux operand is that saved gelu'.
-// M16: the main loop on `v_mfma_f32_16x16x32_bf16` (32 MFMAs of 16 384 flop per 32-deep half k-step from 8 + 4 fragments)
-// instead of `v_mfma_f32_32x32x16_bf16` (8 of 32 768 flop per 16-deep substep from 4 + 2): the same LDS traffic and
-// accumulator registers, a quarter of the accumulator read-modify-write per flop.  The board is power-limited on real
-// data: a register-only loop of the 16x16x32 instruction sustains 2087 TF/s on random-normal operands
-// against 1862 TF/s for 32x32x16 (profiles/r03b_mfma_power_probe.log).
-template <int EPI, int ACT, bool M16>
+// The main loop runs on `v_mfma_f32_16x16x32_*` (32 MFMAs of 16 384 flop per 32-deep half k-step from 8 + 4 fragments): against
+// `v_mfma_f32_32x32x16_*` (rounds 2-3a; removed in round 5 with its A/B switch) the same LDS traffic and accumulator registers,
+// a quarter of the accumulator read-modify-write per flop.  The board is power-limited on real data (profiles/
+// r05_power_trace.log: 1 400 W, 1.86 GHz through a GEMM loop): a register-only loop of the 16x16x32 instruction sustains
+// 2087 TF/s on random-normal operands against 1862 TF/s for 32x32x16 (profiles/r03b_mfma_power_probe.log).
+// F16: operands (A, W) and the 16-bit output are IEEE half instead of bf16 (`v_mfma_f32_16x16x32_f16`, same rate, same LDS
+// image; fp32 accumulation and epilogue arithmetic unchanged, the 16-bit store saturates at +-65504).  Instantiated for the
+// frozen text tower's three launches (plain, GELU, fp32 residual): three more mantissa bits on every operand bring its
+// cosine matrix to 1-2e-4 of the fp32 CPU path at ONE product per weight (two-term bf16 weights: 6-8e-4 at two).
+template <int EPI, int ACT, bool F16>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
     gemm_nt_pk_kernel(const GemmP p PK_PROF_ARG) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -80,7 +81,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   constexpr bool LNF = (EPI == EPI_BF16 && ACT >= 10 && ACT < 20);
   constexpr int ACTB = LNF ? ACT - 10 : ACT;
   constexpr bool STATS = (EPI == EPI_RES_BF16 && ACT == 20);
-  static_assert(!(LNF || STATS) || M16, "the LayerNorm-folding epilogues exist for the 16x16x32 main loop only");
+  static_assert(!F16 || ((EPI == EPI_BF16 && (ACT == 0 || ACT == 1)) || (EPI == EPI_RES_F32 && ACT == 0)),
+                "fp16 operands: plain / GELU 16-bit output and the fp32 residual epilogue only");
   // GEGLU (Perceiver feed-forward, perceiver.py:85-102): rows of W interleaved (a_j, gate_j) -> out[M, N/2] = a * gelu(gate),
   // optionally the bf16 pre-activation [M, N] to out2 (row stride 2 * ldo).  DGEGLU (its backward): acc = dy[M, N], res =
   // the saved pre-activation h[M, 2N]: out[M, 2N] = (dy * gelu(g), dy * a * gelu'(g)) interleaved (ldo = row stride of h / out).
@@ -106,15 +108,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wid & 1, wave_n = (wid >> 1) & 3;
   const bool grpB = wid >= 4;                // the second wave of each SIMD (waves w and w+4 share one)
-  const int fr = lane & 31, fg = lane >> 5;
-  const int fsw = (fr >> 1) & 7;
 
   // tile order: groups of PK_GN consecutive N-tiles, M fastest inside a group, each XCD owns a contiguous run per round
   auto tile_origin = [&](int ti, int& m0, int& n0, int& sp) {
     int v = ti * G + slot;
     sp = 0;
     if constexpr (EPI == EPI_F32) { sp = v / ntiles_mn; v -= sp * ntiles_mn; }
-    const int GN = p.pk_gn > 0 ? p.pk_gn : PK_GN;
+    constexpr int GN = PK_GN;
     const int gsz = GN * tiles_m;
     const int gid = v / gsz, rem = v - gid * gsz;
     const int first_n = gid * GN;
@@ -136,70 +136,47 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   };
 
   // ---- fragments (two sets: the reads of substep s+1 are in flight under the MFMAs of substep s) ----
-  const int fa_base = (wave_m * 128 + fr) * 128, fw_base = PK_ABYTES + (wave_n * WTN + fr) * 128;
-  bf16x8 af[2][4], wf[2][M16 ? 4 : NTL];
-  [[maybe_unused]] auto ldfrag = [&](const unsigned char* stage, int kk, int c) {
-    const int off = ((kk * 2 + fg) ^ fsw) * 16;
-#pragma unroll
-    for (int j = 0; j < NTL; ++j) wf[c][j] = *(const bf16x8*)(stage + fw_base + j * 4096 + off);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) af[c][i] = *(const bf16x8*)(stage + fa_base + i * 4096 + off);
-  };
-  [[maybe_unused]] f32x16 acc[M16 ? 1 : 4][M16 ? 1 : NTL];
-  [[maybe_unused]] auto mma = [&](int c) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < NTL; ++j)
-        acc[M16 ? 0 : i][M16 ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][j], af[c][i], acc[M16 ? 0 : i][M16 ? 0 : j], 0, 0, 0);
-  };
-  // ---- the same wave tile in 16x16 blocks: fragment = 16 rows x 32 k (lane: row lane&15, 8-wide k chunk lane>>4), A rows
+  bf16x8 af[2][4], wf[2][4];
+  // ---- the wave tile in 16x16 blocks: fragment = 16 rows x 32 k (lane: row lane&15, 8-wide k chunk lane>>4), A rows
   // mh*64 + ia*16, W rows jb*16; accumulator block [ib][jb]: lane owns output row ib*16 + (lane&15) and the four columns
   // jb*16 + (lane>>4)*4 .. +3.  Same XOR swizzle ((row>>1)&7 on the 16-byte chunk index; block bases are multiples of 16
   // rows), conflict-free in the four 16-lane groups of ds_read_b128.
   const int fr16 = lane & 15, fq = lane >> 4;
   const int fsw16 = (fr16 >> 1) & 7;
   const int fa16 = (wave_m * 128 + fr16) * 128, fw16 = PK_ABYTES + (wave_n * WTN + fr16) * 128;
-  [[maybe_unused]] f32x4 acc16[M16 ? 8 : 1][M16 ? 4 : 1];
-  [[maybe_unused]] auto ldA16 = [&](const unsigned char* stage, int h, int mh, int c) {
+  f32x4 acc16[8][4];
+  auto ldA16 = [&](const unsigned char* stage, int h, int mh, int c) {
     const int off = ((h * 4 + fq) ^ fsw16) * 16;
 #pragma unroll
     for (int ia = 0; ia < 4; ++ia) af[c][ia] = *(const bf16x8*)(stage + fa16 + (mh * 4 + ia) * 2048 + off);
   };
-  [[maybe_unused]] auto ldW16 = [&](const unsigned char* stage, int h, int c, auto J0, auto J1) {
+  auto ldW16 = [&](const unsigned char* stage, int h, int c, auto J0, auto J1) {
     const int off = ((h * 4 + fq) ^ fsw16) * 16;
 #pragma unroll
-    for (int jb = decltype(J0)::value; jb < decltype(J1)::value; ++jb) wf[c][M16 ? jb : 0] = *(const bf16x8*)(stage + fw16 + jb * 2048 + off);
+    for (int jb = decltype(J0)::value; jb < decltype(J1)::value; ++jb) wf[c][jb] = *(const bf16x8*)(stage + fw16 + jb * 2048 + off);
   };
-  [[maybe_unused]] auto mma16 = [&](auto MH, int ca, int cw) {
+  auto mma16 = [&](auto MH, int ca, int cw) {
     constexpr int mh = decltype(MH)::value;
 #pragma unroll
     for (int o = 0; o < 4; ++o)
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        const int jb = (VL_PK_VARIANT & 1) ? n : o, ia = (VL_PK_VARIANT & 1) ? o : n;
-        acc16[M16 ? mh * 4 + ia : 0][M16 ? jb : 0] =
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cw][M16 ? jb : 0], af[ca][ia], acc16[M16 ? mh * 4 + ia : 0][M16 ? jb : 0], 0, 0, 0);
+        const int jb = o, ia = n;      // (W-fragment-outer order; A-outer and a static s_setprio for waves 4-7 measured equal, profiles/r03e_*)
+        if constexpr (F16)
+          acc16[mh * 4 + ia][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[cw][jb]), __builtin_bit_cast(f16x8, af[ca][ia]),
+                                                                          acc16[mh * 4 + ia][jb], 0, 0, 0);
+        else
+          acc16[mh * 4 + ia][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cw][jb], af[ca][ia], acc16[mh * 4 + ia][jb], 0, 0, 0);
       }
   };
   auto first_frags = [&](const unsigned char* stage) {       // fragments of a stage's first phase
-    if constexpr (M16) { ldA16(stage, 0, 0, 0); ldW16(stage, 0, 0, IC<0>{}, IC<4>{}); }
-    else ldfrag(stage, 0, 0);
+    ldA16(stage, 0, 0, 0); ldW16(stage, 0, 0, IC<0>{}, IC<4>{});
   };
   auto zero_acc = [&]() {
-    if constexpr (M16) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NTL; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    }
+      for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
   // ---- epilogue operands ----
@@ -284,9 +261,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   dma_step(smem + PK_STAGE);                     // nk >= 8: still inside tile 0
   dma_wait_and_barrier();
   first_frags(smem);
-#if VL_PK_VARIANT & 2
-  if (grpB) __builtin_amdgcn_s_setprio(1);       // the second-dispatched half loses every VALU / issue arbitration (MI355X guide, pairing rule 4)
-#endif
 
   int par = 0;                                   // stage buffer of the k-step being computed
   bool pendB = false;                            // group B: a DMA batch is due at the top of the next k-step
@@ -297,40 +271,22 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     unsigned char* oth = smem + (par ^ 1) * PK_STAGE;
     if (grpB && pendB) { dma_step(oth); pendB = false; }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (M16) {
-      // four phases of 16 MFMAs: (k half 0, rows 0-63) (0, 64-127) (1, 0-63) (1, 64-127); W fragments of a half stay for both
-      ldA16(cur, 0, 1, 1); ldW16(cur, 1, 1, IC<0>{}, IC<2>{});
-      mma16(IC<0>{}, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      ldA16(cur, 1, 0, 0); ldW16(cur, 1, 1, IC<2>{}, IC<4>{});
-      mma16(IC<1>{}, 1, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      ldA16(cur, 1, 1, 1);
-      mma16(IC<0>{}, 0, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (after_epi) { first_wait_and_barrier(); after_epi = false; } else dma_wait_and_barrier();
-      // (at the last k-step of a tile BOTH wave groups issue at once: the batch must sit in front of the epilogue's stores)
-      if (dti < my_tiles) { if (!grpB || last) dma_step(cur); else pendB = true; }
-      if constexpr (!last) first_frags(oth);
-      __builtin_amdgcn_sched_barrier(0);
-      mma16(IC<1>{}, 1, 1);
-    } else {
-    ldfrag(cur, 1, 1);
-    mma(0);
+    // four phases of 16 MFMAs: (k half 0, rows 0-63) (0, 64-127) (1, 0-63) (1, 64-127); W fragments of a half stay for both
+    ldA16(cur, 0, 1, 1); ldW16(cur, 1, 1, IC<0>{}, IC<2>{});
+    mma16(IC<0>{}, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    ldfrag(cur, 2, 0);
-    mma(1);
+    ldA16(cur, 1, 0, 0); ldW16(cur, 1, 1, IC<2>{}, IC<4>{});
+    mma16(IC<1>{}, 1, 0);
     __builtin_amdgcn_sched_barrier(0);
-    ldfrag(cur, 3, 1);
-    mma(0);
+    ldA16(cur, 1, 1, 1);
+    mma16(IC<0>{}, 0, 1);
     __builtin_amdgcn_sched_barrier(0);
-    // every wave holds its last fragments of `cur`; the DMA of the next k-step (issued 0.5 - 1 k-step ago) has landed
     if (after_epi) { first_wait_and_barrier(); after_epi = false; } else dma_wait_and_barrier();
+    // (at the last k-step of a tile BOTH wave groups issue at once: the batch must sit in front of the epilogue's stores)
     if (dti < my_tiles) { if (!grpB || last) dma_step(cur); else pendB = true; }
-    if constexpr (!last) ldfrag(oth, 0, 0);      // (at a tile boundary the fragments would sit in registers through the epilogue)
+    if constexpr (!last) first_frags(oth);
     __builtin_amdgcn_sched_barrier(0);
-    mma(1);
-    }
+    mma16(IC<1>{}, 1, 1);
     __builtin_amdgcn_sched_barrier(0);
     par ^= 1;
   };
@@ -356,13 +312,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       asm volatile("" : "+v"(el));
       prow = el >> 3; pcol = (el & 7) * 8;
       lo_out = (unsigned)((prow * pe.ldo + pcol) * 2);
-      [[maybe_unused]] const int fr = el & 31, fg = el >> 5, fr16 = el & 15, fq = el >> 4;      // shadow the main loop's copies
+      const int fr16 = el & 15, fq = el >> 4;      // shadow the main loop's copies
       if constexpr (HAS_AUX) {
         load_block(IC<0>{});
       }
       unsigned char* const slab = smem + 2 * PK_STAGE + wid * SLAB;
-      unsigned char* const wr = slab + fr * 128 + fg * 8;
-      const int wsw = fr & 7;
       // branch-free optional bias: read SOMETHING valid (the weight matrix) and select zero
       const bool has_bias = pe.bias != nullptr;
       const float* const bsrc = has_bias ? pe.bias : (const float*)pe.W;
@@ -371,17 +325,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       // covers the output STORES issued just before, so every row block first waited for the previous block's stores to
       // reach memory and then paid eight serial L2 round trips.  tools/gemm_phase_prof.py: the plain epilogue took 10.4 k
       // cycles per 256x256 tile (21 % of a K = 1024 launch) with ~0.8 k cycles of VALU work in it.
-      // (the 32x32x16 A/B build of the loop, M16 = false, has eight column groups per lane and no registers for them: it keeps
-      //  loading the bias where it is used - measurement path only, VL_GEMM_MFMA16=0)
       [[maybe_unused]] f32x4 bvq[4];
-      auto bias_at = [&](int n) {
-        f32x4 b = *(const f32x4*)(bsrc + n);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) b[e] = has_bias ? b[e] : 0.f;
-        return b;
-      };
-#pragma unroll
-      for (int c = 0; c < (M16 ? 4 : 0); ++c) {
+      for (int c = 0; c < 4; ++c) {
         const int n = ncol0 + c * 16 + fq * 4;
         if constexpr (IS_DGEGLU) {                 // (never has a bias: vl_gemm_park_supported)
           bvq[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -440,26 +386,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
               for (int pass = 0; pass < 4; ++pass)
                 rr[pass] = *(const f32x4*)(rin + (size_t)(i * 32 + pass * 8 + prow) * pe.ldo + j * 32 + (el & 7) * 4);
             }
-            if constexpr (M16) {
 #pragma unroll
-              for (int ibh = 0; ibh < 2; ++ibh)
+            for (int ibh = 0; ibh < 2; ++ibh)
 #pragma unroll
-                for (int jbh = 0; jbh < 2; ++jbh) {
-                  const int row = ibh * 16 + fr16;
-                  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                  if constexpr (EPI == EPI_RES_F32) bv = bvq[M16 ? j * 2 + jbh : 0];
-                  *(f32x4*)(slab + row * 128 + (((jbh * 4 + fq) ^ (row & 7)) << 4)) =
-                      scale_bias(acc16[M16 ? i * 2 + ibh : 0][M16 ? j * 2 + jbh : 0], pe.alpha, bv);
-                }
-            } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              f32x4 v = {acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 0], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 1], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 2], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 3]};
-              f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-              if constexpr (EPI == EPI_RES_F32) bv = bias_at(ncol0 + j * 32 + q * 8 + fg * 4);
-              *(f32x4*)(slab + fr * 128 + (((q * 2 + fg) ^ wsw) << 4)) = scale_bias(v, pe.alpha, bv);
-            }
-            }
+              for (int jbh = 0; jbh < 2; ++jbh) {
+                const int row = ibh * 16 + fr16;
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (EPI == EPI_RES_F32) bv = bvq[j * 2 + jbh];
+                *(f32x4*)(slab + row * 128 + (((jbh * 4 + fq) ^ (row & 7)) << 4)) = scale_bias(acc16[i * 2 + ibh][j * 2 + jbh], pe.alpha, bv);
+              }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
@@ -479,17 +414,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int j = 0; j < NTL; ++j) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            // 32x32 blocks: (j, q) = column block, 8-column group; 16x16 blocks: (j, q) = (row half ibh, column block jb)
-            f32x4 v;
-            if constexpr (M16) v = acc16[M16 ? i * 2 + j : 0][M16 ? q : 0];
-            else v = f32x4{acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 0], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 1], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 2], acc[M16 ? 0 : i][M16 ? 0 : j][q * 4 + 3]};
+            // (j, q) = (16-row half, 16-column block) of the 32 x 64 row block
+            f32x4 v = acc16[i * 2 + j][q];
             if constexpr (LNF) {
               // rstd * acc + (bias - mean * rstd * c): two FMAs per value (alpha is 1 on this path)
 #pragma unroll
               for (int e = 0; e < 4; ++e)
-                v[e] = __builtin_fmaf(ln_r[i * 2 + j], v[e], __builtin_fmaf(ln_nm[i * 2 + j], cvq[M16 ? q : 0][e], bvq[M16 ? q : 0][e]));
+                v[e] = __builtin_fmaf(ln_r[i * 2 + j], v[e], __builtin_fmaf(ln_nm[i * 2 + j], cvq[q][e], bvq[q][e]));
             } else {
-              v = scale_bias(v, pe.alpha, M16 ? bvq[M16 ? q : 0] : bias_at(ncol0 + j * 32 + q * 8 + fg * 4));
+              v = scale_bias(v, pe.alpha, bvq[q]);
             }
             if constexpr (EPI == EPI_BF16 && ACTB == 1) {
 #pragma unroll
@@ -498,13 +431,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-            if constexpr (M16) {
-              const int row = j * 16 + fr16;
-              *(u32x2*)(slab + row * 128 + (((q * 2 + (fq >> 1)) ^ (row & 7)) << 4) + (fq & 1) * 8) = o;
-            } else {
-              *(u32x2*)(wr + (((j * 4 + q) ^ wsw) << 4)) = o;
-            }
+            u32x2 o;
+            if constexpr (F16) { o[0] = pack2h(v[0], v[1]); o[1] = pack2h(v[2], v[3]); }
+            else { o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]); }
+            const int row = j * 16 + fr16;
+            *(u32x2*)(slab + row * 128 + (((q * 2 + (fq >> 1)) ^ (row & 7)) << 4) + (fq & 1) * 8) = o;
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -617,9 +548,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
 }
 
-template <int EPI, int ACT, bool M16>
-hipError_t launch_pk_v(const GemmP& p, int ncu, hipStream_t s) {
-  auto kern = gemm_nt_pk_kernel<EPI, ACT, M16>;
+template <int EPI, int ACT, bool F16 = false>
+hipError_t launch_pk(const GemmP& p, int ncu, hipStream_t s) {
+  auto kern = gemm_nt_pk_kernel<EPI, ACT, F16>;
   static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PK_LDS);   // thread-safe one-time init
   if (attr != hipSuccess) return attr;
   const int tiles = (p.M >> 8) * (p.N >> 8) * ((EPI == EPI_F32 && p.ksplit_len) ? (p.K >> 6) / p.ksplit_len : 1);
@@ -627,11 +558,6 @@ hipError_t launch_pk_v(const GemmP& p, int ncu, hipStream_t s) {
   if (tiles < G) G = (tiles + 7) & ~7;
   hipLaunchKernelGGL(kern, dim3(G), dim3(512), PK_LDS, s, p PK_PROF_PASS);
   return hipGetLastError();
-}
-
-template <int EPI, int ACT>
-hipError_t launch_pk(const GemmP& p, int ncu, hipStream_t s) {
-  return p.mfma16 ? launch_pk_v<EPI, ACT, true>(p, ncu, s) : launch_pk_v<EPI, ACT, false>(p, ncu, s);
 }
 
 }  // namespace
@@ -668,19 +594,25 @@ bool vl_gemm_park_supported(int epi, const void* params) {
 
 int vl_gemm_park_launch(int epi, const void* params, int ncu, hipStream_t s) {
   const GemmP& p = *(const GemmP*)params;
+  if (p.f16) {                // IEEE-half operands (vl_gemm_f16): the frozen text tower's three launches
+    if (p.ln_mean || p.row_part || p.out2) return (int)hipErrorInvalidValue;
+    if (epi == EPI_BF16 && p.act == 0) return (int)launch_pk<EPI_BF16, 0, true>(p, ncu, s);
+    if (epi == EPI_BF16 && p.act == 1) return (int)launch_pk<EPI_BF16, 1, true>(p, ncu, s);
+    if (epi == EPI_RES_F32) return (int)launch_pk<EPI_RES_F32, 0, true>(p, ncu, s);
+    return (int)hipErrorInvalidValue;
+  }
   switch (epi) {
     case EPI_BF16:
       if (p.ln_mean) {        // LayerNorm folded into the epilogue (vl_gemm_lnfold_bf16 checked the rest)
-        if (!p.mfma16) return (int)hipErrorInvalidValue;
-        if (p.act == 1) return (int)launch_pk_v<EPI_BF16, 11, true>(p, ncu, s);
-        if (p.act == 4) return (int)launch_pk_v<EPI_BF16, 14, true>(p, ncu, s);
-        return p.act == 0 ? (int)launch_pk_v<EPI_BF16, 10, true>(p, ncu, s) : (int)hipErrorInvalidValue;
+        if (p.act == 1) return (int)launch_pk<EPI_BF16, 11>(p, ncu, s);
+        if (p.act == 4) return (int)launch_pk<EPI_BF16, 14>(p, ncu, s);
+        return p.act == 0 ? (int)launch_pk<EPI_BF16, 10>(p, ncu, s) : (int)hipErrorInvalidValue;
       }
       if (p.act == 1) return p.out2 ? (int)launch_pk<EPI_BF16, 3>(p, ncu, s) : (int)launch_pk<EPI_BF16, 1>(p, ncu, s);
       if (p.act == 4) return (int)launch_pk<EPI_BF16, 4>(p, ncu, s);
       return p.act == 2 ? (int)launch_pk<EPI_BF16, 2>(p, ncu, s) : (int)launch_pk<EPI_BF16, 0>(p, ncu, s);
     case EPI_RES_BF16:
-      if (p.row_part) return p.mfma16 ? (int)launch_pk_v<EPI_RES_BF16, 20, true>(p, ncu, s) : (int)hipErrorInvalidValue;
+      if (p.row_part) return (int)launch_pk<EPI_RES_BF16, 20>(p, ncu, s);
       return (int)launch_pk<EPI_RES_BF16, 0>(p, ncu, s);
     case EPI_DGELU: return p.act == 4 ? (int)launch_pk<EPI_DGELU, 4>(p, ncu, s) : (int)launch_pk<EPI_DGELU, 0>(p, ncu, s);
     case EPI_GEGLU: return (int)launch_pk<EPI_GEGLU, 0>(p, ncu, s);

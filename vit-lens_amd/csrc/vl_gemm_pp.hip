@@ -72,11 +72,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 
   // Start-up phase shift: the workgroup whose waves sit in the odd wave slot of their SIMD (the second one dispatched to
   // this CU) waits ~one epilogue before its first tile, so the two workgroups' epilogues never coincide.  Speed only.
-  if (p.pp_delay > 0) {
+  {
+    constexpr int PP_DELAY = 4;      // x 4096 cycles (0 / 2 / 4 / 8 measured: 0.695 / 0.684 / 0.677 / 0.705 ms on the c_fc shape, round 3)
     unsigned hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hw));
     if (hw & 1)
-      for (int i = 0; i < p.pp_delay; ++i) __builtin_amdgcn_s_sleep(64);      // 64 x 64 cycles
+      for (int i = 0; i < PP_DELAY; ++i) __builtin_amdgcn_s_sleep(64);      // 64 x 64 cycles
   }
 
   // tile order: groups of PP_GN consecutive N-tiles, each XCD owns a contiguous run per round

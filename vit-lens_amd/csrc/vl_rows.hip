@@ -26,6 +26,11 @@ __device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
 __device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
   u32x2 t; t[0] = pack2bf(v[0], v[1]); t[1] = pack2bf(v[2], v[3]); *(u32x2*)p = t;
 }
+struct f16_t { uint16_t v; };      // IEEE-half output rows (the frozen text tower's GEMM inputs)
+__device__ __forceinline__ void store4(f16_t* p, const float (&v)[4]) {
+  u32x2 t; t[0] = pack2h(v[0], v[1]); t[1] = pack2h(v[2], v[3]); *(u32x2*)p = t;
+}
+__device__ __forceinline__ void store1(f16_t* p, float v) { p->v = f2h(v); }
 __device__ __forceinline__ float load1(const float* p) { return *p; }
 __device__ __forceinline__ float load1(const bf16_t* p) { return bf2f(*p); }
 __device__ __forceinline__ void store1(float* p, float v) { *p = v; }
@@ -153,6 +158,7 @@ hipError_t ln_launch(const LnP& p, hipStream_t s) {
 
 template <int MODE>
 hipError_t ln_dispatch(const LnP& p, int in_dt, int out_dt, hipStream_t s) {
+  if (in_dt == VL_F32 && out_dt == VL_F16) return ln_launch<float, f16_t, MODE>(p, s);
   if (in_dt == VL_F32 && out_dt == VL_BF16) return ln_launch<float, bf16_t, MODE>(p, s);
   if (in_dt == VL_BF16 && out_dt == VL_BF16) return ln_launch<bf16_t, bf16_t, MODE>(p, s);
   if (in_dt == VL_F32 && out_dt == VL_F32) return ln_launch<float, float, MODE>(p, s);
@@ -265,8 +271,21 @@ __global__ void __launch_bounds__(256) row_stats_kernel(const float* part, int P
     const vl_f32x2* pp = (const vl_f32x2*)part + (size_t)row * P;
     float s1 = 0.f, s2 = 0.f;
     for (int i = 0; i < P; ++i) { const vl_f32x2 v = pp[i]; s1 += v[0]; s2 += v[1]; }
-    const float mu = s1 * invD;
-    const float var = fmaxf(fmaf(-mu, mu, s2 * invD), 0.f);
+    float mu = s1 * invD;
+    const float ex2 = s2 * invD;
+    float var = fmaxf(fmaf(-mu, mu, ex2), 0.f);
+    // E[x^2] - mean^2 in fp32 loses log2(E[x^2] / var) bits: a row whose mean dwarfs its spread (|mean| > ~30 sigma) would get
+    // a variance made of rounding noise, clamped to 0 at worst.  Such a row takes the two-pass formula on the stored values,
+    // exactly as the leftover rows below do (one thread walks the row: rare, and correct beats fast here)
+    if (var < 1e-3f * ex2) {
+      const bf16_t* xr = x + (size_t)row * xs;
+      float s = 0.f;
+      for (int e = 0; e < D; ++e) s += bf2f(xr[e]);
+      mu = s * invD;
+      float q = 0.f;
+      for (int e = 0; e < D; ++e) { const float d = bf2f(xr[e]) - mu; q = fmaf(d, d, q); }
+      var = q * invD;
+    }
     mean[row] = mu; rstd[row] = rsqrtf(var + eps);
     return;
   }
@@ -290,7 +309,7 @@ extern "C" int vl_ln_row_stats(const float* row_part, int P, const void* x_bf16,
   if (m_main > 0 && (!row_part || P <= 0 || (((uintptr_t)row_part) & 7))) return vl_set_error("vl_ln_row_stats: partial statistics missing");
   if (m_main > 0 && P * 64 != D) return vl_set_error("vl_ln_row_stats: P must be D / 64 (one partial pair per 64-column slice of the row)");
   if (!mean || !rstd) return vl_set_error("vl_ln_row_stats: outputs missing");
-  if (m_main < rows && !x_bf16) return vl_set_error("vl_ln_row_stats: rows missing");
+  if (!x_bf16) return vl_set_error("vl_ln_row_stats: rows missing (the leftover rows and ill-conditioned rows are read from them)");
   const int nb = ((m_main + 255) >> 8) + (rows - m_main + 3) / 4;
   hipLaunchKernelGGL(row_stats_kernel, dim3(nb), dim3(256), 0, stream, row_part, P, (const bf16_t*)x_bf16, x_row_stride, D, m_main,
                      rows, eps, mean, rstd);

@@ -93,8 +93,8 @@ def tri_create_model(model_name: str, pretrained: Optional[str] = None, precisio
                      force_custom_text: bool = False, force_patch_dropout: Optional[float] = None,
                      force_image_size=None, pretrained_image: bool = False, pretrained_hf: bool = True,
                      cache_dir: Optional[str] = None, output_dict: Optional[bool] = None,
-                     require_pretrained: bool = False, strict: bool = False, args=None, text_wsplit: bool = True):
-    """text_wsplit (appended to the reference's signature, factory.py:164): see TriCLIP.set_precision."""
+                     require_pretrained: bool = False, strict: bool = False, args=None, text_arith: str = "f16"):
+    """text_arith (appended to the reference's signature, factory.py:164): see TriCLIP.set_precision."""
     model_name = model_name.replace("/", "-")
     cfg = get_model_config(model_name)
     if cfg is None:
@@ -114,7 +114,7 @@ def tri_create_model(model_name: str, pretrained: Optional[str] = None, precisio
         v["visual_arch"] = getattr(args, "visual_arch", "perceiver_vit")
         v["exp_args"] = args
     model = TriCLIP(**cfg)
-    model.set_precision(precision, text_wsplit=text_wsplit)
+    model.set_precision(precision, text_arith=text_arith)
     model.to(device=torch.device(device))
     if pretrained:
         if not os.path.exists(pretrained):

@@ -579,28 +579,30 @@ class TriCLIP(nn.Module):
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
         self._text_engine, self._text_key = None, None
         self._res_dtype = torch.float32
-        self._text_wsplit = True
+        self._text_arith = "f16"
 
-    def set_precision(self, precision: str, text_wsplit: bool = True):
-        """`precision` of tri_create_model (factory.py:164): the GEMMs always run bf16 x bf16 -> f32 (what the reference's
-        amp_bf16 autocast computes); "fp32" keeps the residual stream and its gradient in f32 (more precise than the
-        reference's autocast), "amp" / "amp_bf16" / "bf16" carry them in bf16 exactly as autocast does.
-        text_wsplit (default on): the TEXT tower's weights as the sum of two bf16 terms on an fp32 residual stream - more
-        precise than the reference's autocast, needed for the 1e-3 bound on its cosine matrix; off = the
-        reference's amp_bf16 arithmetic for the text tower as well (half the text GEMM flops)."""
+    def set_precision(self, precision: str, text_arith: str = "f16"):
+        """`precision` of tri_create_model (factory.py:164): the GEMMs always run on 16-bit operands with fp32 accumulation
+        (what the reference's amp_bf16 autocast computes); "fp32" keeps the residual stream and its gradient in f32 (more
+        precise than the reference's autocast), "amp" / "amp_bf16" / "bf16" carry them in bf16 exactly as autocast does.
+        text_arith: operands of the frozen TEXT tower (vitlens_hip.engine.TextEngine): "f16" (default) IEEE half on an fp32
+        residual stream - what holds its cosine matrix within 1e-3 of the fp32 CPU path (1-2e-4) at the bf16 rate; "bf16x2"
+        two-term bf16 weights (round 4: 6-8e-4 at twice the flops); "bf16" the reference's amp_bf16 arithmetic (0.8-1.9e-3)."""
         import warnings
         dt = torch.float32 if precision == "fp32" else torch.bfloat16
         self._res_dtype = self.image.res_dtype = self.visual.res_dtype = dt
-        self._text_wsplit = bool(text_wsplit)
+        if text_arith not in ("f16", "bf16x2", "bf16"):
+            raise ValueError(f"text_arith must be 'f16', 'bf16x2' or 'bf16', got {text_arith!r}")
+        self._text_arith = text_arith
         self._text_engine = None
         # what actually runs, stated where the caller asked for something else (reference: factory.py:260-295 converts the
         # model / sets up autocast; training/precision.py:5-12)
         self.precision_requested = precision
+        text = {"f16": "fp16 x fp16 -> fp32, residual stream fp32 (falls back to two-term bf16 weights where the width is not a multiple of 256)",
+                "bf16x2": "two-term bf16 weights x bf16 activations -> fp32, residual stream fp32",
+                "bf16": "bf16 x bf16 -> fp32, residual stream " + ("fp32" if dt == torch.float32 else "bf16")}[text_arith]
         self.precision_effective = ("image / modality towers: bf16 x bf16 -> fp32 matrix products, residual stream "
-                                    + ("fp32" if dt == torch.float32 else "bf16")
-                                    + "; text tower: " + ("two-term bf16 weights x bf16 activations -> fp32, residual stream fp32"
-                                                          if self._text_wsplit else
-                                                          "bf16 x bf16 -> fp32, residual stream " + ("fp32" if dt == torch.float32 else "bf16"))
+                                    + ("fp32" if dt == torch.float32 else "bf16") + "; text tower: " + text
                                     + "; LayerNorm / softmax statistics, features, logits, loss in fp32")
         if precision == "fp32":
             warnings.warn("precision='fp32': the MI355X path has no fp32-arithmetic mode - matrix products take bf16 operands with "
@@ -640,14 +642,14 @@ class TriCLIP(nn.Module):
         # (logit_scale is not a text-tower operand: it changes every step and must not invalidate the frozen tower's engine)
         prm = dict(self.named_parameters())
         names = [n for n in prm if not n.startswith(("image.", "visual.")) and n != "logit_scale"]
-        key = (str(dev), self._res_dtype, self._text_wsplit, tuple(prm[n]._version for n in names))
+        key = (str(dev), self._res_dtype, self._text_arith, tuple(prm[n]._version for n in names))
         if self._text_engine is None or key != self._text_key:
             sd = {k: v for k, v in self.state_dict().items() if not k.startswith(("image.", "visual."))}
             t = self.text_cfg
             self._text_engine = E.TextEngine(sd, E.TextCfg(context_length=t.context_length, vocab_size=t.vocab_size,
                                                            width=t.width, heads=t.heads, layers=t.layers,
                                                            embed_dim=self.text_projection.shape[1]), dev, res_dtype=self._res_dtype,
-                                                wsplit=self._text_wsplit)
+                                                arith=self._text_arith)
             self._text_key = key
         return self._text_engine
 

@@ -118,15 +118,17 @@ class _Workspace:
         self.part = torch.empty(B * L * (D // 64) * 2, device=device, dtype=torch.float32) if D % 64 == 0 else None
 
 
-# LayerNorm folding is OPT-IN (VL_LN_FOLD=1, bench.py --ln-fold on): measured +0.25 % on the C3 step (DESIGN.md 7.4 - the chip is
-# power-limited, the time of the removed passes comes back as lower GEMM clocks), i.e. inside the spread between boxes, and every
-# full-size parity bound of tests/ was established on the separate passes
-LN_FOLD = os.environ.get("VL_LN_FOLD", "0") != "0"
+# LayerNorm folding is ON by default since round 5 (the whole GPU suite is green with it: profiles/r05_pytest_gpu_lnfold_on_*.log;
+# it takes 88 of 96 LayerNorm passes and 270 MB of HBM traffic out of a frozen ViT-L micro-batch; +0.25 % on the C3 step - the
+# chip is power-limited and gives most of the removed time back as lower GEMM clocks).  A module attribute,
+# not an environment variable: `engine.LN_FOLD = False` (or `fold=False` on run_blocks, `bench.py --ln-fold off`) selects the
+# separate LayerNorm passes; engines read it when they are built and when they run.
+LN_FOLD = True
 
 
 def run_blocks(blocks, ws: _Workspace, B, L, D, H, causal=False, cfg=-1, fold=None):
     """x (ws.x, residual stream) <- N pre-LN transformer blocks (transformer.py:254-272, 364-371).
-    fold (default: the VL_LN_FOLD switch, bf16 stream only): the LayerNorms folded into the GEMMs either side of them - ln_1 / ln_2 are never
+    fold (default: engine.LN_FOLD, bf16 stream only): the LayerNorms folded into the GEMMs either side of them - ln_1 / ln_2 are never
     materialised, the in-projection and c_fc read the residual rows and apply (mean, rstd) in their epilogues, the
     out-projection and c_proj leave the partial row sums of what they store (ops.gemm_lnfold / gemm_res_rowstats)."""
     dh = D // H
@@ -271,43 +273,117 @@ class VitEngine:
         return ops.l2_normalize(f) if normalize else f
 
 
+def prep_block_f16(sd: Dict[str, torch.Tensor], p: str, device) -> Dict[str, torch.Tensor]:
+    """One ResidualAttentionBlock with IEEE-half GEMM weights (`TextEngine(arith="f16")`): LayerNorm parameters and biases f32."""
+    hf = torch.float16
+    return {
+        "ln1_w": _dev(sd[p + "ln_1.weight"], device), "ln1_b": _dev(sd[p + "ln_1.bias"], device),
+        "in_w": _dev(sd[p + "attn.in_proj_weight"], device, hf), "in_b": _dev(sd[p + "attn.in_proj_bias"], device),
+        "out_w": _dev(sd[p + "attn.out_proj.weight"], device, hf), "out_b": _dev(sd[p + "attn.out_proj.bias"], device),
+        "ln2_w": _dev(sd[p + "ln_2.weight"], device), "ln2_b": _dev(sd[p + "ln_2.bias"], device),
+        "fc_w": _dev(sd[p + "mlp.c_fc.weight"], device, hf), "fc_b": _dev(sd[p + "mlp.c_fc.bias"], device),
+        "proj_w": _dev(sd[p + "mlp.c_proj.weight"], device, hf), "proj_b": _dev(sd[p + "mlp.c_proj.bias"], device),
+    }
+
+
+class _WorkspaceF16:
+    """Activations of the fp16 text tower.  Rows are padded to whole 256-row tiles (vl_gemm_f16 is the persistent kernel
+    only); the padded rows are zero GEMM inputs, never normalised, never read by the attention or the pooling."""
+
+    def __init__(self, B, L, D, H, device):
+        hf = torch.float16
+        self.rows = B * L
+        self.Mp = (self.rows + 255) // 256 * 256
+        self.Bp = (B + 255) // 256 * 256
+        z = lambda *shape, dt=hf: torch.zeros(*shape, device=device, dtype=dt)
+        self.x = z(self.Mp, D, dt=torch.float32)
+        self.h, self.qkv, self.a, self.hid = z(self.Mp, D), z(self.Mp, 3 * D), z(self.Mp, D), z(self.Mp, 4 * D)
+        dh = D // H
+        hv = lambda i: ops.heads_view(self.qkv, B, L, H, dh, i * D)
+        self.q, self.k, self.v = hv(0), hv(1), hv(2)
+        self.pooled = z(self.Bp, D)
+
+
 class TextEngine:
     """TriCLIP.encode_text (model.py:528-540): embedding + causal transformer + ln_final + EOT + proj.
 
-    wsplit=True (the default): every weight of the tower is the sum of TWO bf16 terms and the residual stream is fp32 whatever
-    `res_dtype` says.  Why only here: random-init (and trained) text features share a large common component - mutual cosine
-    ~0.6 - which amplifies operand rounding in the cosine-similarity MATRIX; with plain bf16 weights that matrix is off by
-    1.3-1.5e-3 from the fp32 CPU path (the reference's own amp_bf16 forward: 1.4e-3), above the 1e-3 of BASELINE.json's
-    north_star.  Emulated on the CPU per rounding point: weights 4.6e-4, GEMM input activations 5.0e-4,
-    bf16 stores 5.7e-4, attention internals 2.2e-4 taken alone; two-term weights bring the whole tower to 5.5-9.3e-4.  Cost:
-    the tower's GEMM flops double (K-concatenated [hi | lo] for the in-projection and c_fc, two accumulating launches for
-    the residual projections) = +2.5 % of the C3 step's arithmetic.  wsplit=False is the reference's amp_bf16 arithmetic."""
+    The tower is frozen in every recipe (forward only) and its cosine-similarity MATRIX amplifies operand rounding: random-init
+    (and trained) text features share a mutual cosine of ~0.6, so with bf16 operands - the reference's amp_bf16 arithmetic -
+    that matrix is 0.8-1.9e-3 from the fp32 CPU path (the reference's own amp_bf16 forward: 1.4e-3), above the 1e-3 of
+    BASELINE.json's north_star.  CPU emulation per rounding point: weights 4.6e-4, GEMM input
+    activations 5.0e-4, 16-bit stores 5.7e-4, attention internals 2.2e-4 taken alone.  `arith` selects the operands:
+      "f16"    (default, round 5) every GEMM / attention operand IEEE half, fp32 residual stream, fp32 accumulation: three
+               more mantissa bits on ALL four sources at the bf16 MFMA rate - 1.3-2.0e-4 emulated on four seeds.  (The
+               reference converts CLIP to fp16 itself: convert_weights_to_fp16, model.py:393-419.)  Needs head dim 64 and a
+               width that is a multiple of 256 (every CLIP text tower); otherwise falls back to "bf16x2"
+      "bf16x2" (round 4) weights as the sum of TWO bf16 terms, fp32 residual stream: 6.1-8.1e-4 measured at twice the GEMM
+               flops and twice the LayerNorm passes (+17 ms per C3 step)
+      "bf16"   the reference's amp_bf16 arithmetic."""
 
-    def __init__(self, sd, cfg: TextCfg, device, res_dtype=torch.float32, gemm_cfg: int = -1, wsplit: bool = True):
+    def __init__(self, sd, cfg: TextCfg, device, res_dtype=torch.float32, gemm_cfg: int = -1, wsplit: Optional[bool] = None,
+                 arith: str = "f16"):
         self.cfg, self.device, self.gemm_cfg = cfg, torch.device(device), gemm_cfg
-        self.wsplit = bool(wsplit)
-        self.res_dtype = torch.float32 if self.wsplit else res_dtype
+        if wsplit is not None:            # round-4 spelling
+            arith = "bf16x2" if wsplit else "bf16"
+        if arith not in ("f16", "bf16x2", "bf16"):
+            raise ValueError(f"TextEngine: arith must be 'f16', 'bf16x2' or 'bf16', got {arith!r}")
+        if arith == "f16" and (cfg.width % 256 or cfg.width // cfg.heads != 64 or cfg.embed_dim % 256 or cfg.context_length > 288):
+            arith = "bf16x2"
+        self.arith = arith
+        self.wsplit = arith == "bf16x2"
+        self.res_dtype = res_dtype if arith == "bf16" else torch.float32
         self.tok = _dev(sd["token_embedding.weight"], device)
         self.pos = _dev(sd["positional_embedding"], device)
         self.ln_final = (_dev(sd["ln_final.weight"], device), _dev(sd["ln_final.bias"], device))
-        if self.wsplit:
+        if arith == "f16":
+            self.projT = _dev(sd["text_projection"].t(), device, torch.float16)       # [E, D]
+            self.blocks = [prep_block_f16(sd, f"transformer.resblocks.{i}.", device) for i in range(cfg.layers)]
+        elif self.wsplit:
             hi, lo = _hi_lo(sd["text_projection"].t(), device)
             self.projT = torch.cat([hi, lo], dim=1).contiguous()                      # [E, 2D]
             self.blocks = [prep_block_wsplit(sd, f"transformer.resblocks.{i}.", device) for i in range(cfg.layers)]
         else:
             self.projT = _dev(sd["text_projection"].t(), device, torch.bfloat16)
-            self.blocks = [prep_block(sd, f"transformer.resblocks.{i}.", device) for i in range(cfg.layers)]
+            self.blocks = [_prep_block_plain(sd, f"transformer.resblocks.{i}.", device) for i in range(cfg.layers)]
         self._ws = {}
+
+    def _encode_f16(self, text: torch.Tensor) -> torch.Tensor:
+        cfg = self.cfg
+        B, L = text.shape
+        D, H = cfg.width, cfg.heads
+        key = ("f16", B, L)
+        if key not in self._ws:
+            self._ws[key] = _WorkspaceF16(B, L, D, H, self.device)
+        ws = self._ws[key]
+        rows = ws.rows
+        ops.text_embed(text, self.tok, self.pos, ws.x[:rows])
+        eot = text.argmax(dim=-1).contiguous()            # index-exact EOT position (model.py:539)
+        qs = (D // H) ** -0.5 * ops.LOG2E
+        for w in self.blocks:
+            ops.layernorm(ws.x, w["ln1_w"], w["ln1_b"], ws.h, rows, D)
+            ops.gemm_f16(ws.h, w["in_w"], w["in_b"], out=ws.qkv)
+            ops.attn_fwd(ws.q, ws.k, ws.v, ws.a, causal=True, qscale=qs)
+            ops.gemm_f16(ws.a, w["out_w"], w["out_b"], out=ws.x, res=ws.x, epi=ops.EPI_RES_F32)
+            ops.layernorm(ws.x, w["ln2_w"], w["ln2_b"], ws.h, rows, D)
+            ops.gemm_f16(ws.h, w["fc_w"], w["fc_b"], out=ws.hid, act=ops.ACT_GELU)
+            ops.gemm_f16(ws.hid, w["proj_w"], w["proj_b"], out=ws.x, res=ws.x, epi=ops.EPI_RES_F32)
+        ops.layernorm(ws.x, self.ln_final[0], self.ln_final[1], ws.pooled, B, D, x_row_stride=D, row_index=eot, row_mul=L)
+        f = torch.zeros(ws.Bp, self.projT.shape[0], device=self.device, dtype=torch.float32)
+        ops.gemm_f16(ws.pooled, self.projT, None, out=f, res=f, epi=ops.EPI_RES_F32)
+        return f[:B]
 
     def encode_text(self, text: torch.Tensor, normalize: bool = False) -> torch.Tensor:
         cfg = self.cfg
         B, L = text.shape
         D = cfg.width
+        text = text.to(self.device).contiguous()
+        if self.arith == "f16":
+            f = self._encode_f16(text)
+            return ops.l2_normalize(f) if normalize else f.contiguous()
         key = (B, L)
         if key not in self._ws:
             self._ws[key] = _Workspace(B, L, D, cfg.heads, 4 * D, self.device, self.res_dtype)
         ws = self._ws[key]
-        text = text.to(self.device).contiguous()
         ops.text_embed(text, self.tok, self.pos, ws.x)
         eot = text.argmax(dim=-1).contiguous()            # index-exact EOT position (model.py:539)
         if self.wsplit:
@@ -318,7 +394,7 @@ class TextEngine:
             for half in (pooled[:, :D], pooled[:, D:]):
                 ops.layernorm(ws.x, self.ln_final[0], self.ln_final[1], half, B, D, x_row_stride=D, row_index=eot, row_mul=L)
         else:
-            run_blocks(self.blocks, ws, B, L, D, cfg.heads, causal=True, cfg=self.gemm_cfg)
+            run_blocks(self.blocks, ws, B, L, D, cfg.heads, causal=True, cfg=self.gemm_cfg, fold=False)
             pooled = torch.empty(B, D, device=self.device, dtype=torch.bfloat16)
             ops.layernorm(ws.x, self.ln_final[0], self.ln_final[1], pooled, B, D, x_row_stride=D, row_index=eot, row_mul=L)
         f = ops.gemm(pooled, self.projT, None, epi=ops.EPI_F32, cfg=self.gemm_cfg)

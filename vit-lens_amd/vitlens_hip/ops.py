@@ -6,7 +6,7 @@ import torch
 
 from ._lib import load_library, check
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 EPI_BF16, EPI_F32, EPI_RES_F32, EPI_RES_BF16, EPI_GEGLU, EPI_DGELU, EPI_DGEGLU = 0, 1, 2, 3, 5, 6, 7
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 ACT_GELU_DSAVE = 4          # forward: out = gelu(pre), out2 = gelu'(pre);  with EPI_DGELU: res is that gelu' tensor
@@ -32,6 +32,8 @@ def _dt(t):
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
+    if t.dtype == torch.float16:
+        return F16
     raise TypeError(f"unsupported dtype {t.dtype}")
 
 
@@ -73,6 +75,29 @@ def gemm(a, w, bias=None, out=None, res=None, epi=EPI_BF16, act=ACT_NONE, alpha=
         raise ValueError("gemm: out2 must be bf16 with out's row stride (twice that for GEGLU)")
     check(_lib.vl_gemm_bf16_ex(_p(a), _p(w), _p(bias), _p(out), _p(res), _p(out2), M, N, K, a.stride(0), w.stride(0),
                                out.stride(0), float(alpha), epi, act, res_div, cfg, _stream()))
+    return out
+
+
+def gemm_f16(a, w, bias=None, out=None, res=None, epi=EPI_BF16, act=ACT_NONE, alpha=1.0):
+    """The persistent 256x256 GEMM on IEEE-half operands (vl_gemm_f16; the frozen text tower): a [M,K], w [N,K] fp16;
+    epi = EPI_BF16 -> out fp16 [M,N] = act(a @ w.T + bias), epi = EPI_RES_F32 -> out f32 = res + a @ w.T + bias (in place
+    allowed).  M, N multiples of 256, K a multiple of 64 and >= 512: the caller pads (TextEngine keeps whole row tiles)."""
+    _chk2d(a, "a", torch.float16); _chk2d(w, "w", torch.float16)
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"gemm_f16: K mismatch {a.shape} vs {w.shape}")
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32 if epi == EPI_RES_F32 else torch.float16)
+    _chk2d(out, "out", torch.float32 if epi == EPI_RES_F32 else torch.float16)
+    if res is not None:
+        _chk2d(res, "res", torch.float32)
+        if res.stride(0) != out.stride(0):
+            raise ValueError("gemm_f16: residual must share out's row stride")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N):
+        raise ValueError("gemm_f16: bias must be f32 [N]")
+    check(_lib.vl_gemm_f16(_p(a), _p(w), _p(bias), _p(out), _p(res), M, N, K, a.stride(0), w.stride(0), out.stride(0),
+                           float(alpha), epi, act, _stream()))
     return out
 
 
@@ -225,8 +250,8 @@ def _bhld_strides(*views):
     import ctypes
     vals = []
     for t in views:
-        if t.dim() != 4 or t.stride(3) != 1 or t.dtype != torch.bfloat16:
-            raise ValueError("attention operands must be bf16 [B,H,L,dh] views with unit last stride")
+        if t.dim() != 4 or t.stride(3) != 1 or t.dtype != views[0].dtype or t.dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError("attention operands must be bf16 (or, forward only, fp16) [B,H,L,dh] views of one dtype with unit last stride")
         vals += [t.stride(0), t.stride(1), t.stride(2)]
     return (ctypes.c_long * len(vals))(*vals)
 
@@ -243,6 +268,12 @@ def attn_fwd(q, k, v, out, lse=None, causal=False, qscale=1.0):
     B, H, Lq, dh = q.shape
     Lk = k.shape[2]
     st = _bhld_strides(q, k, v)
+    if q.dtype == torch.float16:          # the frozen text tower's operands (head dim 64, <= 288 keys)
+        if k.dtype != q.dtype or v.dtype != q.dtype or out.dtype != q.dtype:
+            raise TypeError("attn_fwd: fp16 q needs fp16 k, v and out")
+        check(_lib.vl_attn_fwd_f16(_p(q), _p(k), _p(v), st, _p(out), _p(lse), B, H, Lq, Lk, dh, float(qscale),
+                                   1 if causal else 0, _stream()))
+        return out
     check(_lib.vl_attn_fwd_bf16(_p(q), _p(k), _p(v), st, _p(out), _p(lse), B, H, Lq, Lk, dh, float(qscale),
                                 1 if causal else 0, _stream()))
     return out

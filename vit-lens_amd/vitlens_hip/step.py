@@ -285,7 +285,7 @@ class TriModalDepthStep(_StepState):
                  unlock_first_n: int = 4, lr: float = 5e-4, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2,
                  rank: int = 0, world_size: int = 1, gemm_cfg: int = -1, comm=None, frozen_res_dtype=torch.float32,
                  local_loss: bool = False, gather_with_grad: bool = False, train_res_dtype=torch.float32,
-                 grad_checkpointing: bool = False, force_comm: bool = False, text_wsplit: bool = True):
+                 grad_checkpointing: bool = False, force_comm: bool = False, text_wsplit: Optional[bool] = None, text_arith: str = "f16"):
         self.dev, self.mb, self.rank, self.world = torch.device(device), micro_batch, rank, world_size
         # the multi-rank path (packed all-gather, bucketed async all-reduce, optional reduce-scatter) runs when there are
         # peers - or when asked for on ONE rank, so that the RCCL calls execute on a single GPU (tests, bench --force-dist)
@@ -296,7 +296,7 @@ class TriModalDepthStep(_StepState):
         self._base_sd = {k: v.detach() for k, v in sd.items()}
         # frozen towers: forward only; their residual stream may be kept in bf16 (= the reference's autocast)
         self.image = VitEngine(sd, "image.", tower, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
-        self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype, wsplit=text_wsplit)
+        self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype, wsplit=text_wsplit, arith=text_arith)
         # trainable tower: residual stream AND residual-gradient stream in `train_res_dtype` (bf16 = the reference's amp_bf16)
         self.lens = LensEngine(sd, "visual.", tower, LensCfg(modality="depth", perceiver_identity=True), device, gemm_cfg=gemm_cfg,
                                res_dtype=train_res_dtype)
@@ -603,10 +603,10 @@ class DualAudioStep(_PerceiverLensStep):
     def __init__(self, sd, tower: TowerCfg, text: TextCfg, lens: LensCfg, device, micro_batch: int = 256, lr: float = 2e-4,
                  betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2, rank: int = 0, world_size: int = 1,
                  gemm_cfg: int = -1, comm=None, frozen_res_dtype=torch.float32, local_loss: bool = False,
-                 gather_with_grad: bool = False, train_res_dtype=torch.float32, force_comm: bool = False, text_wsplit: bool = True):
+                 gather_with_grad: bool = False, train_res_dtype=torch.float32, force_comm: bool = False, text_wsplit: Optional[bool] = None, text_arith: str = "f16"):
         from .train import AudioLensTrainer
         self._init_common(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad, force_comm)
-        self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype, wsplit=text_wsplit)
+        self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype, wsplit=text_wsplit, arith=text_arith)
         self.lens = LensEngine(sd, "visual.", tower, lens, device, gemm_cfg=gemm_cfg, res_dtype=train_res_dtype)
         self._mk = lambda: AudioLensTrainer(self.lens)
         self.masters["visual.class_embedding"] = self.lens.vit.cls
@@ -666,12 +666,12 @@ class TriModalPCStep(_PerceiverLensStep):
                  betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2, rank: int = 0, world_size: int = 1,
                  gemm_cfg: int = -1, bn_training: bool = True, unlock_cls: bool = False, comm=None,
                  frozen_res_dtype=torch.float32, local_loss: bool = False, gather_with_grad: bool = False,
-                 train_res_dtype=torch.float32, bn_sync: bool = False, force_comm: bool = False, text_wsplit: bool = True):
+                 train_res_dtype=torch.float32, bn_sync: bool = False, force_comm: bool = False, text_wsplit: Optional[bool] = None, text_arith: str = "f16"):
         from .points import PointTokenizerTrainer
         from .train import PCLensTrainer
         self._init_common(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad, force_comm)
         self.image = VitEngine(sd, "image.", tower, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
-        self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype, wsplit=text_wsplit)
+        self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype, wsplit=text_wsplit, arith=text_arith)
         self.lens = LensEngine(sd, "visual.", tower, lens, device, gemm_cfg=gemm_cfg, res_dtype=train_res_dtype)
         self.tok = PointTokenizerTrainer(sd, "visual.visual_adapter.", lens, device, gemm_cfg=gemm_cfg, bn_training=bn_training,
                                          bn_sync=self.comm if bn_sync and self.dist else None, world_size=world_size)
