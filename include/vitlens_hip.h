@@ -122,6 +122,23 @@ int vl_gemm_f16(const void* A, const void* W, const float* bias, void* out, cons
 int vl_attn_fwd_f16(const void* q, const void* k, const void* v, const long* strides, void* out, float* lse,
                     int B, int H, int Lq, int Lk, int dh, float qscale, int causal, hipStream_t stream);
 
+/* True fp32 arithmetic for INFERENCE (round 5): `precision="fp32"` of the reference's factory (open_clip/factory.py:260-295,
+ * training/precision.py:5-12) means fp32 nn.Linear / attention products; rounds 1-4 ran bf16 operands there and said so in a
+ * warning.  gfx950 has fp32-input MFMA at the fp32 vector rate (157 TFLOP/s, 1/16 of bf16), exact fmaf chains:
+ *   vl_gemm_f32      out f32 [M,N] = act(alpha * A[M,K] W[N,K]^T + bias) (+ res f32 [M,N], in place allowed); any M, N;
+ *                    K, lda, ldw multiples of 4; act none / GELU (erff) / ReLU        (csrc/vl_f32.hip, v_mfma_f32_32x32x2_f32)
+ *   vl_attn_fwd_f32  softmax(scale * q k^T [+ causal mask]) v on strided f32 [B,H,L,dh] views (strides as vl_attn_fwd_bf16,
+ *                    multiples of 4), dh = 32 or 64; out f32 [B,Lq,H*dh]; lse optional (natural log)
+ *   vl_im2col_f32    vl_im2col_bf16 with f32 patches
+ * LayerNorm, the token assembly and the text embedding already take f32 in and out.  Forward only: training under
+ * precision="fp32" keeps bf16 operands with fp32 residual / gradient streams (vitlens_hip/f32.py says what runs). */
+int vl_gemm_f32(const float* A, const float* W, const float* bias, float* out, const float* res, int M, int N, int K,
+                int lda, int ldw, int ldo, float alpha, int act, hipStream_t stream);
+int vl_attn_fwd_f32(const float* q, const float* k, const float* v, const long* strides, float* out, float* lse,
+                    int B, int H, int Lq, int Lk, int dh, float scale, int causal, hipStream_t stream);
+int vl_im2col_f32(const float* x, float* patches, int N, int C, int H, int W, int kh, int kw, int sh, int sw,
+                  int Kp, int transpose_hw, hipStream_t stream);
+
 int vl_device_info(int device, char* arch, int arch_len, int* cus, int* clock_khz, long* hbm_bytes);
 
 /* Fused attention forward: softmax(q k^T [+ causal mask]) v without materialising the scores.

@@ -188,7 +188,8 @@ __global__ void __launch_bounds__(256) l2norm_kernel(const float* x, float* y, b
 // column order = (c, i, j) row-major = conv weight.reshape(width, -1) order; columns >= C*kh*kw are zero.
 // `transpose_hw`: read the input as x[n, c, j_w, i_h] i.e. the AST tokenizer's transpose(2,3)
 // (modal_audio/models/AST_tokenizer.py:46-47) fused into the gather.
-struct I2cP { const float* x; bf16_t* out; int N, C, H, W, kh, kw, sh, sw, gh, gw, Kp, transpose_hw; };
+struct I2cP { const float* x; void* out; int N, C, H, W, kh, kw, sh, sw, gh, gw, Kp, transpose_hw; };
+template <typename TOUT>
 __global__ void __launch_bounds__(256) im2col_kernel(const I2cP p) {
   const long total = (long)p.N * p.gh * p.gw * p.Kp;
   const int K = p.C * p.kh * p.kw;
@@ -209,7 +210,7 @@ __global__ void __launch_bounds__(256) im2col_kernel(const I2cP p) {
       else
         v = p.x[((long)n * p.C + c) * p.H * p.W + (long)hh * p.W + ww];
     }
-    p.out[i] = f2bf(v);
+    store1((TOUT*)p.out + i, v);
   }
 }
 
@@ -339,8 +340,18 @@ extern "C" int vl_im2col_bf16(const float* x, void* patches, int N, int C, int H
                               int Kp, int transpose_hw, hipStream_t stream) {
   if (N <= 0 || H < kh || W < kw) return vl_set_error("vl_im2col_bf16: bad shape");
   if (Kp < C * kh * kw) return vl_set_error("vl_im2col_bf16: Kp smaller than C*kh*kw");
-  I2cP p{x, (bf16_t*)patches, N, C, H, W, kh, kw, sh, sw, (H - kh) / sh + 1, (W - kw) / sw + 1, Kp, transpose_hw};
-  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for((long)N * p.gh * p.gw * Kp)), dim3(256), 0, stream, p);
+  I2cP p{x, patches, N, C, H, W, kh, kw, sh, sw, (H - kh) / sh + 1, (W - kw) / sw + 1, Kp, transpose_hw};
+  hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid_for((long)N * p.gh * p.gw * Kp)), dim3(256), 0, stream, p);
+  VL_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vl_im2col_f32(const float* x, float* patches, int N, int C, int H, int W, int kh, int kw, int sh, int sw,
+                             int Kp, int transpose_hw, hipStream_t stream) {
+  if (N <= 0 || H < kh || W < kw) return vl_set_error("vl_im2col_f32: bad shape");
+  if (Kp < C * kh * kw) return vl_set_error("vl_im2col_f32: Kp smaller than C*kh*kw");
+  I2cP p{x, patches, N, C, H, W, kh, kw, sh, sw, (H - kh) / sh + 1, (W - kw) / sw + 1, Kp, transpose_hw};
+  hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid_for((long)N * p.gh * p.gw * Kp)), dim3(256), 0, stream, p);
   VL_HIP_OK(hipGetLastError());
   return 0;
 }

@@ -239,6 +239,8 @@ class VisionTransformer(nn.Module):
                 mods[str(i)] = mods["1"]
         self.image_mean = self.image_std = None
         self.res_dtype = torch.float32          # residual-stream dtype of the HIP towers; TriCLIP.set_precision maps `precision` to it
+        self.arith_f32 = False                  # precision="fp32": eval-mode, graph-less forwards run true fp32 arithmetic (vitlens_hip/f32.py)
+        self._f32_engine, self._f32_vers = None, None
         self._engine = None
         self._engine_key, self._engine_vers = None, None
         self._trainer_obj, self._trainer_key, self._gen = None, None, 0
@@ -467,10 +469,30 @@ class VisionTransformer(nn.Module):
             feat = tr.forward(x, **kwargs)
             self._sync_bn_buffers(tr)
             return feat.clone()
+        f32 = self._engine_f32() if (self.arith_f32 and not self.training) else None
+        if f32 is not None:
+            return f32.encode(x)
         eng = self.engine()
         if self.modality in ("image", "tactile"):
             return eng.encode_image(x)
         return eng.encode(x, **kwargs)
+
+    def _engine_f32(self):
+        """The fp32-arithmetic executor of this tower (precision="fp32", inference), or None where it does not exist: the
+        Perceiver / point-cloud / audio / EEG Lenses and head dims other than 32 / 64 stay on the 16-bit engines."""
+        from vitlens_hip import f32 as F
+        simple = self.modality in ("image", "tactile") or (self.modality == "depth" and self.perceiver_identity)
+        if not simple or not F.f32_supported(self.cfg.width, self.heads) or self.class_embedding.device.type != "cuda":
+            return None
+        vers = {n: p._version for n, p in self.named_parameters()}
+        if self._f32_engine is None or vers != self._f32_vers:
+            sd = {("t." + k): v for k, v in self.state_dict().items()}
+            tower, lens = self._cfgs()
+            self._f32_engine = F.VitEngineF32(sd, "t.", tower, self.class_embedding.device, depth=self.modality == "depth",
+                                              use_orig_pos=True if lens is None else lens.use_orig_pos,
+                                              disable_adapter_pos=False if lens is None else lens.disable_adapter_pos)
+            self._f32_vers = vers
+        return self._f32_engine
 
     def _sync_bn_buffers(self, tr):
         """Running statistics of the point tokenizer's BatchNorm layers after a train-mode forward -> this module's buffers."""
@@ -579,6 +601,7 @@ class TriCLIP(nn.Module):
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
         self._text_engine, self._text_key = None, None
         self._res_dtype = torch.float32
+        self._arith_f32 = False
         self._text_arith = "f16"
 
     def set_precision(self, precision: str, text_arith: str = "f16"):
@@ -591,6 +614,7 @@ class TriCLIP(nn.Module):
         import warnings
         dt = torch.float32 if precision == "fp32" else torch.bfloat16
         self._res_dtype = self.image.res_dtype = self.visual.res_dtype = dt
+        self.image.arith_f32 = self.visual.arith_f32 = self._arith_f32 = precision == "fp32"
         if text_arith not in ("f16", "bf16x2", "bf16"):
             raise ValueError(f"text_arith must be 'f16', 'bf16x2' or 'bf16', got {text_arith!r}")
         self._text_arith = text_arith
@@ -605,9 +629,13 @@ class TriCLIP(nn.Module):
                                     + ("fp32" if dt == torch.float32 else "bf16") + "; text tower: " + text
                                     + "; LayerNorm / softmax statistics, features, logits, loss in fp32")
         if precision == "fp32":
-            warnings.warn("precision='fp32': the MI355X path has no fp32-arithmetic mode - matrix products take bf16 operands with "
-                          "fp32 accumulation (cosine matrices within 1e-3 of the fp32 CPU path); 'fp32' selects the fp32 residual "
-                          "stream.  See model.precision_effective.", UserWarning, stacklevel=3)
+            self.precision_effective = ("eval mode, no autograd graph: true fp32 arithmetic (fp32-input MFMA, vitlens_hip/f32.py) for the "
+                                        "image / tactile / depth(identity Perceiver) towers and the text tower with head dim 32 or 64; "
+                                        "otherwise (train mode, towers with trainable parameters, Perceiver / audio / point-cloud / EEG "
+                                        "Lenses): " + self.precision_effective)
+            warnings.warn("precision='fp32': fp32 arithmetic runs for eval-mode inference (model.eval(), no trainable tower in the "
+                          "call); training keeps bf16 matrix operands with fp32 accumulation on fp32 residual / gradient streams - "
+                          "the MI355X path has no fp32 backward.  See model.precision_effective.", UserWarning, stacklevel=3)
         elif precision == "amp":
             warnings.warn("precision='amp' (fp16 autocast in the reference) runs as amp_bf16 on the MI355X path: bf16 operands, "
                           "fp32 accumulation, no loss scaling.", UserWarning, stacklevel=3)
@@ -642,10 +670,18 @@ class TriCLIP(nn.Module):
         # (logit_scale is not a text-tower operand: it changes every step and must not invalidate the frozen tower's engine)
         prm = dict(self.named_parameters())
         names = [n for n in prm if not n.startswith(("image.", "visual.")) and n != "logit_scale"]
-        key = (str(dev), self._res_dtype, self._text_arith, tuple(prm[n]._version for n in names))
+        from vitlens_hip import f32 as F32
+        f32 = self._arith_f32 and not self.training and F32.f32_supported(self.text_cfg.width, self.text_cfg.heads)
+        key = (str(dev), self._res_dtype, "f32" if f32 else self._text_arith, tuple(prm[n]._version for n in names))
         if self._text_engine is None or key != self._text_key:
             sd = {k: v for k, v in self.state_dict().items() if not k.startswith(("image.", "visual."))}
             t = self.text_cfg
+            if f32:
+                self._text_engine = F32.TextEngineF32(sd, E.TextCfg(context_length=t.context_length, vocab_size=t.vocab_size,
+                                                                   width=t.width, heads=t.heads, layers=t.layers,
+                                                                   embed_dim=self.text_projection.shape[1]), dev)
+                self._text_key = key
+                return self._text_engine
             self._text_engine = E.TextEngine(sd, E.TextCfg(context_length=t.context_length, vocab_size=t.vocab_size,
                                                            width=t.width, heads=t.heads, layers=t.layers,
                                                            embed_dim=self.text_projection.shape[1]), dev, res_dtype=self._res_dtype,

@@ -25,6 +25,9 @@ SIGNATURES = {
     "vl_gemm_tn_splitk_accum_f32": [P, P, P, I, I, I, I, I, L, F, I, P, P],
     "vl_attn_fwd_bf16": [P, P, P, P, P, P, I, I, I, I, I, F, I, P],
     "vl_gemm_f16": [P, P, P, P, P, I, I, I, I, I, I, F, I, I, P],
+    "vl_gemm_f32": [P, P, P, P, P, I, I, I, I, I, I, F, I, P],
+    "vl_attn_fwd_f32": [P, P, P, P, P, P, I, I, I, I, I, F, I, P],
+    "vl_im2col_f32": [P, P, I, I, I, I, I, I, I, I, I, I, P],
     "vl_attn_fwd_f16": [P, P, P, P, P, P, I, I, I, I, I, F, I, P],
     "vl_layernorm_fwd": [P, I, L, P, L, P, P, P, I, L, P, P, I, I, F, P],
     "vl_gemm_main_rows": [I, I],

@@ -101,6 +101,57 @@ def gemm_f16(a, w, bias=None, out=None, res=None, epi=EPI_BF16, act=ACT_NONE, al
     return out
 
 
+# ---- true fp32 arithmetic (inference under precision="fp32": vitlens_hip/f32.py) ----
+def gemm_f32(a, w, bias=None, out=None, res=None, act=ACT_NONE, alpha=1.0):
+    """out f32 = act(alpha * a @ w.T + bias) (+ res), a [M,K], w [N,K] f32, any M and N, K % 4 == 0 (vl_gemm_f32: fp32-input MFMA)."""
+    _chk2d(a, "a", torch.float32); _chk2d(w, "w", torch.float32)
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"gemm_f32: K mismatch {a.shape} vs {w.shape}")
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    _chk2d(out, "out", torch.float32)
+    if res is not None:
+        _chk2d(res, "res", torch.float32)
+        if res.stride(0) != out.stride(0):
+            raise ValueError("gemm_f32: residual must share out's row stride")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N):
+        raise ValueError("gemm_f32: bias must be f32 [N]")
+    check(_lib.vl_gemm_f32(_p(a), _p(w), _p(bias), _p(out), _p(res), M, N, K, a.stride(0), w.stride(0), out.stride(0),
+                           float(alpha), act, _stream()))
+    return out
+
+
+def attn_fwd_f32(q, k, v, out, lse=None, causal=False, scale=1.0):
+    """softmax(scale * q k^T [+ causal mask]) v on strided f32 [B,H,L,dh] views -> out f32 [B*Lq, H*dh] (dh = 32 or 64)."""
+    import ctypes
+    B, H, Lq, dh = q.shape
+    Lk = k.shape[2]
+    vals = []
+    for t in (q, k, v):
+        if t.dim() != 4 or t.stride(3) != 1 or t.dtype != torch.float32:
+            raise ValueError("attn_fwd_f32: operands must be f32 [B,H,L,dh] views with unit last stride")
+        vals += [t.stride(0), t.stride(1), t.stride(2)]
+    if out.dtype != torch.float32:
+        raise TypeError("attn_fwd_f32: out must be f32")
+    check(_lib.vl_attn_fwd_f32(_p(q), _p(k), _p(v), (ctypes.c_long * 9)(*vals), _p(out), _p(lse), B, H, Lq, Lk, dh, float(scale),
+                               1 if causal else 0, _stream()))
+    return out
+
+
+def im2col_f32(x, kh, kw, sh, sw, Kp, transpose_hw=False):
+    """im2col with f32 patches (the conv stem under precision="fp32")."""
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("im2col_f32: need contiguous f32 input")
+    N, Cc = x.shape[0], x.shape[1]
+    H, W = (x.shape[3], x.shape[2]) if transpose_hw else (x.shape[2], x.shape[3])
+    gh, gw = (H - kh) // sh + 1, (W - kw) // sw + 1
+    out = torch.empty(N * gh * gw, Kp, device=x.device, dtype=torch.float32)
+    check(_lib.vl_im2col_f32(_p(x), _p(out), N, Cc, H, W, kh, kw, sh, sw, Kp, 1 if transpose_hw else 0, _stream()))
+    return out, gh, gw
+
+
 # ---- LayerNorm folded into the GEMMs either side of it (frozen pre-LN blocks, bf16 residual stream; include/vitlens_hip.h) ----
 def fold_ln_linear(w, b, gamma, beta):
     """Operands of  LN(x; gamma, beta) @ w.T + b  for vl_gemm_lnfold_bf16: (Wg bf16 [N,K] = bf16(w * gamma), bias_f f32 [N] =
