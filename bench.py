@@ -147,6 +147,13 @@ class GemmTimer:
             return timed(key, rrs, a, w, *args, **kw)
 
         self.ops.gemm_lnfold, self.ops.gemm_res_rowstats = gemm_lnfold, gemm_res_rowstats
+        g16 = self.ops.gemm_f16
+
+        def gemm_f16(a, w, *args, **kw):      # the fp16 text tower's launches count in the all-GEMM figures like any other
+            key = ("gemm_f16", a.shape[0], w.shape[0], a.shape[1], kw.get("epi", 0), kw.get("act", 0))
+            return timed(key, g16, a, w, *args, **kw)
+
+        self.ops.gemm_f16 = gemm_f16
 
     def summary(self):
         agg = {}
@@ -212,7 +219,7 @@ def hbm_traffic(dom):
     collected by tools/gpu_evidence_r03.sh with this very command and corrected per the MI355X guide by
     tools/traffic_summary.py).  PMC collection cannot run inside the timed process, so the number is read from
     profiles/; None when no summary for this kernel shape has been committed."""
-    for name in ("r04b_hbm_traffic_c3.json", "r04_hbm_traffic_c3.json", "hbm_traffic.json"):        # newest summary first
+    for name in ("r05_hbm_traffic_c3.json", "r04b_hbm_traffic_c3.json", "r04_hbm_traffic_c3.json", "hbm_traffic.json"):        # newest summary first
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
             for e in t.get("shapes", [t]):
@@ -225,30 +232,48 @@ def hbm_traffic(dom):
 
 
 def pmc_mfma_busy(dom):
-    """MFMA-busy fraction IN CYCLES of the dominant kernel from the committed SQ counter passes (profiles/r03c_gemm_pmc.json:
-    SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), tools/gpu_r03_pmc_proj.sh -> profiles/r03d_gemm_pmc.json; round-3a passes in
-    profiles/r03_gemm_pmc.json).  The chip is power-managed: on random-normal operands the shader clock averages 1.4-1.7 GHz
-    instead of 2.4 GHz (kernel cycles / measured time; the same kernel runs 27 % faster on zero-filled operands,
-    profiles/r03a_clock_probe_dvfs.log), so the wall-clock fraction of the 2.5 PFLOP/s peak (`frac`) is lower than the
-    fraction of cycles the matrix pipes are busy."""
-    key = {(1024, 4096, 3, 0): "gemm_nt_pk_kernel<3, 0, true>", (4096, 1024, 0, 1): "gemm_nt_pk_kernel<0, 1, true>",
-           (4096, 1024, 0, 4): "gemm_nt_pk_kernel<0, 4, true>", (4096, 1024, 6, 4): "gemm_nt_pk_kernel<6, 4, true>",
-           (3072, 1024, 0, 0): "gemm_nt_pk_kernel<0, 0, true>"}.get((dom["N"], dom["K"], dom["epi"], dom["act"]))
-    plain = key
-    if key and LN_FOLDED:
-        # with the LayerNorm folding most launches of these shapes are the folding instantiations of the same kernel
-        key = {"gemm_nt_pk_kernel<3, 0, true>": "gemm_nt_pk_kernel<3, 20, true>", "gemm_nt_pk_kernel<0, 1, true>": "gemm_nt_pk_kernel<0, 11, true>",
-               "gemm_nt_pk_kernel<0, 4, true>": "gemm_nt_pk_kernel<0, 14, true>", "gemm_nt_pk_kernel<0, 0, true>": "gemm_nt_pk_kernel<0, 10, true>"}.get(key, key)
-    keys = [key] if key == plain else [key, plain]      # no counter pass of the folding instantiation committed: the plain one
-    for key in keys:
-        for src in ("r04b_gemm_pmc.json", "r04_gemm_pmc.json", "r03d_gemm_pmc.json", "r03c_gemm_pmc.json"):   # r04: round-4 epilogue; r03d: 16x16x32 main loop; r03c: 32x32x16
-            try:
-                t = json.load(open(os.path.join(ROOT, "profiles", src)))["kernels"]
-                k = t.get(key) or t[key.replace(", true>", ">")]
-                return {"mfma_busy_frac_cycles": k["mfma_busy_frac"], "wait_any_frac": k["wait_any_frac"], "kernel_cycles": k["kernel_cycles"],
-                        "kernel": key if key in t else key.replace(", true>", ">"), "source": "profiles/" + src}
-            except (OSError, ValueError, KeyError, TypeError):
-                continue
+    """MFMA-busy fraction IN CYCLES of the dominant kernel from the committed SQ counter passes (SQ_VALU_MFMA_BUSY_CYCLES /
+    (kernel cycles x 1024 SIMDs); tools/gpu_evidence_r05.sh -> profiles/r05_gemm_pmc.json, earlier rounds' files behind it).
+    The chip is power-managed: through a GEMM loop the board sits at its 1 400 W limit and the shader clock at ~1.86 GHz instead
+    of 2.4 (profiles/r05_power_trace.log), so the wall-clock fraction of the 2.5 PFLOP/s peak (`frac`) is lower than the
+    fraction of cycles the matrix pipes are busy.  Kernel names: `gemm_nt_pk_kernel<EPI, ACT, F16>` since round 5 (the third
+    parameter was the main-loop selector, always true, in the round-3 / round-4 files)."""
+    base = {(1024, 4096, 3, 0): (3, 0), (4096, 1024, 0, 1): (0, 1), (4096, 1024, 0, 4): (0, 4), (4096, 1024, 6, 4): (6, 4),
+            (3072, 1024, 0, 0): (0, 0)}.get((dom["N"], dom["K"], dom["epi"], dom["act"]))
+    if base is None:
+        return None
+    epi, act = base
+    # with the LayerNorm folding most launches of these shapes are the folding instantiations of the same kernel
+    fold_act = {(3, 0): 20, (0, 1): 11, (0, 4): 14, (0, 0): 10}.get(base)
+    cands = []
+    if LN_FOLDED and fold_act is not None:
+        cands.append(("r05_gemm_pmc.json", f"gemm_nt_pk_kernel<{epi}, {fold_act}, false>"))
+    cands.append(("r05_gemm_pmc.json", f"gemm_nt_pk_kernel<{epi}, {act}, false>"))
+    for src in ("r04b_gemm_pmc.json", "r04_gemm_pmc.json", "r03d_gemm_pmc.json", "r03c_gemm_pmc.json"):   # r04: round-4 epilogue; r03d: 16x16x32 main loop
+        cands.append((src, f"gemm_nt_pk_kernel<{epi}, {act}, true>"))
+        cands.append((src, f"gemm_nt_pk_kernel<{epi}, {act}>"))
+    for src, key in cands:
+        try:
+            k = json.load(open(os.path.join(ROOT, "profiles", src)))["kernels"][key]
+            return {"mfma_busy_frac_cycles": k["mfma_busy_frac"], "wait_any_frac": k["wait_any_frac"], "kernel_cycles": k["kernel_cycles"],
+                    "kernel": key, "source": "profiles/" + src}
+        except (OSError, ValueError, KeyError, TypeError):
+            continue
+    return None
+
+
+def leftover_launch_ms(dom):
+    """Average duration of the leftover-row launch that follows the dominant persistent launch, from the committed rocprofv3
+    kernel statistics of this command (the bench's HIP events bracket both launches).  None: no statistics committed."""
+    import csv
+    name = f"gemm_tail_kernel<{dom['epi']}>"
+    for src in ("r05_bench_c3_kernel_stats.csv", "r04_bench_c3_kernel_stats.csv"):
+        try:
+            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", src))):
+                if name in r["Name"]:
+                    return float(r["AverageNs"]) * 1e-6
+        except (OSError, ValueError, KeyError):
+            continue
     return None
 
 
@@ -653,6 +678,13 @@ def main():
                     "gemm_share_of_step": round(tot_ms / (ms * a.steps), 4),
                     "step_tflops": round(gf_unit * a.batch / (ms * 1e-3) / 1e3, 1),
                     "step_frac": round(gf_unit * a.batch / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS, 4)}
+            # the clock the fraction was achieved at: cycles of the persistent launch (SQ counters, committed) / its duration in THIS
+            # run (events minus the leftover-row launch they also bracket, committed kernel statistics)
+            pm, lo = roof["pmc"], leftover_launch_ms(dom)
+            if pm and lo is not None and dom["avg_ms"] > lo:
+                roof["effective_clock_ghz"] = round(pm["kernel_cycles"] / ((dom["avg_ms"] - lo) * 1e-3) / 1e9, 3)
+                roof["effective_clock_note"] = ("kernel cycles (profiles SQ pass, M = 65 536 rows) / (avg_launch_ms - leftover-row launch "
+                                                f"{lo:.4f} ms from the committed kernel statistics); board limit 1 400 W: profiles/r05_power_trace.log")
         out = {"metric": "modality-pairs/sec (ViT-L, 224^2 patches)", "value": round(value, 2),
                "unit": "modality-pairs/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
