@@ -381,6 +381,8 @@ def test_step_checkpoint_export_reload_and_resume(recipe):
     missing = model.load_state_dict(exported, strict=False)
     assert not missing.unexpected_keys and not [k for k in missing.missing_keys if not k.endswith("num_batches_tracked")]
     model.eval()
+    model.visual.arith_f32 = False      # compare like with like: the step's tower runs bf16 operands (default precision "fp32" + eval()
+    #                                     would route the depth tower through the fp32-arithmetic executor, tests/test_hip_f32.py)
     kw = {"fps_start": ins["fps_start"].cuda()} if recipe == "pc" else {}
     with torch.no_grad():
         got = model.encode_visual(ins["visual_x"].cuda(), normalize=True, **kw)
