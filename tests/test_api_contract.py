@@ -497,19 +497,22 @@ def test_tri_create_model_from_pretrained(tmp_path):
 
 
 def test_precision_modes_say_what_they_run():
-    """`precision` is accepted with the reference's spellings, but the path has ONE arithmetic (bf16 operands, fp32
-    accumulation): "fp32" and "amp" say so with a warning instead of silently computing something else
-    (reference: open_clip/factory.py:260-295, training/precision.py:5-12)."""
+    """`precision` is accepted with the reference's spellings and every mode SAYS what it runs: "fp32" = true fp32 arithmetic
+    for eval-mode inference (round 5) and bf16 operands on fp32 streams for training, with a warning that names the split;
+    "amp" runs as amp_bf16 with a warning instead of silently computing something else (reference:
+    open_clip/factory.py:260-295, training/precision.py:5-12)."""
     import warnings
     import open_clip as oc
     from mm_vit_lens.model_cfg import fetch_model_cfg
     args = fetch_model_cfg(modality="image")
-    with pytest.warns(UserWarning, match="no fp32-arithmetic mode"):
+    with pytest.warns(UserWarning, match="no fp32 backward"):
         m = oc.tri_create_model("ViT-B-32", precision="fp32", device="cpu", args=args)
     assert m.precision_requested == "fp32" and "residual stream fp32" in m.precision_effective and "bf16 x bf16" in m.precision_effective
+    assert "true fp32 arithmetic" in m.precision_effective and m.image.arith_f32 and m.visual.arith_f32
+    assert "text tower: fp16 x fp16" in m.precision_effective
     with pytest.warns(UserWarning, match="runs as amp_bf16"):
         m = oc.tri_create_model("ViT-B-32", precision="amp", device="cpu", args=args)
-    assert "residual stream bf16" in m.precision_effective
+    assert "residual stream bf16" in m.precision_effective and not m.image.arith_f32
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         m = oc.tri_create_model("ViT-B-32", precision="amp_bf16", device="cpu", args=args)       # what it runs: no warning
