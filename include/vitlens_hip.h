@@ -170,7 +170,10 @@ int vl_attn_fwd_bf16(const void* q, const void* k, const void* v, const long* st
  *   vl_ln_row_stats            mean / rstd [rows]: rows < m_main from row_part (P = N/64 slices, summed in slice order),
  *                              rows >= m_main from the bf16 rows themselves (the leftover rows of a row-split GEMM); a row
  *                              whose E[x^2] - mean^2 would cancel (variance below 1e-3 of E[x^2], |mean| > ~30 sigma) is
- *                              also recomputed two-pass from its stored values: x_bf16 is always required
+ *                              also recomputed two-pass from its stored values: x_bf16 is always required.  y_left (optional,
+ *                              with ln_w / ln_b): bf16 LayerNorm output of the rows >= y_row0 (>= m_main), row r at
+ *                              y_left[(r - y_row0) * y_row_stride] - the rows the consuming GEMM runs as layernorm + small
+ *                              tiles get their operand from this launch instead of one more 256-row LayerNorm launch
  * Whole 256x256 tiles, K >= 512, 16-byte aligned operands; anything else is refused (the caller keeps vl_layernorm_fwd +
  * vl_gemm_bf16 for it). */
 int vl_gemm_main_rows(int M, int N);
@@ -180,7 +183,8 @@ int vl_gemm_lnfold_bf16(const void* A, const void* Wg, const float* bias_f, cons
 int vl_gemm_res_rowstats_bf16(const void* A, const void* W, const float* bias, void* out, const void* res, float* row_part,
                               int M, int N, int K, int lda, int ldw, int ldo, hipStream_t stream);
 int vl_ln_row_stats(const float* row_part, int P, const void* x_bf16, long x_row_stride, int D, int m_main, int rows, float eps,
-                    float* mean, float* rstd, hipStream_t stream);
+                    float* mean, float* rstd, const float* ln_w, const float* ln_b, void* y_left, long y_row_stride, int y_row0,
+                    hipStream_t stream);
 
 /* LayerNorm over the last dim (eps inside sqrt, biased variance): y = (x-mean)*rstd*w + b.
  * Source row for output row r is  r*row_mul + row_index[r]  when row_index != NULL (EOT gather,

@@ -160,3 +160,34 @@ def test_tower_forward_and_backward_with_and_without_folding():
         for m_a, r_a, m_b, r_b in ((s1[l][0], s1[l][1], s0[l][0], s0[l][1]), (s1[l][2], s1[l][3], s0[l][2], s0[l][3])):
             assert float(((m_a - m_b).abs() * r_b).max()) < 2e-3          # in units of the row's standard deviation
             assert float((r_a / r_b - 1).abs().max()) < 5e-3
+
+
+def test_row_stats_launch_also_normalises_the_leftover_rows():
+    """Round 5: `ln_row_stats(..., h_left=, h_row0=)` writes the LayerNorm output of the rows >= h_row0 (the consuming GEMM's
+    leftover rows) from the same launch that finalises the statistics - against a separate layernorm of those rows, and the
+    statistics unchanged by the extra output; gemm_lnfold(h_ready=True) then equals the path with its own layernorm launch."""
+    from vitlens_hip import ops
+    M, D, N = 65792, 1024, 3072
+    x = (rnd(M, D, seed=21) * 1.5 + 0.2).bfloat16().cuda()
+    gamma, beta = (1 + 0.2 * rnd(D, seed=22)).cuda(), (0.1 * rnd(D, seed=23)).cuda()
+    w, b = rnd(N, D, seed=24, scale=D ** -0.5).cuda(), rnd(N, seed=25).cuda()
+    out_a = torch.empty(M, N, device="cuda", dtype=torch.bfloat16); out_b = torch.empty_like(out_a)
+    r0 = ops.fold_rows(x, out_a, N)
+    assert r0 == 65536
+    mean0, rstd0 = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    mean1, rstd1 = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    ops.ln_row_stats(None, x, 0, mean0, rstd0)
+    h = torch.zeros(256, D, device="cuda", dtype=torch.bfloat16)
+    ops.ln_row_stats(None, x, 0, mean1, rstd1, ln_w=gamma, ln_b=beta, h_left=h, h_row0=r0)
+    assert torch.equal(mean0, mean1) and torch.equal(rstd0, rstd1)
+    ref = torch.empty(256, D, device="cuda", dtype=torch.bfloat16)
+    ops.layernorm(x[r0:], gamma, beta, ref, 256, D, x_row_stride=x.stride(0))
+    assert relerr(h, ref) < 2e-3 and float((h.float() - ref.float()).abs().max()) <= 2.0 ** -6 * float(ref.float().abs().max())
+    fold = ops.fold_ln_linear(w, b, gamma, beta)
+    hws = torch.zeros(256, D, device="cuda", dtype=torch.bfloat16)
+    ops.gemm_lnfold(x, fold, mean0, rstd0, out_a, w.bfloat16(), b, gamma, beta, hws)                     # own layernorm launch
+    ops.gemm_lnfold(x, fold, mean1, rstd1, out_b, w.bfloat16(), b, gamma, beta, h, h_ready=True)        # operand left by ln_row_stats
+    assert torch.equal(out_a[:r0], out_b[:r0])
+    assert relerr(out_b[r0:], out_a[r0:]) < 4e-3
+    with pytest.raises(ValueError):
+        ops.ln_row_stats(None, x, 0, mean1, rstd1, ln_w=gamma, ln_b=beta, h_left=h[:100], h_row0=r0)

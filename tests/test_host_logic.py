@@ -49,9 +49,9 @@ def test_folding_entries_refuse_bad_arguments_without_touching_the_gpu():
     """Argument checks of the round-4 entries run before any HIP call: status 1 + a message from vl_last_error()."""
     from vitlens_hip import _lib
     lib = _lib.load_library()
-    assert lib.vl_ln_row_stats(None, 0, None, 0, 0, 0, 0, 1e-5, None, None, None) == 1
+    assert lib.vl_ln_row_stats(None, 0, None, 0, 0, 0, 0, 1e-5, None, None, None, None, None, 0, 0, None) == 1
     assert b"bad shape" in lib.vl_last_error()
-    assert lib.vl_ln_row_stats(None, 16, None, 1024, 1024, 256, 512, 1e-5, None, None, None) == 1
+    assert lib.vl_ln_row_stats(None, 16, None, 1024, 1024, 256, 512, 1e-5, None, None, None, None, None, 0, 0, None) == 1
     assert b"partial statistics missing" in lib.vl_last_error()
     assert lib.vl_gemm_lnfold_bf16(None, None, None, None, None, None, None, None, 256, 256, 512, 512, 512, 256, 0, None) == 1
     assert b"null operand" in lib.vl_last_error()

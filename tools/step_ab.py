@@ -22,6 +22,17 @@ def patch(name):
         orig = ops.attn_bwd
         ops.attn_bwd = functools.partial(orig, fused=False)
         return lambda: setattr(ops, "attn_bwd", orig)
+    if name == "ln_left_separate":      # round 5: the leftover rows' LayerNorm as its own launch again (what the fused row-statistics launch replaced)
+        o_stats, o_fold = ops.ln_row_stats, ops.gemm_lnfold
+
+        def stats(part, x, m_main, mean, rstd, eps=1e-5, **kw):
+            return o_stats(part, x, m_main, mean, rstd, eps)
+
+        def fold(*a, **kw):
+            kw["h_ready"] = False
+            return o_fold(*a, **kw)
+        ops.ln_row_stats, ops.gemm_lnfold = stats, fold
+        return lambda: (setattr(ops, "ln_row_stats", o_stats), setattr(ops, "gemm_lnfold", o_fold))
     raise SystemExit(f"unknown variant {name}")
 
 

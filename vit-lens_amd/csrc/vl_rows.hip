@@ -263,7 +263,8 @@ extern "C" int vl_layernorm_fwd(const void* x, int x_dtype, long x_row_stride, c
 // order: fixed), the remaining rows from the bf16 rows themselves (two-pass, as ln_rows_kernel).
 namespace {
 __global__ void __launch_bounds__(256) row_stats_kernel(const float* part, int P, const bf16_t* x, long xs, int D, int m_main,
-                                                        int rows, float eps, float* mean, float* rstd) {
+                                                        int rows, float eps, float* mean, float* rstd, const float* lw,
+                                                        const float* lb, bf16_t* y, long ys, int y_row0) {
   const int nb_main = (m_main + 255) >> 8;
   const float invD = 1.0f / (float)D;
   if ((int)blockIdx.x < nb_main) {
@@ -301,19 +302,28 @@ __global__ void __launch_bounds__(256) row_stats_kernel(const float* part, int P
   for (int e = lane; e < D; e += 64) { const float d = bf2f(xr[e]) - mu; q = fmaf(d, d, q); }
   const float rs = rsqrtf(wave_sum(q) * invD + eps);
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  // the leftover rows of the CONSUMING GEMM (rows >= y_row0) also get their LayerNorm output here: those rows run layernorm + a
+  // small-tile GEMM instead of the folded epilogue, and a separate 256-row LayerNorm launch per fold cost 8.6 us x 392 per C3 step
+  if (y && row >= y_row0) {
+    bf16_t* yr = y + (size_t)(row - y_row0) * ys;
+    for (int e = lane; e < D; e += 64) yr[e] = f2bf(fmaf((bf2f(xr[e]) - mu) * rs, lw[e], lb[e]));
+  }
 }
 }  // namespace
 
 extern "C" int vl_ln_row_stats(const float* row_part, int P, const void* x_bf16, long x_row_stride, int D, int m_main, int rows,
-                               float eps, float* mean, float* rstd, hipStream_t stream) {
+                               float eps, float* mean, float* rstd, const float* ln_w, const float* ln_b, void* y_left,
+                               long y_row_stride, int y_row0, hipStream_t stream) {
   if (rows <= 0 || D <= 0 || m_main < 0 || m_main > rows) return vl_set_error("vl_ln_row_stats: bad shape");
   if (m_main > 0 && (!row_part || P <= 0 || (((uintptr_t)row_part) & 7))) return vl_set_error("vl_ln_row_stats: partial statistics missing");
   if (m_main > 0 && P * 64 != D) return vl_set_error("vl_ln_row_stats: P must be D / 64 (one partial pair per 64-column slice of the row)");
   if (!mean || !rstd) return vl_set_error("vl_ln_row_stats: outputs missing");
   if (!x_bf16) return vl_set_error("vl_ln_row_stats: rows missing (the leftover rows and ill-conditioned rows are read from them)");
+  if (y_left && (!ln_w || !ln_b || y_row0 < m_main || y_row0 > rows || y_row_stride < D))
+    return vl_set_error("vl_ln_row_stats: y_left needs ln_w, ln_b, m_main <= y_row0 <= rows and a row stride >= D");
   const int nb = ((m_main + 255) >> 8) + (rows - m_main + 3) / 4;
   hipLaunchKernelGGL(row_stats_kernel, dim3(nb), dim3(256), 0, stream, row_part, P, (const bf16_t*)x_bf16, x_row_stride, D, m_main,
-                     rows, eps, mean, rstd);
+                     rows, eps, mean, rstd, ln_w, ln_b, (bf16_t*)y_left, y_row_stride, y_row0);
   VL_HIP_OK(hipGetLastError());
   return 0;
 }

@@ -33,7 +33,7 @@ SIGNATURES = {
     "vl_gemm_main_rows": [I, I],
     "vl_gemm_lnfold_bf16": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "vl_gemm_res_rowstats_bf16": [P, P, P, P, P, P, I, I, I, I, I, I, P],
-    "vl_ln_row_stats": [P, I, P, L, I, I, I, F, P, P, P],
+    "vl_ln_row_stats": [P, I, P, L, I, I, I, F, P, P, P, P, P, L, I, P],
     "vl_assemble_ln_pre": [P, I, P, P, P, P, P, P, I, P, P, P, I, I, I, F, P],
     "vl_l2_normalize": [P, P, P, P, I, I, F, P],
     "vl_l2_normalize_bwd": [P, P, P, P, I, I, F, P],

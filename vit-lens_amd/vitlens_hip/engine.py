@@ -137,14 +137,19 @@ def run_blocks(blocks, ws: _Workspace, B, L, D, H, causal=False, cfg=-1, fold=No
         fold = LN_FOLD
     if fold and ws.x.dtype == torch.bfloat16 and ws.part is not None and blocks and "in_f" in blocks[0]:
         mm = 0                                            # rows of ws.x whose partial sums are in ws.part
+        r_in, r_fc = ops.fold_rows(ws.x, ws.qkv, 3 * D), ops.fold_rows(ws.x, ws.hid, ws.hid.shape[1])
+        # (the row-statistics launch also writes the LayerNorm output of the consuming GEMM's leftover rows into ws.h)
         for w in blocks:
-            ops.ln_row_stats(ws.part, ws.x, mm, ws.mean, ws.rstd)
-            ops.gemm_lnfold(ws.x, w["in_f"], ws.mean, ws.rstd, ws.qkv, w["in_w"], w["in_b"], w["ln1_w"], w["ln1_b"], ws.h, cfg=cfg)
+            k_in = dict(ln_w=w["ln1_w"], ln_b=w["ln1_b"], h_left=ws.h, h_row0=r_in) if mm <= r_in else {}
+            ops.ln_row_stats(ws.part, ws.x, mm, ws.mean, ws.rstd, **k_in)
+            ops.gemm_lnfold(ws.x, w["in_f"], ws.mean, ws.rstd, ws.qkv, w["in_w"], w["in_b"], w["ln1_w"], w["ln1_b"], ws.h, cfg=cfg,
+                            h_ready=bool(k_in))
             ops.attn_fwd(ws.q, ws.k, ws.v, ws.a, causal=causal, qscale=dh ** -0.5 * ops.LOG2E)
             mm = ops.gemm_res_rowstats(ws.a, w["out_w"], w["out_b"], ws.x, ws.x, ws.part, cfg=cfg)
-            ops.ln_row_stats(ws.part, ws.x, mm, ws.mean, ws.rstd)
+            k_fc = dict(ln_w=w["ln2_w"], ln_b=w["ln2_b"], h_left=ws.h, h_row0=r_fc) if mm <= r_fc else {}
+            ops.ln_row_stats(ws.part, ws.x, mm, ws.mean, ws.rstd, **k_fc)
             ops.gemm_lnfold(ws.x, w["fc_f"], ws.mean, ws.rstd, ws.hid, w["fc_w"], w["fc_b"], w["ln2_w"], w["ln2_b"], ws.h,
-                            act=ops.ACT_GELU, cfg=cfg)
+                            act=ops.ACT_GELU, cfg=cfg, h_ready=bool(k_fc))
             mm = ops.gemm_res_rowstats(ws.hid, w["proj_w"], w["proj_b"], ws.x, ws.x, ws.part, cfg=cfg)
         return
     for w in blocks:

@@ -159,7 +159,7 @@ def fold_ln_linear(w, b, gamma, beta):
     w = w.detach().float()
     wg = (w * gamma.detach().float()[None, :]).to(torch.bfloat16).contiguous()
     c = wg.float().sum(1).contiguous()
-    d = (b.detach().float() + w @ beta.detach().float()).contiguous()
+    d = (b.detach().float() + (w * beta.detach().float()[None, :]).sum(1)).contiguous()       # (w @ beta without a BLAS call: build-time only)
     return wg, d, c
 
 
@@ -181,10 +181,11 @@ def _leftover_cfg(rows, N, cfg):
     return 11 if ((rows + 63) // 64) * ((N + 63) // 64) >= 192 else 9
 
 
-def gemm_lnfold(x, fold, mean, rstd, out, w, b, ln_w, ln_b, h_ws, act=ACT_NONE, out2=None, eps=1e-5, cfg=-1):
+def gemm_lnfold(x, fold, mean, rstd, out, w, b, ln_w, ln_b, h_ws, act=ACT_NONE, out2=None, eps=1e-5, cfg=-1, h_ready=False):
     """out = act(LN(x) @ w.T + b) with the LayerNorm folded into the GEMM's epilogue for the rows the persistent kernel takes
     (x raw bf16 rows, mean / rstd their statistics, fold = fold_ln_linear(...)); the leftover rows - and every row of a shape
-    that kernel refuses - go through layernorm + gemm on the plain operands (h_ws: a bf16 [>= leftover rows, K] buffer)."""
+    that kernel refuses - go through layernorm + gemm on the plain operands (h_ws: a bf16 [>= leftover rows, K] buffer;
+    h_ready: ln_row_stats(..., h_left=h_ws, h_row0=fold_rows(...)) already left their LayerNorm output there)."""
     wg, d, c = fold
     M, K = x.shape
     N = wg.shape[0]
@@ -195,7 +196,8 @@ def gemm_lnfold(x, fold, mean, rstd, out, w, b, ln_w, ln_b, h_ws, act=ACT_NONE, 
     if mm < M:
         r = M - mm
         h = h_ws[:r]
-        layernorm(x[mm:], ln_w, ln_b, h, r, K, x_row_stride=x.stride(0), mean=mean[mm:], rstd=rstd[mm:], eps=eps)
+        if not h_ready:
+            layernorm(x[mm:], ln_w, ln_b, h, r, K, x_row_stride=x.stride(0), mean=mean[mm:], rstd=rstd[mm:], eps=eps)
         gemm(h, w, b, out=out[mm:], epi=EPI_BF16, act=act, cfg=_leftover_cfg(r, N, cfg) if mm else cfg,
              out2=None if out2 is None else out2[mm:])
     return out
@@ -216,12 +218,22 @@ def gemm_res_rowstats(a, w, b, out, res, part, cfg=-1):
     return mm
 
 
-def ln_row_stats(part, x, m_main, mean, rstd, eps=1e-5):
+def fold_rows(x, out, N):
+    """Rows of `out = f(LN(x) @ W[N, K].T)` that gemm_lnfold runs through the folded epilogue (the others: layernorm + gemm)."""
+    return _fold_rows(x, out, N, x.shape[1])
+
+
+def ln_row_stats(part, x, m_main, mean, rstd, eps=1e-5, ln_w=None, ln_b=None, h_left=None, h_row0=None):
     """mean / rstd of the rows of x (bf16 [rows, D]): rows < m_main from the partial sums `part` of gemm_res_rowstats, the
-    others from the rows themselves."""
+    others from the rows themselves.  h_left (bf16 [>= rows - h_row0, D], with ln_w / ln_b): the LayerNorm output of the rows
+    >= h_row0 (the consuming gemm_lnfold's leftover rows, h_row0 = fold_rows(...) >= m_main) from the same launch."""
     rows, D = x.shape
+    if h_left is not None:
+        if h_row0 is None or h_row0 < m_main or h_left.dtype != torch.bfloat16 or h_left.shape[0] < rows - h_row0:
+            raise ValueError("ln_row_stats: h_left needs h_row0 >= m_main and a bf16 buffer of at least rows - h_row0 rows")
     check(_lib.vl_ln_row_stats(_p(part) if m_main else None, D // 64, _p(x), x.stride(0), D, m_main, rows, float(eps), _p(mean),
-                               _p(rstd), _stream()))
+                               _p(rstd), _p(ln_w), _p(ln_b), _p(h_left), h_left.stride(0) if h_left is not None else 0,
+                               int(h_row0 or 0), _stream()))
 
 
 def logits_gemm(xb, yb, scale):

@@ -171,13 +171,18 @@ class TowerTrainer:
             x0, x1 = S.X[2 * l], S.X[2 * l + 1]
             mm0 = S.part_rows if S.part_of is x0 else 0      # (a recompute in front of the backward finds none: from the rows)
             S.part_of = None
-            ops.ln_row_stats(S.part, x0, mm0, m1, r1)
-            ops.gemm_lnfold(x0, w["in_f"], m1, r1, S.qkv[l], w["in_w"], w["in_b"], w["ln1_w"], w["ln1_b"], S.h, cfg=cfg)
+            # (the row-statistics launch also leaves the LayerNorm output of the consuming GEMM's leftover rows in S.h)
+            r_in, r_fc = ops.fold_rows(x0, S.qkv[l], 3 * D), ops.fold_rows(x1, hid, hid.shape[1])
+            k_in = dict(ln_w=w["ln1_w"], ln_b=w["ln1_b"], h_left=S.h, h_row0=r_in) if mm0 <= r_in else {}
+            ops.ln_row_stats(S.part, x0, mm0, m1, r1, **k_in)
+            ops.gemm_lnfold(x0, w["in_f"], m1, r1, S.qkv[l], w["in_w"], w["in_b"], w["ln1_w"], w["ln1_b"], S.h, cfg=cfg,
+                            h_ready=bool(k_in))
             ops.attn_fwd(S.q[l], S.k[l], S.v[l], S.a[l], lse=S.lse[l], qscale=dh ** -0.5 * ops.LOG2E)
             mm = ops.gemm_res_rowstats(S.a[l], w["out_w"], w["out_b"], x1, x0, S.part, cfg=cfg)
-            ops.ln_row_stats(S.part, x1, mm, m2, r2)
+            k_fc = dict(ln_w=w["ln2_w"], ln_b=w["ln2_b"], h_left=S.h, h_row0=r_fc) if mm <= r_fc else {}
+            ops.ln_row_stats(S.part, x1, mm, m2, r2, **k_fc)
             ops.gemm_lnfold(x1, w["fc_f"], m2, r2, hid, w["fc_w"], w["fc_b"], w["ln2_w"], w["ln2_b"], S.h,
-                            act=ops.ACT_GELU_DSAVE, out2=S.u[l], cfg=cfg)
+                            act=ops.ACT_GELU_DSAVE, out2=S.u[l], cfg=cfg, h_ready=bool(k_fc))
         else:
             ops.layernorm(S.X[2 * l], w["ln1_w"], w["ln1_b"], h1, B * L, D, mean=m1, rstd=r1)
             ops.gemm(h1, w["in_w"], w["in_b"], out=S.qkv[l], epi=ops.EPI_BF16, cfg=cfg)
