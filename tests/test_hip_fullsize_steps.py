@@ -427,7 +427,7 @@ def test_c3_depth_backward_vitl_given_upstream_gradient(res_dtype):
         return st.grads[k]
     f32 = res_dtype == torch.float32
     _given_upstream(names, grads_of, ref_grads, "c3_given_upstream_" + ("f32" if f32 else "bf16"),
-                    tol=2e-2 if f32 else 4e-2, cos_min=0.9995 if f32 else 0.999)
+                    tol=1.5e-2 if f32 else 2.5e-2, cos_min=0.9995)      # measured 0.51-0.74e-2 (f32 stream), 0.90-1.33e-2 (bf16 stream), cosine >= 0.99992
 
 
 def test_c4_audio_backward_vitl_given_upstream_gradient():
@@ -467,4 +467,4 @@ def test_c4_audio_backward_vitl_given_upstream_gradient():
             ref = ref_grads[k]
             return st.grads[k + "_gemm"][:, :ref[0].numel()].reshape(ref.shape)
         return st.grads[k]
-    _given_upstream(names, grads_of, ref_grads, "c4_given_upstream", tol=2e-2, cos_min=0.9995)
+    _given_upstream(names, grads_of, ref_grads, "c4_given_upstream", tol=1.5e-2, cos_min=0.9995)      # measured 0.44-0.80e-2, cosine >= 0.99997
