@@ -87,3 +87,20 @@ if os.environ.get("LNFOLD", "1") != "0":
         xo = torch.empty_like(x)
         _prof(name + " plain", lambda: ops.gemm(a, w, b, out=xo, res=x, epi=ops.EPI_RES_BF16, cfg=8), T, D, K)
         _prof(name + " + row sums", lambda: ops.gemm_res_rowstats(a, w, b, xo, x, part), T, D, K)
+
+
+# ---- round 5: what makes the k-step of the K = 4096 launches 15 % slower than at K = 1024?  (KSTEP=1 python tools/gemm_phase_prof.py) ----
+if os.environ.get("KSTEP", "0") != "0":
+    def case(name, M, N, K, pad=0):
+        buf = torch.empty(M, K + pad, device="cuda", dtype=torch.bfloat16); a = buf[:, :K]; a.copy_(torch.randn(M, K, device="cuda").bfloat16())
+        wb = torch.empty(N, K + pad, device="cuda", dtype=torch.bfloat16); w = wb[:, :K]; w.copy_((torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16())
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        _prof(name, lambda: ops.gemm(a, w, None, out=out, epi=ops.EPI_BF16, cfg=8), M, N, K)
+    case("K=1024 N=1024", T, 1024, 1024)
+    case("K=2048 N=1024", T, 1024, 2048)
+    case("K=4096 N=1024", T, 1024, 4096)
+    case("K=4096 N=1024 rows + 64", T, 1024, 4096, pad=64)
+    case("K=4096 N=4096", T, 4096, 4096)
+    case("K=4096 N=1024 M=16384 (A in MALL)", 16384, 1024, 4096)
+    case("K=8192 N=1024 M=16384", 16384, 1024, 8192)
+    case("K=1024 N=4096", T, 4096, 1024)
