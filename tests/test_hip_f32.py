@@ -113,3 +113,22 @@ def test_depth_lens_identity_perceiver_in_fp32():
     got = eng.encode(ins["visual_x"].cuda())
     ref = O.encode_visual(sd, ins["visual_x"], tower, lens)
     assert relerr(got, ref) < 1e-5, relerr(got, ref)
+
+
+def test_vitl14_towers_in_fp32_arithmetic():
+    """The fp32 executors at the geometry BASELINE.json's metric is quoted on: ViT-L/14 image tower (24 x 1024, 257 tokens) and
+    the ViT-L text tower (12 x 768, 77 tokens, causal) against the fp32 oracle - features within 1e-5 relative."""
+    from vitlens_hip import engine as E, f32 as F
+    g = torch.Generator().manual_seed(7)
+    spec = O.TowerSpec()
+    sd = O.init_tower(spec, g, "image.")
+    image = torch.randn(2, 3, 224, 224, generator=g)
+    ref = O.encode_image(sd, image, spec)
+    got = F.VitEngineF32(sd, "image.", E.TowerCfg(), "cuda").encode(image.cuda())
+    ei = relerr(got, ref)
+    tspec = O.TextSpec()
+    sdt = O.init_text(tspec, g)
+    text = O.synth_text(4, g)
+    et = relerr(F.TextEngineF32(sdt, E.TextCfg(), "cuda").encode_text(text.cuda()), O.encode_text(sdt, text, tspec))
+    print(f"fp32 arithmetic, ViT-L/14: image features {ei:.2e}, text features {et:.2e} relative to the fp32 CPU path")
+    assert ei < 1e-5 and et < 1e-5, (ei, et)
