@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--ln-fold", default=None, choices=["on", "off"],
                     help="LayerNorms of the frozen ViT blocks folded into the GEMMs either side of them (on) or run as their own "
                          "passes (off); default: the library's (on since round 5)")
+    ap.add_argument("--overlap-frozen", action="store_true",
+                    help="EXPERIMENT (c3): the frozen image / text towers' forwards on a second HIP stream beside the trainable tower's "
+                         "forward (the per-launch GEMM timings of the forward are then no longer those of a launch that owns the chip)")
     ap.add_argument("--force-dist", action="store_true",
                     help="--gpus 1 only: initialise a ONE-rank RCCL communicator and run the step's multi-rank code path on it "
                          "(packed all-gather, bucketed async all-reduce; prints collective_ms_per_step) - the API / stream "
@@ -621,7 +624,7 @@ def main():
         texts = synth_text(a.batch, g).to(dev)
         trainer = vstep.TriModalDepthStep(sd, engine.TowerCfg(), engine.TextCfg(), dev, micro_batch=a.micro_batch,
                                           unlock_first_n=4, rank=rank, world_size=world, gemm_cfg=a.gemm_cfg, frozen_res_dtype=res_dtype, train_res_dtype=res_dtype, comm=comm,
-                                          force_comm=a.force_dist, text_arith=a.text_arith)
+                                          force_comm=a.force_dist, text_arith=a.text_arith, overlap_frozen=a.overlap_frozen)
 
         def step():
             return trainer.step(images, texts, depths)
@@ -706,6 +709,8 @@ def main():
                           "layernorm": "folded into the GEMMs (frozen blocks)" if LN_FOLDED else "own passes",
                           **({"force_dist": True} if a.force_dist else {})},
                "roofline": roof}
+        if a.workload != "c2":
+            out["final_loss"] = round(out_loss, 6)      # of the last timed step: the same for every launch configuration of one tree
         if use_dist:         # diagnosis of a scaling run: per-rank step time (stragglers) and the exchange's share of the step
             out["per_rank_ms_per_step"] = per_rank_ms
             out["collective_ms_per_step"] = coll

@@ -285,8 +285,13 @@ class TriModalDepthStep(_StepState):
                  unlock_first_n: int = 4, lr: float = 5e-4, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2,
                  rank: int = 0, world_size: int = 1, gemm_cfg: int = -1, comm=None, frozen_res_dtype=torch.float32,
                  local_loss: bool = False, gather_with_grad: bool = False, train_res_dtype=torch.float32,
-                 grad_checkpointing: bool = False, force_comm: bool = False, text_wsplit: Optional[bool] = None, text_arith: str = "f16"):
+                 grad_checkpointing: bool = False, force_comm: bool = False, text_wsplit: Optional[bool] = None, text_arith: str = "f16",
+                 overlap_frozen: bool = False):
         self.dev, self.mb, self.rank, self.world = torch.device(device), micro_batch, rank, world_size
+        # EXPERIMENT (default off): the two frozen towers' forwards on a second HIP stream beside the trainable
+        # tower's forward - independent work whose low-power phases (attention, LayerNorm) could fill the other's GEMM phases
+        self.overlap_frozen = bool(overlap_frozen)
+        self._side = None
         # the multi-rank path (packed all-gather, bucketed async all-reduce, optional reduce-scatter) runs when there are
         # peers - or when asked for on ONE rank, so that the RCCL calls execute on a single GPU (tests, bench --force-dist)
         self._force_comm = bool(force_comm)
@@ -443,11 +448,29 @@ class TriModalDepthStep(_StepState):
         vnorm = torch.empty(B, device=self.dev)
         # the frozen text tower sees the whole per-GPU batch in one pass: 77-token sequences give a micro-batch only 77 row
         # tiles (one uneven round of the persistent GEMM, 600-900 TF/s); four times the rows run whole rounds
-        ops.l2_normalize(self.text.encode_text(texts), out=ft)
-        for i in range(nmb):
-            s = slice(i * mb, (i + 1) * mb)
-            ops.l2_normalize(self.image.encode_image(images[s]), out=fi[s])
-            vraw[s] = self._trainer(i).forward(depths[s])
+        if self.overlap_frozen:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.dev)
+            main = torch.cuda.current_stream()
+            ready, done = torch.cuda.Event(), torch.cuda.Event()
+            ready.record(main)
+            self._side.wait_event(ready)                  # inputs and output buffers exist
+            with torch.cuda.stream(self._side):
+                ops.l2_normalize(self.text.encode_text(texts), out=ft)
+                for i in range(nmb):
+                    s = slice(i * mb, (i + 1) * mb)
+                    ops.l2_normalize(self.image.encode_image(images[s]), out=fi[s])
+                done.record(self._side)
+            for i in range(nmb):
+                s = slice(i * mb, (i + 1) * mb)
+                vraw[s] = self._trainer(i).forward(depths[s])
+            main.wait_event(done)
+        else:
+            ops.l2_normalize(self.text.encode_text(texts), out=ft)
+            for i in range(nmb):
+                s = slice(i * mb, (i + 1) * mb)
+                ops.l2_normalize(self.image.encode_image(images[s]), out=fi[s])
+                vraw[s] = self._trainer(i).forward(depths[s])
         ops.l2_normalize(vraw, out=fv, norms=vnorm)
         scale = self.logit_scale          # the log-temperature, on the device: exp() is applied inside the loss section
         if self.dist:
