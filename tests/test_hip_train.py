@@ -325,6 +325,35 @@ def test_tri_modal_step_matches_reference_step(res_dtype):
     assert torch.isfinite(loss2) and float(loss2) < float(loss) + 1e-3
 
 
+def test_tri_modal_step_with_the_frozen_towers_on_a_second_stream():
+    """`TriModalDepthStep(overlap_frozen=True)` (experiment switch, default off): the image / text towers' forwards run on a
+    second HIP stream beside the trainable tower's forward.  Same kernels, same operands: loss, every gradient and the masters
+    after the optimizer step are BIT-equal to the serial step, over several steps (a missing event would show as a stale or
+    half-written feature)."""
+    from vitlens_hip import engine as E, step as ST
+    sd, ins, outs, grads, tc, lc = _tiny_depth()
+    _, _, _, _, meta = split(load_npz("tiny_depth.npz"))
+    _, text, _ = specs_from_meta(meta)
+    xc = E.TextCfg(context_length=text.context_length, vocab_size=text.vocab_size, width=text.width, heads=text.heads,
+                   layers=text.layers, embed_dim=text.embed_dim)
+    img, txt, dep = ins["image"].cuda(), ins["text"].cuda(), ins["visual_x"].cuda()
+    runs = {}
+    for overlap in (False, True):
+        st = ST.TriModalDepthStep(sd, tc, xc, "cuda", micro_batch=2, unlock_first_n=1, lr=1e-3, overlap_frozen=overlap)
+        losses = []
+        for it in range(4):
+            losses.append(float(st.forward_backward(img, txt, dep)))
+            g = {k: v.clone() for k, v in st.grads.items()} if it == 0 else g
+            st.optimizer_step()
+        torch.cuda.synchronize()
+        runs[overlap] = (losses, g, {k: v.clone() for k, v in st.masters.items()})
+    assert runs[True][0] == runs[False][0], (runs[True][0], runs[False][0])
+    for k in runs[False][1]:
+        assert torch.equal(runs[True][1][k], runs[False][1][k]), k
+    for k in runs[False][2]:
+        assert torch.equal(runs[True][2][k], runs[False][2][k]), k
+
+
 @pytest.mark.parametrize("recipe", ["depth", "audio", "pc"])
 def test_step_checkpoint_export_reload_and_resume(recipe):
     """Train one step with a fused step object, export `state_dict()` (reference names / layouts: conv weight un-padded,
