@@ -68,9 +68,14 @@ def parse():
     ap.add_argument("--ln-fold", default=None, choices=["on", "off"],
                     help="LayerNorms of the frozen ViT blocks folded into the GEMMs either side of them (on) or run as their own "
                          "passes (off); default: the library's (on since round 5)")
-    ap.add_argument("--overlap-frozen", action="store_true",
-                    help="EXPERIMENT (c3): the frozen image / text towers' forwards on a second HIP stream beside the trainable tower's "
-                         "forward (the per-launch GEMM timings of the forward are then no longer those of a launch that owns the chip)")
+    ap.add_argument("--no-overlap-frozen", dest="overlap_frozen", action="store_false", default=True,
+                    help="c3 / c4 / c5: run the frozen image / text towers' forwards in the launch stream instead of on a second HIP "
+                         "stream beside the trainable tower's forward (the product default since round 6: -1.35 %% per C3 step, "
+                         "bit-equal results).  With the overlap on, `value` / `ms_per_step` are measured on that default path and "
+                         "the per-launch `roofline` figures come from a short SERIAL pass after the timed region (a launch's "
+                         "HIP-event duration only measures that launch when it owns the chip); `roofline.measured_on` says which")
+    ap.add_argument("--overlap-frozen", dest="overlap_frozen", action="store_true", help="(round-5 spelling; now the default)")
+    ap.add_argument("--serial-steps", type=int, default=2, help="steps of the serial roofline pass (overlap on only)")
     ap.add_argument("--force-dist", action="store_true",
                     help="--gpus 1 only: initialise a ONE-rank RCCL communicator and run the step's multi-rank code path on it "
                          "(packed all-gather, bucketed async all-reduce; prints collective_ms_per_step) - the API / stream "
@@ -261,21 +266,6 @@ def pmc_mfma_busy(dom):
             return {"mfma_busy_frac_cycles": k["mfma_busy_frac"], "wait_any_frac": k["wait_any_frac"], "kernel_cycles": k["kernel_cycles"],
                     "kernel": key, "source": "profiles/" + src}
         except (OSError, ValueError, KeyError, TypeError):
-            continue
-    return None
-
-
-def leftover_launch_ms(dom):
-    """Average duration of the leftover-row launch that follows the dominant persistent launch, from the committed rocprofv3
-    kernel statistics of this command (the bench's HIP events bracket both launches).  None: no statistics committed."""
-    import csv
-    name = f"gemm_tail_kernel<{dom['epi']}>"
-    for src in ("r05_bench_c3_kernel_stats.csv", "r04_bench_c3_kernel_stats.csv"):
-        try:
-            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", src))):
-                if name in r["Name"]:
-                    return float(r["AverageNs"]) * 1e-6
-        except (OSError, ValueError, KeyError):
             continue
     return None
 
@@ -575,7 +565,7 @@ def main():
             audio = (torch.randn(a.batch, 512, 128, generator=g) * 0.5).to(dev)
             trainer = vstep.DualAudioStep(sd, tower_cfg, engine.TextCfg(), lens_cfg, dev, micro_batch=a.micro_batch,
                                           rank=rank, world_size=world, gemm_cfg=a.gemm_cfg, frozen_res_dtype=res_dtype, train_res_dtype=res_dtype, comm=comm,
-                                          force_comm=a.force_dist, text_arith=a.text_arith)
+                                          force_comm=a.force_dist, text_arith=a.text_arith, overlap_frozen=a.overlap_frozen)
 
             def step():
                 return trainer.step(audio, texts)
@@ -586,7 +576,7 @@ def main():
             start = torch.randint(0, 8192, (a.batch,), generator=g).to(dev)
             trainer = vstep.TriModalPCStep(sd, tower_cfg, engine.TextCfg(), lens_cfg, dev, micro_batch=a.micro_batch,
                                            rank=rank, world_size=world, gemm_cfg=a.gemm_cfg, bn_training=True, frozen_res_dtype=res_dtype, train_res_dtype=res_dtype, comm=comm,
-                                           bn_sync=a.bn_sync, force_comm=a.force_dist, text_arith=a.text_arith)
+                                           bn_sync=a.bn_sync, force_comm=a.force_dist, text_arith=a.text_arith, overlap_frozen=a.overlap_frozen)
 
             def step():
                 return trainer.step(images, texts, pts, start)
@@ -629,13 +619,15 @@ def main():
         def step():
             return trainer.step(images, texts, depths)
 
+    trainer_obj = locals().get("trainer")
+    overlapped = bool(trainer_obj is not None and getattr(trainer_obj, "_overlap_active", False))
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.on = True
+    timer.on = not overlapped          # two towers sharing the chip: per-launch events are taken in the serial pass below
     if comm is not None:
         comm.on = True
     t0 = time.perf_counter()
@@ -647,9 +639,24 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timer.on = False
+    if comm is not None:
+        comm.on = False
+    serial_ms = None
+    if overlapped:
+        # per-launch roofline figures: the SAME step with the frozen towers in the launch stream, outside the timed region
+        # (`value` / `ms_per_step` above are the default, overlapped path); every rank runs it - the step has collectives
+        trainer_obj.overlap_frozen = False
+        step(); torch.cuda.synchronize()
+        timer.on = True
+        ts = time.perf_counter()
+        for _ in range(max(1, a.serial_steps)):
+            step()
+        torch.cuda.synchronize()
+        serial_ms = (time.perf_counter() - ts) / max(1, a.serial_steps) * 1e3
+        timer.on = False
+        trainer_obj.overlap_frozen = True
     per_rank_ms, coll = None, None
     if use_dist:
-        comm.on = False
         coll = comm.summary(a.steps)
         allt = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(allt, torch.tensor([dt], device=dev, dtype=torch.float64))
@@ -668,26 +675,33 @@ def main():
         tot_fl = sum(s["flops_per_launch"] * s["launches"] for s in shapes)
         tot_ms = sum(s["avg_ms"] * s["launches"] for s in shapes)
         roof = None
+        gemm_steps = max(1, a.serial_steps) if overlapped else a.steps       # steps the GEMM records cover
+        gemm_step_ms = serial_ms if overlapped else ms
         if dom:
             ach = dom["tflops"]
+            pm = pmc_mfma_busy(dom)
             roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": hbm_traffic(dom), "pmc": pmc_mfma_busy(dom),
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": hbm_traffic(dom),
                     "kernel": (f"vl_gemm_bf16_ex M={dom['M']} N={dom['N']} K={dom['K']} epi={dom['epi']} act={dom['act']} "
                                "(gemm_nt_pk_kernel<EPI,ACT>, the persistent 256x256 kernel, on the whole rounds of row tiles + "
                                "gemm_tail_kernel<EPI> on the leftover 256 rows; avg_launch_ms covers both launches)"),
                     "avg_launch_ms": round(dom["avg_ms"], 4), "flops_per_launch": dom["flops_per_launch"],
                     "all_gemm_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
                     "all_gemm_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-                    "gemm_share_of_step": round(tot_ms / (ms * a.steps), 4),
+                    "gemm_share_of_step": round(tot_ms / (gemm_step_ms * gemm_steps), 4),
                     "step_tflops": round(gf_unit * a.batch / (ms * 1e-3) / 1e3, 1),
-                    "step_frac": round(gf_unit * a.batch / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS, 4)}
-            # the clock the fraction was achieved at: cycles of the persistent launch (SQ counters, committed) / its duration in THIS
-            # run (events minus the leftover-row launch they also bracket, committed kernel statistics)
-            pm, lo = roof["pmc"], leftover_launch_ms(dom)
-            if pm and lo is not None and dom["avg_ms"] > lo:
-                roof["effective_clock_ghz"] = round(pm["kernel_cycles"] / ((dom["avg_ms"] - lo) * 1e-3) / 1e9, 3)
-                roof["effective_clock_note"] = ("kernel cycles (profiles SQ pass, M = 65 536 rows) / (avg_launch_ms - leftover-row launch "
-                                                f"{lo:.4f} ms from the committed kernel statistics); board limit 1 400 W: profiles/r05_power_trace.log")
+                    "step_frac": round(gf_unit * a.batch / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS, 4),
+                    # provenance, field by field: what THIS process measured on THIS box, and what is read from files
+                    # committed under profiles/ (PMC passes cannot run inside the timed process)
+                    "measured_on": (f"serial pass: {gemm_steps} step(s) after the timed region with the frozen towers in the launch "
+                                    f"stream ({serial_ms:.1f} ms/step there); HIP events on the launch stream, this run, this box"
+                                    if overlapped else "timed region: HIP events on the launch stream, this run, this box"),
+                    "measured_in_this_run": ["achieved", "frac", "avg_launch_ms", "all_gemm_tflops", "all_gemm_frac",
+                                             "gemm_share_of_step", "step_tflops", "step_frac"],
+                    "from_committed_profiles": {"fields": ["traffic", "pmc"],
+                                                "note": "builder's rocprofv3 PMC passes over this command on an earlier box; "
+                                                        "NOT measured by this run"},
+                    "pmc": pm}
         out = {"metric": "modality-pairs/sec (ViT-L, 224^2 patches)", "value": round(value, 2),
                "unit": "modality-pairs/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -707,6 +721,7 @@ def main():
                           "accumulate": "fp32", "parallelism": f"dp{world}", "gemm_cfg": a.gemm_cfg, "via": a.via,
                           "text_tower_operands": {"f16": "fp16", "bf16x2": "bf16 x 2 weight terms", "bf16": "bf16"}[a.text_arith] if a.workload != "c2" else "n/a",
                           "layernorm": "folded into the GEMMs (frozen blocks)" if LN_FOLDED else "own passes",
+                          "frozen_towers": ("second HIP stream beside the trainable tower's forward" if overlapped else "launch stream"),
                           **({"force_dist": True} if a.force_dist else {})},
                "roofline": roof}
         if a.workload != "c2":

@@ -82,8 +82,8 @@ def test_traffic_summary_tells_two_gemm_shapes_of_one_kernel_apart(tmp_path):
 def test_committed_counter_summary_is_found_under_the_round5_kernel_names():
     """`roofline.pmc`: with the LayerNorm folding on (the default) the dominant c_proj launches are the row-statistics
     instantiation `gemm_nt_pk_kernel<3, 20, false>` (third template parameter: fp16 operands, false); the round-5 counter file
-    is preferred, and a shape without a committed pass yields None.  `effective_clock_ghz` needs the leftover-row launch's
-    average from the committed kernel statistics."""
+    is preferred, and a shape without a committed pass yields None.  (The derived `effective_clock_ghz` left the bench line
+    in round 6: it mixed this run's event times with cycles and launch durations from committed files.)"""
     import bench
     dom = {"M": 65792, "N": 1024, "K": 4096, "epi": 3, "act": 0, "avg_ms": 0.4664}
     bench.LN_FOLDED = True
@@ -94,7 +94,4 @@ def test_committed_counter_summary_is_found_under_the_round5_kernel_names():
     assert bench.pmc_mfma_busy(dom)["kernel"] == "gemm_nt_pk_kernel<3, 0, false>"
     bench.LN_FOLDED = True
     assert bench.pmc_mfma_busy({"N": 5, "K": 7, "epi": 0, "act": 0}) is None
-    lo = bench.leftover_launch_ms(dom)
-    assert lo is not None and 0.005 < lo < 0.05
-    clock = p["kernel_cycles"] / ((dom["avg_ms"] - lo) * 1e-3) / 1e9
-    assert 1.2 < clock < 2.4            # the GEMM runs at the board's power limit, below the 2.4 GHz of the peak figure
+    assert not hasattr(bench, "leftover_launch_ms")

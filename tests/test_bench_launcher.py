@@ -37,6 +37,16 @@ def test_plain_invocation_spawns_n_ranks():
     assert 0.0 < j["collective_share"] <= 1.0
 
 
+def test_plain_invocation_spawns_8_ranks():
+    """The node size of BASELINE.json (8 ranks) through the same launcher path, CPU + gloo."""
+    p = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--workload", "selftest"], timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    (j,) = _json_lines(p.stdout)
+    assert j["n_gpus"] == 8 and len(j["per_rank_ms_per_step"]) == 8 and j["config"]["parallelism"] == "dp8"
+    assert j["ms_per_step"] == pytest.approx(max(j["per_rank_ms_per_step"]), rel=1e-6)
+    assert set(j["collective_ms_per_step"]) == {"all_gather", "all_reduce"}
+
+
 def test_single_gpu_default_does_not_spawn():
     p = _run(["--steps", "2", "--warmup", "1", "--workload", "selftest"])
     assert p.returncode == 0, p.stderr[-2000:]

@@ -325,24 +325,41 @@ def test_tri_modal_step_matches_reference_step(res_dtype):
     assert torch.isfinite(loss2) and float(loss2) < float(loss) + 1e-3
 
 
-def test_tri_modal_step_with_the_frozen_towers_on_a_second_stream():
-    """`TriModalDepthStep(overlap_frozen=True)` (experiment switch, default off): the image / text towers' forwards run on a
-    second HIP stream beside the trainable tower's forward.  Same kernels, same operands: loss, every gradient and the masters
-    after the optimizer step are BIT-equal to the serial step, over several steps (a missing event would show as a stale or
-    half-written feature)."""
+@pytest.mark.parametrize("recipe", ["depth", "audio", "pc"])
+def test_steps_with_the_frozen_towers_on_a_second_stream(recipe):
+    """`overlap_frozen=True` (the steps' default since round 6): the frozen image / text towers' forwards run on a second HIP
+    stream beside the trainable tower's forward.  Same kernels, same operands: loss, every gradient and the masters after
+    the optimizer step are BIT-equal to the serial step, over several steps (a missing event would show as a stale or
+    half-written feature) - for the depth (C3), audio (C4) and point-cloud (C5) steps."""
+    import importlib, json, os, sys, tempfile
+    from types import SimpleNamespace
     from vitlens_hip import engine as E, step as ST
-    sd, ins, outs, grads, tc, lc = _tiny_depth()
-    _, _, _, _, meta = split(load_npz("tiny_depth.npz"))
-    _, text, _ = specs_from_meta(meta)
+    sd, ins, outs, grads, meta = split(load_npz(f"tiny_{recipe}.npz"))
+    tower, text, lens = specs_from_meta(meta)
+    tc = E.TowerCfg(width=tower.width, layers=tower.layers, heads=tower.heads, patch=tower.patch, image_size=tower.image_size,
+                    embed_dim=tower.embed_dim)
     xc = E.TextCfg(context_length=text.context_length, vocab_size=text.vocab_size, width=text.width, heads=text.heads,
                    layers=text.layers, embed_dim=text.embed_dim)
-    img, txt, dep = ins["image"].cuda(), ins["text"].cuda(), ins["visual_x"].cuda()
+    lc = E.LensCfg(**{k: getattr(lens, k) for k in E.LensCfg.__dataclass_fields__ if hasattr(lens, k)})
+    img, txt, vis = ins["image"].cuda(), ins["text"].cuda(), ins["visual_x"].cuda()
+
+    def make(overlap):
+        if recipe == "depth":
+            st = ST.TriModalDepthStep(sd, tc, xc, "cuda", micro_batch=2, unlock_first_n=1, lr=1e-3, overlap_frozen=overlap)
+            return st, lambda: st.forward_backward(img, txt, vis)
+        if recipe == "audio":
+            st = ST.DualAudioStep(sd, tc, xc, lc, "cuda", micro_batch=2, lr=1e-3, overlap_frozen=overlap)
+            return st, lambda: st.forward_backward(vis, txt)
+        st = ST.TriModalPCStep(sd, tc, xc, lc, "cuda", micro_batch=4, lr=1e-3, bn_training=True, overlap_frozen=overlap)
+        return st, lambda: st.forward_backward(img, txt, vis, ins["fps_start"].cuda())
+    assert make(True)[0]._overlap_active and not make(False)[0]._overlap_active
+    assert ST.TriModalDepthStep(sd, tc, xc, "cuda", micro_batch=2, unlock_first_n=1).overlap_frozen, "overlap is the default"
     runs = {}
     for overlap in (False, True):
-        st = ST.TriModalDepthStep(sd, tc, xc, "cuda", micro_batch=2, unlock_first_n=1, lr=1e-3, overlap_frozen=overlap)
+        st, fb = make(overlap)
         losses = []
         for it in range(4):
-            losses.append(float(st.forward_backward(img, txt, dep)))
+            losses.append(float(fb()))
             g = {k: v.clone() for k, v in st.grads.items()} if it == 0 else g
             st.optimizer_step()
         torch.cuda.synchronize()
@@ -352,6 +369,45 @@ def test_tri_modal_step_with_the_frozen_towers_on_a_second_stream():
         assert torch.equal(runs[True][1][k], runs[False][1][k]), k
     for k in runs[False][2]:
         assert torch.equal(runs[True][2][k], runs[False][2][k]), k
+
+
+def test_trained_blocks_carry_no_stale_layernorm_folds():
+    """Advisor finding of round 5: with LayerNorm folding on, `prep_block` builds folded operands (bf16(W*gamma), b + W.beta,
+    row sums) for EVERY block of the trainable tower - and an AdamW step moves W, gamma and beta of the unlocked blocks, so an
+    inference through the step's own engine on a bf16 stream (`st.lens.encode`) used the construction-time folds for exactly
+    the blocks that were trained.  Now a fused step strips the folded operands from the blocks it trains and `run_blocks`
+    decides per block.  Width 512 on a bf16 stream = the folded path really runs for the frozen blocks (K >= 512); after
+    three steps at a large learning rate the step's engine must agree with a FRESH engine built from `st.state_dict()`."""
+    from vitlens_hip import engine as E, step as ST
+    assert E.LN_FOLD
+    g = torch.Generator().manual_seed(5)
+    tspec = O.TowerSpec(width=512, layers=3, heads=8, patch=14, image_size=224, embed_dim=256)
+    xspec = O.TextSpec(context_length=16, vocab_size=300, width=512, heads=8, layers=1, embed_dim=256)
+    sd = O.init_tower(tspec, g, "image.")
+    sd.update(O.init_tower(tspec, g, "visual."))
+    sd.pop("visual.conv1.weight")
+    sd.update(O.init_text(xspec, g))
+    sd["visual.visual_adapter.conv1.weight"] = (torch.rand(512, 1, 14, 14, generator=g) * 2 - 1) / 14.0
+    sd["visual.visual_adapter.pos_emb"] = torch.randn(256, 512, generator=g) * 512 ** -0.5
+    sd["logit_scale"] = torch.tensor(2.659)
+    tc = E.TowerCfg(width=512, layers=3, heads=8, embed_dim=256)
+    xc = E.TextCfg(context_length=16, vocab_size=300, width=512, heads=8, layers=1, embed_dim=256)
+    B = 4
+    img = torch.randn(B, 3, 224, 224, generator=g).cuda(); dep = torch.randn(B, 1, 224, 224, generator=g).cuda()
+    txt = torch.randint(1, 298, (B, 16), generator=g); txt[:, 7] = 299; txt = txt.cuda()
+    st = ST.TriModalDepthStep(sd, tc, xc, "cuda", micro_batch=B, unlock_first_n=2, lr=2e-2, train_res_dtype=torch.bfloat16,
+                              frozen_res_dtype=torch.bfloat16)
+    assert all("in_f" not in st.lens.vit.blocks[l] for l in range(2)) and "in_f" in st.lens.vit.blocks[2]
+    f0 = st.lens.encode(dep, normalize=True).clone()
+    for _ in range(3):
+        st.step(img, txt, dep)
+    got = st.lens.encode(dep, normalize=True)
+    assert relerr(got, f0) > 5e-2, "the steps did not move the tower: the test would prove nothing"
+    fresh = E.LensEngine(st.state_dict(), "visual.", tc, E.LensCfg(modality="depth", perceiver_identity=True), "cuda",
+                         res_dtype=torch.bfloat16)
+    assert "in_f" in fresh.vit.blocks[0]                      # the fresh engine folds all three blocks (from the trained weights)
+    want = fresh.encode(dep, normalize=True)
+    assert relerr(got, want) < 2e-2, relerr(got, want)       # folded vs unfolded LayerNorm of the same weights: bf16 noise only
 
 
 @pytest.mark.parametrize("recipe", ["depth", "audio", "pc"])

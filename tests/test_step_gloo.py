@@ -140,7 +140,7 @@ class _Rec:
         self.log.append(("reduce_scatter", tuple(inp.shape))); self.inner.reduce_scatter_sum(out, inp)
 
 
-def _worker(rank, world, port, recipe, local_loss, gwg, ret):
+def _worker(rank, world, port, recipe, local_loss, gwg, ret, overlap=False):
     sys.path.insert(0, os.path.join(ROOT, "vit-lens_amd"))
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -155,36 +155,49 @@ def _worker(rank, world, port, recipe, local_loss, gwg, ret):
     mine = {k: v[rank * b:(rank + 1) * b] for k, v in X.items()}
     comm = _Rec(ST.TorchComm())
     errs = []
+    sd0 = {"logit_scale": torch.tensor(2.0).log()}              # the parameter is log(scale) (model.py:446,619)
+
+    # The objects under test are the PRODUCT classes, constructed by their own __init__ (-> _StepState._init_host: flags,
+    # communicator, master table, bucket bookkeeping, optimizer); only the engine-building hook `_build`, the trainer factory
+    # and the bf16 operand refresh are replaced by the linear stand-ins above.
+    class _HostMixin:
+        def _trainer(self, i):
+            while len(self.trainers) <= i:
+                self.trainers.append(self._mk())
+            return self.trainers[i]
+
+        def _refresh_operands(self):
+            pass
+
+    class DepthHost(_HostMixin, ST.TriModalDepthStep):
+        def _build(self, sd, tower, text, **kw):
+            self.image, self.text = _Frozen(Wi), _Frozen(Wt)
+            for l in range(self.unlock_first_n):
+                self.masters[f"visual.transformer.resblocks.{l}.mlp.c_fc.weight"] = torch.zeros(3, 5)
+            self.masters["visual.W"] = Wv.clone()
+            self._mk = lambda: _LinearTower(self.masters["visual.W"], self.grads, "visual.W", self.unlock_first_n)
+
+    class AudioHost(_HostMixin, ST.DualAudioStep):
+        def _build(self, sd, tower, text, lens, **kw):
+            self.text = _Frozen(Wt)
+            self.lens = types.SimpleNamespace(tower=types.SimpleNamespace(embed_dim=E_DIM))
+            self.masters["visual.W"] = Wv.clone()
+            self._mk = lambda: _LinearTower(self.masters["visual.W"], self.grads, "visual.W")
+
+        def _bind_grads(self, t):
+            t.grads = self.grads
+
+    kw = dict(micro_batch=2, lr=1e-2, rank=rank, world_size=world, comm=comm, local_loss=local_loss, gather_with_grad=gwg,
+              overlap_frozen=overlap)
     if recipe == "depth":
-        st = ST.TriModalDepthStep.__new__(ST.TriModalDepthStep)
-        st.dev, st.mb, st.rank, st.world = torch.device("cpu"), 2, rank, world
-        st.comm, st.local_loss, st.gather_with_grad = comm, local_loss, gwg
-        st.image, st.text = _Frozen(Wi), _Frozen(Wt)
-        st.unlock_first_n = nblk
-        st.logit_scale = torch.tensor([2.0]).log()              # the parameter is log(scale) (model.py:446,619)
-        st.masters = {"logit_scale": st.logit_scale}
-        for l in range(nblk):
-            st.masters[f"visual.transformer.resblocks.{l}.mlp.c_fc.weight"] = torch.zeros(3, 5)
-        st.masters["visual.W"] = Wv.clone()
-        st.bf16_targets, st.trainers, st.flat_grad, st.grads = {}, [], None, {}
-        st._pending, st._reduced_upto, st._reduce_done = [], None, False
-        st.opt = TR.AdamW(st.masters, lr=1e-2)
-        st._trainer = lambda i: st.trainers[i] if i < len(st.trainers) else (st.trainers.append(
-            _LinearTower(st.masters["visual.W"], st.grads, "visual.W", nblk)) or st.trainers[i])
-        st._refresh_operands = lambda: None
+        st = DepthHost(sd0, None, None, "cpu", unlock_first_n=nblk, **kw)
+        # a CPU device cannot run a second HIP stream: the request is recorded, the schedule is the serial one
+        if st.overlap_frozen != overlap or st._overlap_active:
+            errs.append(f"overlap_frozen={st.overlap_frozen} active={st._overlap_active} on a CPU device")
         loss = st.forward_backward(mine["img"], mine["txt"], mine["vis"])
         k = 3
     else:
-        st = ST.DualAudioStep.__new__(ST.DualAudioStep)
-        st._init_common({"logit_scale": torch.tensor(2.0).log()}, "cpu", 2, rank, world, comm, local_loss, gwg)
-        st.text = _Frozen(Wt)
-        st.lens = types.SimpleNamespace(tower=types.SimpleNamespace(embed_dim=E_DIM))
-        st.masters["visual.W"] = Wv.clone()
-        st.opt = TR.AdamW(st.masters, lr=1e-2)
-        st._mk = lambda: _LinearTower(st.masters["visual.W"], st.grads, "visual.W")
-        st._trainer = lambda i: st.trainers[i] if i < len(st.trainers) else (st.trainers.append(st._mk()) or st.trainers[i])
-        st._bind_grads = lambda t: setattr(t, "grads", st.grads)
-        st._refresh_operands = lambda: None
+        st = AudioHost(sd0, None, None, None, "cpu", **kw)
         loss = st.forward_backward(mine["vis"], mine["txt"])
         k = 2
     # between forward_backward and optimizer_step the buffer is mixed (block buckets summed, the rest rank-local):
@@ -255,13 +268,28 @@ def _worker(rank, world, port, recipe, local_loss, gwg, ret):
     dist.destroy_process_group()
 
 
+def _run(world, recipe, local_loss, gwg, overlap=False):
+    port = 29650 + (hash((world, recipe, local_loss, gwg, overlap)) % 300)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, recipe, local_loss, gwg, ret, overlap), nprocs=world, join=True)
+    for r in range(world):
+        assert ret[r] == [], (r, ret[r])
+
+
 @pytest.mark.parametrize("recipe", ["depth", "audio"])
 @pytest.mark.parametrize("local_loss,gwg", [(False, False), (False, True), (True, True)])
 def test_step_host_logic_world2_gloo(recipe, local_loss, gwg):
-    world = 2
-    port = 29650 + (hash((recipe, local_loss, gwg)) % 200)
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, recipe, local_loss, gwg, ret), nprocs=world, join=True)
-    for r in range(world):
-        assert ret[r] == [], (r, ret[r])
+    _run(2, recipe, local_loss, gwg)
+
+
+def test_depth_step_world2_gloo_with_overlap_frozen_requested():
+    """overlap_frozen=True (the product default) on a device without HIP streams: same collectives, same numbers."""
+    _run(2, "depth", False, False, overlap=True)
+
+
+@pytest.mark.parametrize("recipe,local_loss,gwg", [("depth", False, False), ("depth", True, True), ("audio", False, True)])
+def test_step_host_logic_world8_gloo(recipe, local_loss, gwg):
+    """The node size the north_star names (8 ranks): bucket order, ONE packed gather of [b, k*E] per rank, reduce-scatter
+    under gather_with_grad, every gradient element reduced exactly once, replicas identical after AdamW."""
+    _run(8, recipe, local_loss, gwg)

@@ -1,4 +1,4 @@
-"""CPU, 2 processes on gloo: the SyncBatchNorm host logic of the point-cloud tokenizer (`PointTokenizerTrainer._bn` /
+"""CPU, 2 and 8 processes on gloo: the SyncBatchNorm host logic of the point-cloud tokenizer (`PointTokenizerTrainer._bn` /
 `_bn_bwd`, --use-bn-sync) through the real `TorchComm`, with the HIP `ops` replaced by a torch-CPU stand-in of the four
 split passes.  Asserted per rank: the collective sequence and payloads (ONE all-gather of 2C+1 floats per BatchNorm
 forward, ONE all-reduce of 2C floats per backward), and the numbers - outputs, input gradients and running statistics
@@ -8,12 +8,14 @@ import os
 import sys
 import types
 
+import pytest
 import torch
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 C = 8
-ROWS = (5, 11)            # unequal per-rank row counts: the merge must weight by the gathered counts
+# unequal per-rank row counts: the merge must weight by the gathered counts
+ROWS_BY_WORLD = {2: (5, 11), 8: (5, 11, 3, 7, 2, 9, 4, 6)}
 
 
 def _fake_ops():
@@ -58,7 +60,8 @@ def _fake_ops():
     return o
 
 
-def _data():
+def _data(world):
+    ROWS = ROWS_BY_WORLD[world]
     g = torch.Generator().manual_seed(0)
     x = torch.randn(sum(ROWS), C, generator=g) * 0.7 + torch.randn(C, generator=g) * 3
     dy = torch.randn(sum(ROWS), C, generator=g)
@@ -75,15 +78,27 @@ def _worker(rank, world, port, ret):
     from test_step_gloo import _Rec
     from vitlens_hip import points as PT, step as ST
     PT.ops = _fake_ops()
-    x, dy, gamma, beta = _data()
+    x, dy, gamma, beta = _data(world)
+    ROWS = ROWS_BY_WORLD[world]
     lo = sum(ROWS[:rank]); s = slice(lo, lo + ROWS[rank])
     k, a = "encoder.first_conv.1", "t."
-    tr = PT.PointTokenizerTrainer.__new__(PT.PointTokenizerTrainer)
-    tr.a, tr.device, tr.bn_training, tr.world = a, torch.device("cpu"), True, world
-    tr.bn_sync = _Rec(ST.TorchComm())
-    tr.masters = {a + k + ".weight": gamma.clone(), a + k + ".bias": beta.clone()}
-    tr.running = {k: (torch.zeros(C), torch.ones(C))}
-    tr.grads = {}
+    # the PRODUCT object through its own __init__ (pure tensor work: masters, running statistics, bf16 operands) on a tiny
+    # PointBERT-shaped state_dict, C channels in the first BatchNorm
+    gs = torch.Generator().manual_seed(7)
+    rn = lambda *sh: torch.randn(*sh, generator=gs) * 0.1
+    E, T = 12, 10
+    sd = {a + "encoder.first_conv.0.weight": rn(C, 3, 1), a + "encoder.first_conv.0.bias": rn(C),
+          a + "encoder.first_conv.3.weight": rn(2 * C, C, 1), a + "encoder.first_conv.3.bias": rn(2 * C),
+          a + "encoder.second_conv.0.weight": rn(4 * C, 4 * C, 1), a + "encoder.second_conv.0.bias": rn(4 * C),
+          a + "encoder.second_conv.3.weight": rn(E, 4 * C, 1), a + "encoder.second_conv.3.bias": rn(E),
+          a + "reduce_dim.weight": rn(T, E), a + "reduce_dim.bias": rn(T),
+          a + "pos_embed.0.weight": rn(C, 3), a + "pos_embed.0.bias": rn(C),
+          a + "pos_embed.2.weight": rn(T, C), a + "pos_embed.2.bias": rn(T),
+          a + "encoder.first_conv.1.weight": gamma.clone(), a + "encoder.first_conv.1.bias": beta.clone(),
+          a + "encoder.first_conv.1.running_mean": torch.zeros(C), a + "encoder.first_conv.1.running_var": torch.ones(C),
+          a + "encoder.second_conv.1.weight": torch.ones(4 * C), a + "encoder.second_conv.1.bias": torch.zeros(4 * C),
+          a + "encoder.second_conv.1.running_mean": torch.zeros(4 * C), a + "encoder.second_conv.1.running_var": torch.ones(4 * C)}
+    tr = PT.PointTokenizerTrainer(sd, a, None, "cpu", bn_training=True, bn_sync=_Rec(ST.TorchComm()), world_size=world)
     h, stats = tr._bn(x[s], k)
     dx = tr._bn_bwd(dy[s], x[s], stats, k)
     ret[rank] = dict(log=tr.bn_sync.log, h=h, dx=dx, rm=tr.running[k][0], rv=tr.running[k][1], total=int(stats[2]),
@@ -91,12 +106,13 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_syncbn_host_logic_world2_gloo():
-    world = 2
-    port = 30200 + os.getpid() % 90
+@pytest.mark.parametrize("world", [2, 8])
+def test_syncbn_host_logic_gloo(world):
+    ROWS = ROWS_BY_WORLD[world]
+    port = 30200 + (os.getpid() + 97 * world) % 190
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
-    x, dy, gamma, beta = _data()
+    x, dy, gamma, beta = _data(world)
     xr = x.clone().requires_grad_(True); g = gamma.clone().requires_grad_(True); b = beta.clone().requires_grad_(True)
     rm, rv = torch.zeros(C), torch.ones(C)
     y = torch.relu(torch.nn.functional.batch_norm(xr, rm, rv, g, b, training=True, momentum=0.1, eps=1e-5))
@@ -108,5 +124,5 @@ def test_syncbn_host_logic_world2_gloo():
         assert o["total"] == sum(ROWS)
         assert torch.allclose(o["h"], y.detach()[s], atol=1e-5) and torch.allclose(o["dx"], xr.grad[s], atol=1e-5)
         assert torch.allclose(o["rm"], rm, atol=1e-6) and torch.allclose(o["rv"], rv, atol=1e-6)
-    assert torch.allclose(ret[0]["dg"] + ret[1]["dg"], g.grad, atol=1e-4)
-    assert torch.allclose(ret[0]["db"] + ret[1]["db"], b.grad, atol=1e-4)
+    assert torch.allclose(sum(ret[r]["dg"] for r in range(world)), g.grad, atol=1e-4)
+    assert torch.allclose(sum(ret[r]["db"] for r in range(world)), b.grad, atol=1e-4)

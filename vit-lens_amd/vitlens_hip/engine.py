@@ -135,11 +135,18 @@ def run_blocks(blocks, ws: _Workspace, B, L, D, H, causal=False, cfg=-1, fold=No
     res_epi = ops.EPI_RES_F32 if ws.x.dtype == torch.float32 else ops.EPI_RES_BF16
     if fold is None:
         fold = LN_FOLD
-    if fold and ws.x.dtype == torch.bfloat16 and ws.part is not None and blocks and "in_f" in blocks[0]:
-        mm = 0                                            # rows of ws.x whose partial sums are in ws.part
+    can_fold = bool(fold) and ws.x.dtype == torch.bfloat16 and ws.part is not None
+    # decided PER BLOCK: a block folds when it carries the folded operands (prep_block) - a fused training step removes them
+    # from the blocks it trains (their LayerNorm parameters move every step) and those run the LayerNorm passes
+    folded = [can_fold and "in_f" in w for w in blocks]
+    mm = 0                                            # rows of ws.x whose partial sums are in ws.part
+    r_in = r_fc = 0
+    if any(folded):
         r_in, r_fc = ops.fold_rows(ws.x, ws.qkv, 3 * D), ops.fold_rows(ws.x, ws.hid, ws.hid.shape[1])
-        # (the row-statistics launch also writes the LayerNorm output of the consuming GEMM's leftover rows into ws.h)
-        for w in blocks:
+    for i, w in enumerate(blocks):
+        nxt = i + 1 < len(blocks) and folded[i + 1]   # the consumer of this block's output reads row statistics
+        if folded[i]:
+            # (the row-statistics launch also writes the LayerNorm output of the consuming GEMM's leftover rows into ws.h)
             k_in = dict(ln_w=w["ln1_w"], ln_b=w["ln1_b"], h_left=ws.h, h_row0=r_in) if mm <= r_in else {}
             ops.ln_row_stats(ws.part, ws.x, mm, ws.mean, ws.rstd, **k_in)
             ops.gemm_lnfold(ws.x, w["in_f"], ws.mean, ws.rstd, ws.qkv, w["in_w"], w["in_b"], w["ln1_w"], w["ln1_b"], ws.h, cfg=cfg,
@@ -150,16 +157,18 @@ def run_blocks(blocks, ws: _Workspace, B, L, D, H, causal=False, cfg=-1, fold=No
             ops.ln_row_stats(ws.part, ws.x, mm, ws.mean, ws.rstd, **k_fc)
             ops.gemm_lnfold(ws.x, w["fc_f"], ws.mean, ws.rstd, ws.hid, w["fc_w"], w["fc_b"], w["ln2_w"], w["ln2_b"], ws.h,
                             act=ops.ACT_GELU, cfg=cfg, h_ready=bool(k_fc))
+        else:
+            ops.layernorm(ws.x, w["ln1_w"], w["ln1_b"], ws.h, B * L, D)
+            ops.gemm(ws.h, w["in_w"], w["in_b"], out=ws.qkv, epi=ops.EPI_BF16, cfg=cfg)
+            ops.attn_fwd(ws.q, ws.k, ws.v, ws.a, causal=causal, qscale=dh ** -0.5 * ops.LOG2E)
+            ops.gemm(ws.a, w["out_w"], w["out_b"], out=ws.x, res=ws.x, epi=res_epi, cfg=cfg)
+            ops.layernorm(ws.x, w["ln2_w"], w["ln2_b"], ws.h, B * L, D)
+            ops.gemm(ws.h, w["fc_w"], w["fc_b"], out=ws.hid, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg)
+        if nxt:
             mm = ops.gemm_res_rowstats(ws.hid, w["proj_w"], w["proj_b"], ws.x, ws.x, ws.part, cfg=cfg)
-        return
-    for w in blocks:
-        ops.layernorm(ws.x, w["ln1_w"], w["ln1_b"], ws.h, B * L, D)
-        ops.gemm(ws.h, w["in_w"], w["in_b"], out=ws.qkv, epi=ops.EPI_BF16, cfg=cfg)
-        ops.attn_fwd(ws.q, ws.k, ws.v, ws.a, causal=causal, qscale=dh ** -0.5 * ops.LOG2E)
-        ops.gemm(ws.a, w["out_w"], w["out_b"], out=ws.x, res=ws.x, epi=res_epi, cfg=cfg)
-        ops.layernorm(ws.x, w["ln2_w"], w["ln2_b"], ws.h, B * L, D)
-        ops.gemm(ws.h, w["fc_w"], w["fc_b"], out=ws.hid, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=cfg)
-        ops.gemm(ws.hid, w["proj_w"], w["proj_b"], out=ws.x, res=ws.x, epi=res_epi, cfg=cfg)
+        else:
+            ops.gemm(ws.hid, w["proj_w"], w["proj_b"], out=ws.x, res=ws.x, epi=res_epi, cfg=cfg)
+            mm = 0
 
 
 def _hi_lo(w: torch.Tensor, device):

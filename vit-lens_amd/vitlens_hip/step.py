@@ -92,10 +92,62 @@ class _StepState:
     checkpointed, resumed, and handed back to `TriCLIP.load_state_dict` (training/train.py checkpoints `model.state_dict()`
     and `optimizer.state_dict()`)."""
 
+    def _init_host(self, sd, device, micro_batch, rank, world_size, comm=None, local_loss=False, gather_with_grad=False,
+                   force_comm=False, overlap_frozen=False):
+        """Everything of a step that is HOST state - flags, the communicator, the (still empty apart from logit_scale) master
+        table, the gradient-bucket bookkeeping - and nothing that touches an engine or a kernel.  Every step's `__init__`
+        runs this first and then its `_build()` (engines, masters of the trainable set); tests/test_step_gloo.py drives the
+        REAL `__init__` of the product classes on CPU + gloo with `_build` / `_trainer` / `_refresh_operands` overridden by
+        linear stand-in towers, so a field added here can never be missing from the object under test."""
+        self.dev, self.mb, self.rank, self.world = torch.device(device), micro_batch, rank, world_size
+        # the multi-rank path (packed all-gather, bucketed async all-reduce, optional reduce-scatter) runs when there are
+        # peers - or when asked for on ONE rank, so that the RCCL calls execute on a single GPU (tests, bench --force-dist)
+        self._force_comm = bool(force_comm)
+        self.comm = comm or TorchComm()
+        self.local_loss, self.gather_with_grad = local_loss, gather_with_grad
+        # the frozen towers' forwards on a second HIP stream beside the trainable tower's forward (DESIGN.md 7.2): a request;
+        # `_overlap_active` says whether this device can honour it (a CPU device - the gloo tests - runs the serial order,
+        # the same arithmetic)
+        self.overlap_frozen = bool(overlap_frozen)
+        self._side = None
+        self._base_sd = {k: v.detach() for k, v in sd.items()}
+        self.logit_scale = sd["logit_scale"].detach().float().reshape(1).to(device).clone()
+        self.masters: Dict[str, torch.Tensor] = {"logit_scale": self.logit_scale}
+        self.bf16_targets = {}   # depth step: master name -> (block, operand key)
+        self.refresh = []        # Perceiver steps: (master name, forward bf16 tensor, key path of the transposed copy in trainer.perc.wT)
+        self.trainers = []       # one activation store per micro-batch (created lazily)
+        self.flat_grad, self.grads = None, {}
+        self._pending, self._reduced_upto, self._reduce_done = [], None, False
+
     @property
     def dist(self) -> bool:
         """The multi-rank code path is taken: there are peers, or `force_comm` asked for it on one rank."""
-        return self.world > 1 or getattr(self, "_force_comm", False)
+        return self.world > 1 or self._force_comm
+
+    @property
+    def _overlap_active(self) -> bool:
+        return self.overlap_frozen and self.dev.type == "cuda"
+
+    def _frozen_beside(self, frozen, trainable):
+        """Run the two closures of a step's forward: `frozen()` (the locked towers: forward only, results into buffers the
+        caller allocated) and `trainable()` (the Lens tower with saved activations).  Independent work.  With
+        `overlap_frozen` on a GPU the frozen towers go to a second HIP stream: one tower's low-power phases (attention,
+        LayerNorm, leftover rows) sit beside the other's GEMMs on a board that is power-limited in its GEMM phases
+        (-1.35 % per C3 step, bit-equal results: tests/test_hip_train.py).  Otherwise: one after the other."""
+        if not self._overlap_active:
+            frozen(); trainable()
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        main = torch.cuda.current_stream(self.dev)
+        ready, done = torch.cuda.Event(), torch.cuda.Event()
+        ready.record(main)
+        self._side.wait_event(ready)                  # inputs and output buffers exist
+        with torch.cuda.stream(self._side):
+            frozen()
+            done.record(self._side)
+        trainable()
+        main.wait_event(done)
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         out = {k: v.detach().clone() for k, v in self._base_sd.items()}
@@ -286,35 +338,33 @@ class TriModalDepthStep(_StepState):
                  rank: int = 0, world_size: int = 1, gemm_cfg: int = -1, comm=None, frozen_res_dtype=torch.float32,
                  local_loss: bool = False, gather_with_grad: bool = False, train_res_dtype=torch.float32,
                  grad_checkpointing: bool = False, force_comm: bool = False, text_wsplit: Optional[bool] = None, text_arith: str = "f16",
-                 overlap_frozen: bool = False):
-        self.dev, self.mb, self.rank, self.world = torch.device(device), micro_batch, rank, world_size
-        # EXPERIMENT (default off): the two frozen towers' forwards on a second HIP stream beside the trainable
-        # tower's forward - independent work whose low-power phases (attention, LayerNorm) could fill the other's GEMM phases
-        self.overlap_frozen = bool(overlap_frozen)
-        self._side = None
-        # the multi-rank path (packed all-gather, bucketed async all-reduce, optional reduce-scatter) runs when there are
-        # peers - or when asked for on ONE rank, so that the RCCL calls execute on a single GPU (tests, bench --force-dist)
-        self._force_comm = bool(force_comm)
+                 overlap_frozen: bool = True):
+        """overlap_frozen (default ON since round 6): the image / text towers' forwards run on a second HIP stream beside
+        the trainable tower's forward (`_frozen_beside`); results are bit-identical to the serial order."""
+        self._init_host(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad, force_comm, overlap_frozen)
         self.grad_checkpointing = bool(grad_checkpointing)      # block recompute in the trainable tower (transformer.py:366-368)
-        self.comm = comm or TorchComm()
-        self.local_loss, self.gather_with_grad = local_loss, gather_with_grad
-        self._base_sd = {k: v.detach() for k, v in sd.items()}
+        self.unlock_first_n = unlock_first_n
+        self._build(sd, tower, text, gemm_cfg=gemm_cfg, frozen_res_dtype=frozen_res_dtype, train_res_dtype=train_res_dtype,
+                    text_wsplit=text_wsplit, text_arith=text_arith)
+        self.opt = AdamW(self.masters, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+
+    def _build(self, sd, tower, text, gemm_cfg=-1, frozen_res_dtype=torch.float32, train_res_dtype=torch.float32,
+               text_wsplit=None, text_arith="f16"):
+        """Engines and the fp32 masters of the trainable set (reference lock recipe: adapter + first n blocks + logit_scale)."""
+        device, unlock_first_n = self.dev, self.unlock_first_n
         # frozen towers: forward only; their residual stream may be kept in bf16 (= the reference's autocast)
         self.image = VitEngine(sd, "image.", tower, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
         self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype, wsplit=text_wsplit, arith=text_arith)
         # trainable tower: residual stream AND residual-gradient stream in `train_res_dtype` (bf16 = the reference's amp_bf16)
         self.lens = LensEngine(sd, "visual.", tower, LensCfg(modality="depth", perceiver_identity=True), device, gemm_cfg=gemm_cfg,
                                res_dtype=train_res_dtype)
-        self.trainers = []            # one activation store per micro-batch (created lazily)
-        self.unlock_first_n = unlock_first_n
-        self.logit_scale = sd["logit_scale"].detach().float().reshape(1).to(device).clone()
-        # fp32 masters of the trainable set (reference lock recipe: adapter + first n blocks + logit_scale)
-        self.masters: Dict[str, torch.Tensor] = {"logit_scale": self.logit_scale}
-        self.bf16_targets = {}
         eng = self.lens.vit
         for l in range(unlock_first_n):
             p = f"visual.transformer.resblocks.{l}."
             w = eng.blocks[l]
+            # a block whose LayerNorm parameters and weights move every step carries no LayerNorm-folded operands: they would
+            # go stale at the first AdamW step, and `run_blocks` / the trainers decide the folding per block by their presence
+            w.pop("in_f", None); w.pop("fc_f", None)
             for nm, key in (("attn.in_proj_weight", "in_w"), ("attn.out_proj.weight", "out_w"), ("mlp.c_fc.weight", "fc_w"),
                             ("mlp.c_proj.weight", "proj_w")):
                 self.masters[p + nm] = sd[p + nm].detach().float().to(device).contiguous().clone()      # never an alias of the caller's tensor
@@ -327,10 +377,6 @@ class TriModalDepthStep(_StepState):
         from .engine import conv_weight_as_gemm
         self.masters["visual.visual_adapter.conv1.weight_gemm"] = conv_weight_as_gemm(       # from the fp32 weight, not the bf16 operand
             sd["visual.visual_adapter.conv1.weight"], device, torch.float32)
-        self.opt = AdamW(self.masters, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
-        self.flat_grad = None
-        self.grads: Dict[str, torch.Tensor] = {}
-        self._pending, self._reduced_upto, self._reduce_done = [], None, False
 
     # -------------------------------------------------------------------------------------------
     def _trainer(self, i):
@@ -448,29 +494,17 @@ class TriModalDepthStep(_StepState):
         vnorm = torch.empty(B, device=self.dev)
         # the frozen text tower sees the whole per-GPU batch in one pass: 77-token sequences give a micro-batch only 77 row
         # tiles (one uneven round of the persistent GEMM, 600-900 TF/s); four times the rows run whole rounds
-        if self.overlap_frozen:
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.dev)
-            main = torch.cuda.current_stream()
-            ready, done = torch.cuda.Event(), torch.cuda.Event()
-            ready.record(main)
-            self._side.wait_event(ready)                  # inputs and output buffers exist
-            with torch.cuda.stream(self._side):
-                ops.l2_normalize(self.text.encode_text(texts), out=ft)
-                for i in range(nmb):
-                    s = slice(i * mb, (i + 1) * mb)
-                    ops.l2_normalize(self.image.encode_image(images[s]), out=fi[s])
-                done.record(self._side)
-            for i in range(nmb):
-                s = slice(i * mb, (i + 1) * mb)
-                vraw[s] = self._trainer(i).forward(depths[s])
-            main.wait_event(done)
-        else:
+        def frozen():
             ops.l2_normalize(self.text.encode_text(texts), out=ft)
             for i in range(nmb):
                 s = slice(i * mb, (i + 1) * mb)
                 ops.l2_normalize(self.image.encode_image(images[s]), out=fi[s])
+
+        def trainable():
+            for i in range(nmb):
+                s = slice(i * mb, (i + 1) * mb)
                 vraw[s] = self._trainer(i).forward(depths[s])
+        self._frozen_beside(frozen, trainable)
         ops.l2_normalize(vraw, out=fv, norms=vnorm)
         scale = self.logit_scale          # the log-temperature, on the device: exp() is applied inside the loss section
         if self.dist:
@@ -498,20 +532,6 @@ class _PerceiverLensStep(_StepState):
     """Shared plumbing of the steps whose trainable part is a Lens (tokenizer + Perceiver) in front of a locked ViT:
     fp32 masters of the Perceiver under the reference's parameter names, one flat fp32 gradient buffer (a single
     all-reduce per step = DDP's mean of per-rank gradients), AdamW, bf16 operand refresh, logit-scale clamp."""
-
-    def _init_common(self, sd, device, micro_batch, rank, world_size, comm=None, local_loss=False, gather_with_grad=False,
-                     force_comm=False):
-        self.dev, self.mb, self.rank, self.world = torch.device(device), micro_batch, rank, world_size
-        self._force_comm = bool(force_comm)          # (see TriModalDepthStep)
-        self.comm = comm or TorchComm()
-        self.local_loss, self.gather_with_grad = local_loss, gather_with_grad
-        self.trainers = []
-        self._base_sd = {k: v.detach() for k, v in sd.items()}
-        self.logit_scale = sd["logit_scale"].detach().float().reshape(1).to(device).clone()
-        self.masters: Dict[str, torch.Tensor] = {"logit_scale": self.logit_scale}
-        self.refresh = []        # (master name, forward bf16 tensor, key path of the transposed copy in trainer.perc.wT)
-        self.flat_grad, self.grads = None, {}
-        self._reduce_done = False
 
     def _collect_perceiver(self, sd):
         pe, P = self.lens.perceiver, "visual.perceiver."
@@ -626,9 +646,17 @@ class DualAudioStep(_PerceiverLensStep):
     def __init__(self, sd, tower: TowerCfg, text: TextCfg, lens: LensCfg, device, micro_batch: int = 256, lr: float = 2e-4,
                  betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2, rank: int = 0, world_size: int = 1,
                  gemm_cfg: int = -1, comm=None, frozen_res_dtype=torch.float32, local_loss: bool = False,
-                 gather_with_grad: bool = False, train_res_dtype=torch.float32, force_comm: bool = False, text_wsplit: Optional[bool] = None, text_arith: str = "f16"):
+                 gather_with_grad: bool = False, train_res_dtype=torch.float32, force_comm: bool = False, text_wsplit: Optional[bool] = None, text_arith: str = "f16",
+                 overlap_frozen: bool = True):
+        self._init_host(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad, force_comm, overlap_frozen)
+        self._build(sd, tower, text, lens, gemm_cfg=gemm_cfg, frozen_res_dtype=frozen_res_dtype, train_res_dtype=train_res_dtype,
+                    text_wsplit=text_wsplit, text_arith=text_arith)
+        self.opt = AdamW(self.masters, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+
+    def _build(self, sd, tower, text, lens, gemm_cfg=-1, frozen_res_dtype=torch.float32, train_res_dtype=torch.float32,
+               text_wsplit=None, text_arith="f16"):
         from .train import AudioLensTrainer
-        self._init_common(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad, force_comm)
+        device = self.dev
         self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype, wsplit=text_wsplit, arith=text_arith)
         self.lens = LensEngine(sd, "visual.", tower, lens, device, gemm_cfg=gemm_cfg, res_dtype=train_res_dtype)
         self._mk = lambda: AudioLensTrainer(self.lens)
@@ -638,7 +666,6 @@ class DualAudioStep(_PerceiverLensStep):
         self.masters["visual.visual_adapter.conv1.weight_gemm"] = conv_weight_as_gemm(
             sd["visual.visual_adapter.conv1.weight"], device, torch.float32)
         self._collect_perceiver(sd)
-        self.opt = AdamW(self.masters, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
 
     def _refresh_operands(self):
         self._refresh_perceiver()
@@ -650,10 +677,14 @@ class DualAudioStep(_PerceiverLensStep):
         E = self.lens.tower.embed_dim
         ft = torch.empty(B, E, device=self.dev); fv = torch.empty(B, E, device=self.dev)
         vraw = torch.empty(B, E, device=self.dev); vnorm = torch.empty(B, device=self.dev)
-        ops.l2_normalize(self.text.encode_text(texts), out=ft)          # (whole batch at once: see TriModalDepthStep)
-        for i in range(nmb):
-            s = slice(i * mb, (i + 1) * mb)
-            vraw[s] = self._trainer(i).forward(audio[s])
+        def frozen():
+            ops.l2_normalize(self.text.encode_text(texts), out=ft)          # (whole batch at once: see TriModalDepthStep)
+
+        def trainable():
+            for i in range(nmb):
+                s = slice(i * mb, (i + 1) * mb)
+                vraw[s] = self._trainer(i).forward(audio[s])
+        self._frozen_beside(frozen, trainable)
         ops.l2_normalize(vraw, out=fv, norms=vnorm)
         scale = self.logit_scale          # device-side log-temperature (see TriModalDepthStep)
         if self.dist:
@@ -689,21 +720,28 @@ class TriModalPCStep(_PerceiverLensStep):
                  betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2, rank: int = 0, world_size: int = 1,
                  gemm_cfg: int = -1, bn_training: bool = True, unlock_cls: bool = False, comm=None,
                  frozen_res_dtype=torch.float32, local_loss: bool = False, gather_with_grad: bool = False,
-                 train_res_dtype=torch.float32, bn_sync: bool = False, force_comm: bool = False, text_wsplit: Optional[bool] = None, text_arith: str = "f16"):
+                 train_res_dtype=torch.float32, bn_sync: bool = False, force_comm: bool = False, text_wsplit: Optional[bool] = None, text_arith: str = "f16",
+                 overlap_frozen: bool = True):
+        self._init_host(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad, force_comm, overlap_frozen)
+        self._build(sd, tower, text, lens, gemm_cfg=gemm_cfg, frozen_res_dtype=frozen_res_dtype, train_res_dtype=train_res_dtype,
+                    text_wsplit=text_wsplit, text_arith=text_arith, bn_training=bn_training, bn_sync=bn_sync, unlock_cls=unlock_cls)
+        self.opt = AdamW(self.masters, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+
+    def _build(self, sd, tower, text, lens, gemm_cfg=-1, frozen_res_dtype=torch.float32, train_res_dtype=torch.float32,
+               text_wsplit=None, text_arith="f16", bn_training=True, bn_sync=False, unlock_cls=False):
         from .points import PointTokenizerTrainer
         from .train import PCLensTrainer
-        self._init_common(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad, force_comm)
+        device = self.dev
         self.image = VitEngine(sd, "image.", tower, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype)
         self.text = TextEngine(sd, text, device, gemm_cfg=gemm_cfg, res_dtype=frozen_res_dtype, wsplit=text_wsplit, arith=text_arith)
         self.lens = LensEngine(sd, "visual.", tower, lens, device, gemm_cfg=gemm_cfg, res_dtype=train_res_dtype)
         self.tok = PointTokenizerTrainer(sd, "visual.visual_adapter.", lens, device, gemm_cfg=gemm_cfg, bn_training=bn_training,
-                                         bn_sync=self.comm if bn_sync and self.dist else None, world_size=world_size)
+                                         bn_sync=self.comm if bn_sync and self.dist else None, world_size=self.world)
         self._mk = lambda: PCLensTrainer(self.lens, self.tok, train_cls=unlock_cls)
         if unlock_cls:
             self.masters["visual.class_embedding"] = self.lens.vit.cls
         self.masters.update(self.tok.masters)
         self._collect_perceiver(sd)
-        self.opt = AdamW(self.masters, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
 
     def _bind_grads(self, t):
         t.tower.grads = self.grads; t.perc.grads = self.grads; t.tok.grads = self.grads
@@ -722,11 +760,17 @@ class TriModalPCStep(_PerceiverLensStep):
         fi = torch.empty(B, E, device=self.dev); ft = torch.empty(B, E, device=self.dev)
         fv = torch.empty(B, E, device=self.dev); vraw = torch.empty(B, E, device=self.dev)
         vnorm = torch.empty(B, device=self.dev)
-        ops.l2_normalize(self.text.encode_text(texts), out=ft)          # (whole batch at once: see TriModalDepthStep)
-        for i in range(nmb):
-            s = slice(i * mb, (i + 1) * mb)
-            ops.l2_normalize(self.image.encode_image(images[s]), out=fi[s])
-            vraw[s] = self._trainer(i).forward(points[s], None if fps_start is None else fps_start[s])
+        def frozen():
+            ops.l2_normalize(self.text.encode_text(texts), out=ft)          # (whole batch at once: see TriModalDepthStep)
+            for i in range(nmb):
+                s = slice(i * mb, (i + 1) * mb)
+                ops.l2_normalize(self.image.encode_image(images[s]), out=fi[s])
+
+        def trainable():
+            for i in range(nmb):
+                s = slice(i * mb, (i + 1) * mb)
+                vraw[s] = self._trainer(i).forward(points[s], None if fps_start is None else fps_start[s])
+        self._frozen_beside(frozen, trainable)
         ops.l2_normalize(vraw, out=fv, norms=vnorm)
         scale = self.logit_scale          # device-side log-temperature (see TriModalDepthStep)
         if self.dist:

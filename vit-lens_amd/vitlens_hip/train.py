@@ -164,9 +164,9 @@ class TowerTrainer:
         # LayerNorm folding (engine.run_blocks; round 4): a FROZEN block never materialises ln_1 / ln_2 - its backward needs
         # only (mean, rstd), which ln_row_stats leaves in S.stats; a trainable block keeps its LayerNorm outputs (the operands
         # of its weight gradients).  Either kind leaves the partial row sums of its output when the next block is folded.
-        fold_ok = _engine.LN_FOLD and S.part is not None and "in_f" in w
-        folded = fold_ok and l not in self.train_blocks
-        next_folded = fold_ok and l + 1 < self.layers and (l + 1) not in self.train_blocks
+        fold_ok = _engine.LN_FOLD and S.part is not None
+        folded = fold_ok and "in_f" in w and l not in self.train_blocks
+        next_folded = (fold_ok and l + 1 < self.layers and "in_f" in e.blocks[l + 1] and (l + 1) not in self.train_blocks)
         if folded:
             x0, x1 = S.X[2 * l], S.X[2 * l + 1]
             mm0 = S.part_rows if S.part_of is x0 else 0      # (a recompute in front of the backward finds none: from the rows)
