@@ -56,6 +56,11 @@ typedef struct ihipStream_t* hipStream_t;
 #define VL_GEMM_PINGPONG 10
 
 const char* vl_last_error(void);
+/* ABI version of THIS header: bumped whenever an exported signature changes (round 5 changed vl_ln_row_stats and added the
+ * VL_F16 tag and the fp16 / fp32 entries without bumping it; round 6 starts counting: 600 = round 6, first revision).
+ * vl_version() returns the library's value; a client built against this header must find them equal before its first
+ * call - the Python binding (vitlens_hip/_lib.py) and tests/native/abi_c_client.c both refuse to run otherwise. */
+#define VL_ABI_VERSION 600
 int vl_version(void);
 
 /* C[M,N] = A[M,K] · W[N,K]^T with fused epilogue.  A, W bf16.  K % 64 == 0, N % 4 == 0.
@@ -289,10 +294,6 @@ int vl_attn_bwd_fused_supported(int Lq, int Lk, int dh, int causal);
 int vl_attn_bwd_fused_bf16(const void* q, const void* k, const void* v, const void* dO, const void* o, const long* strides,
                            const float* lse, void* dq, void* dk, void* dv, long ld_dq, long ld_dkv, int B, int H, int L, int dh,
                            float qscale, float scale, hipStream_t stream);
-/* torch.optim.AdamW step on one tensor (grad is multiplied by grad_scale first); step counts from 1. */
-/* ---- point-cloud tokenizer (PointBERT grouping) ---- */
-/* farthest point sampling: xyz [B,N,3] f32, start [B] (the reference draws it with torch.randint, misc.py:60);
- * idx [B,G] int64 (bit-exact vs misc.fps), centers [B,G,3] optional. */
 /* ---- audio front end (csrc/vl_audio.hip) ----
  * Kaldi-compatible log-mel filterbank = torchaudio.compliance.kaldi.fbank(htk_compat, 16 kHz, hanning window, 128 bins,
  * no dither, 25 ms / 10 ms frames, snip_edges) + zero-padding / truncation to target_len rows + Normalize(mean, std), i.e.
@@ -302,6 +303,9 @@ int vl_attn_bwd_fused_bf16(const void* q, const void* k, const void* v, const vo
 int vl_kaldi_fbank(const float* wave, long wave_stride, int batch, long n_samples, const float* window, const float* banks,
                    float* out, int target_len, int win, int shift, int nfft, int nmel, float preemph, float mean, float std,
                    hipStream_t stream);
+/* ---- point-cloud tokenizer (PointBERT grouping) ---- */
+/* farthest point sampling: xyz [B,N,3] f32, start [B] (the reference draws it with torch.randint, misc.py:60);
+ * idx [B,G] int64 (bit-exact vs misc.fps), centers [B,G,3] optional. */
 int vl_fps(const float* xyz, const int64_t* start, int64_t* idx, float* centers, int B, int N, int G, hipStream_t stream);
 /* pc_norm after a gather (modal_3d/processors/pc_processor.py:32-38, PCProcessorEval :60-88): out [B,G,C] f32 =
  * (pts[b, idx[b,g], :] - centroid) / max distance from the centroid over the G selected points; idx NULL = all N points. */
@@ -379,6 +383,7 @@ int vl_bn_bwd(const void* dy, long lddy, const void* x, long ldx, const float* m
 int vl_group_max_bwd(const void* f, long ldf, const void* dg, long lddg, const void* base, long ldb, void* out,
                      long ldo, long groups, int M, int C, hipStream_t stream);
 int vl_group_sum(const void* x, long ldx, void* out, long ldo, long groups, int M, int C, hipStream_t stream);
+/* torch.optim.AdamW step on one tensor (grad is multiplied by grad_scale first); step counts from 1. */
 int vl_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, float grad_scale, hipStream_t stream);
 int vl_clamp_scalar(float* p, float lo, float hi, hipStream_t stream);

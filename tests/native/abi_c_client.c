@@ -24,6 +24,10 @@ static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(
 static float frand(uint32_t* s) { *s = *s * 1664525u + 1013904223u; return ((*s >> 8) & 0xffff) / 32768.0f - 1.0f; }
 
 int main(void) {
+  if (vl_version() != VL_ABI_VERSION) {            /* built against another revision of the header than the library */
+    printf("FAIL abi version: library %d, header %d\n", vl_version(), VL_ABI_VERSION);
+    return 2;
+  }
   const int M = 512, N = 768, K = 512;
   uint32_t seed = 12345u;
   uint16_t* a = malloc(sizeof(uint16_t) * M * K); uint16_t* w = malloc(sizeof(uint16_t) * N * K);

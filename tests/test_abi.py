@@ -51,3 +51,15 @@ def test_ops_refuse_cpu_tensors():
     a = torch.zeros(64, 64, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError):
         ops.gemm(a, a)
+
+
+def test_abi_version_is_one_number_in_header_library_and_binding():
+    """`VL_ABI_VERSION` (header) == `vl_version()` (library) == `_lib.ABI_VERSION` (Python binding): a client built against an
+    older header than the library it loads must notice before its first call (advisor finding, round 5: vl_ln_row_stats
+    gained five parameters under an unchanged version 100)."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "vitlens_hip.h")).read()
+    want = int(re.search(r"#define\s+VL_ABI_VERSION\s+(\d+)", hdr).group(1))
+    from vitlens_hip import _lib
+    assert _lib.ABI_VERSION == want
+    assert int(_lib.load_library().vl_version()) == want

@@ -11,7 +11,7 @@ extern "C" int vl_set_error(const char* msg) {
   return 1;
 }
 extern "C" const char* vl_last_error(void) { return g_err; }
-extern "C" int vl_version(void) { return 100; }
+extern "C" int vl_version(void) { return VL_ABI_VERSION; }
 
 extern "C" int vl_device_info(int device, char* arch, int arch_len, int* cus, int* clock_khz, long* hbm_bytes) {
   hipDeviceProp_t prop;

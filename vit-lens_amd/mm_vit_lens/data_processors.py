@@ -16,18 +16,26 @@ from open_clip import get_tokenizer
 
 
 def wrap_list(data):
-    if isinstance(data, list):
-        return data
-    return [data]
+    """One item or a list of items -> list (the reference's processors accept either)."""
+    return data if isinstance(data, list) else [data]
 
 
 def _is_path(x):
     return isinstance(x, (str, bytes)) or hasattr(x, "__fspath__")
 
 
+def _batch(items, one, device):
+    """The call convention every processor shares: None passes through; otherwise `one(item)` per item, stacked on a new
+    leading axis and moved to `device`."""
+    if items is None:
+        return None
+    return torch.stack([one(it) for it in wrap_list(items)], dim=0).to(device)
+
+
 class BaseProcessor:
-    def __init__(self):
-        self.transform = lambda x: x
+    """Identity processor; subclasses replace `transform` (or `__call__`).  `from_config` / `build` exist because callers of
+    the reference construct processors from config dictionaries (mm_vit_lens/data_processors.py:25-43)."""
+    transform = staticmethod(lambda item: item)
 
     def __call__(self, item):
         return self.transform(item)
@@ -40,57 +48,61 @@ class BaseProcessor:
         return self.from_config(dict(kwargs))
 
 
+# caption clean-up of the reference's TextProcessor (data_processors.py:67-82), restated from its behaviour: lower-case,
+# the ten punctuation marks . ! " ( ) * # : ; ~ become blanks, every run of two or more white-space characters becomes one
+# blank (a lone tab / newline survives), trailing newlines and surrounding blanks go, at most `max_words` blank-separated
+# words are kept.  tests/test_data_processors.py pins it against the imported reference on generated captions.
+_PUNCT_TO_BLANK = str.maketrans({c: " " for c in '.!"()*#:;~'})
+_WS_RUN = re.compile(r"\s\s+")
+
+
+def clean_caption(caption: str, max_words: int) -> str:
+    text = _WS_RUN.sub(" ", caption.lower().translate(_PUNCT_TO_BLANK))
+    text = text.rstrip("\n").strip(" ")
+    words = text.split(" ")
+    return text if len(words) <= max_words else " ".join(words[:max_words])
+
+
 class TextProcessor(BaseProcessor):
     def __init__(self, prompt="", max_words=70, cfg=None):
         self.prompt, self.max_words = prompt, max_words
-        self.cfg = cfg if cfg is not None else SimpleNamespace(model="ViT-L-14")
+        self.cfg = SimpleNamespace(model="ViT-L-14") if cfg is None else cfg
         self.tokenizer = get_tokenizer(self.cfg.model)
+
+    def pre_caption(self, caption):
+        return clean_caption(caption, self.max_words)
 
     def __call__(self, caption, device="cpu"):
         if caption is None:
             return None
-        caption = [self.prompt + self.pre_caption(c) for c in wrap_list(caption)]
-        return self.tokenizer(caption).to(device)
+        return self.tokenizer([self.prompt + self.pre_caption(c) for c in wrap_list(caption)]).to(device)
 
     @classmethod
     def from_config(cls, cfg=None):
-        cfg = cfg if cfg is not None else {"model": "ViT-L-14"}
-        get = cfg.get if hasattr(cfg, "get") else (lambda k, d=None: getattr(cfg, k, d))
-        return cls(prompt=get("prompt", ""), max_words=get("max_words", 70), cfg=SimpleNamespace(model=get("model", "ViT-L-14")))
-
-    def pre_caption(self, caption):
-        caption = re.sub(r"([.!\"()*#:;~])", " ", caption.lower())
-        caption = re.sub(r"\s{2,}", " ", caption)
-        caption = caption.rstrip("\n").strip(" ")
-        words = caption.split(" ")
-        if len(words) > self.max_words:
-            caption = " ".join(words[:self.max_words])
-        return caption
+        read = (lambda k, d: d) if cfg is None else (cfg.get if hasattr(cfg, "get") else (lambda k, d: getattr(cfg, k, d)))
+        return cls(prompt=read("prompt", ""), max_words=read("max_words", 70), cfg=SimpleNamespace(model=read("model", "ViT-L-14")))
 
 
 class ImageProcessor(BaseProcessor):
     def __init__(self, image_size=224, image_mean=None, image_std=None, transform=None):
         self.image_size, self.image_mean, self.image_std = image_size, image_mean, image_std
-        if transform:
-            self.transform = transform
-        else:
+        if not transform:
             from open_clip.transform import image_transform
-            self.transform = image_transform(image_size=image_size, is_train=False, mean=image_mean, std=image_std)
+            transform = image_transform(image_size=image_size, is_train=False, mean=image_mean, std=image_std)
+        self.transform = transform
 
     def set_image_transform(self, transform):
         self.transform = transform
 
+    def _one(self, item):
+        if _is_path(item):            # decode on the host (Pillow), everything after it on the GPU (open_clip/transform.py)
+            from PIL import Image
+            with open(item, "rb") as fh:
+                item = Image.open(fh).convert("RGB")
+        return self.transform(item)
+
     def __call__(self, image_paths, device="cpu"):
-        if image_paths is None:
-            return None
-        outs = []
-        for item in wrap_list(image_paths):
-            if _is_path(item):
-                from PIL import Image
-                with open(item, "rb") as f:
-                    item = Image.open(f).convert("RGB")
-            outs.append(self.transform(item))
-        return torch.stack(outs, dim=0).to(device)
+        return _batch(image_paths, self._one, device)
 
 
 class PointCloudProcessor(BaseProcessor):
@@ -103,10 +115,7 @@ class PointCloudProcessor(BaseProcessor):
         self.wrap_processor.idendity = idendity_v
 
     def __call__(self, pc_paths, device="cpu"):
-        if pc_paths is None:
-            return None
-        outs = [self.wrap_processor(np.load(p) if _is_path(p) else p) for p in wrap_list(pc_paths)]
-        return torch.stack(outs, dim=0).to(device)
+        return _batch(pc_paths, lambda p: self.wrap_processor(np.load(p) if _is_path(p) else p), device)
 
 
 class DepthProcessor(BaseProcessor):
@@ -117,13 +126,8 @@ class DepthProcessor(BaseProcessor):
                                                  clamp_max_before_scale=clamp_max_before_scale)
 
     def __call__(self, depth_paths, device="cpu"):
-        if depth_paths is None:
-            return None
-        outs = []
-        for p in wrap_list(depth_paths):
-            d = torch.load(p, map_location="cpu", weights_only=False) if _is_path(p) else p
-            outs.append(self.wrap_processor(d))
-        return torch.stack(outs, dim=0).to(device)
+        load = lambda p: torch.load(p, map_location="cpu", weights_only=False) if _is_path(p) else p
+        return _batch(depth_paths, lambda p: self.wrap_processor(load(p)), device)
 
 
 class AudioProcessor(BaseProcessor):
@@ -163,9 +167,7 @@ class TactileProcessor(BaseProcessor):
         self.wrap_processor = TactileRGBProcessorEval(img_mean=image_mean, img_std=image_std)
 
     def __call__(self, tactile_flist, device="cpu"):
-        if tactile_flist is None:
-            return None
-        return torch.stack([self.wrap_processor(t) for t in wrap_list(tactile_flist)], dim=0).to(device)
+        return _batch(tactile_flist, self.wrap_processor, device)
 
 
 class EEGProcessor(BaseProcessor):
@@ -175,21 +177,17 @@ class EEGProcessor(BaseProcessor):
         self.wrap_processor = EEGProcessorEval(time_low=time_low, time_high=time_high, data_len=data_len)
 
     def __call__(self, eeg_paths, device="cpu"):
-        if eeg_paths is None:
-            return None
-        return torch.stack([self.wrap_processor(e) for e in wrap_list(eeg_paths)], dim=0).to(device)
+        return _batch(eeg_paths, self.wrap_processor, device)
+
+
+# modality key of `ViTLens.encode` -> processor class; the release model's processors take their class defaults (ViT-L/14
+# tokenizer, 224 px CLIP transform, 8192-point uniform sampling, SUN-RGBD depth statistics, 3 x 5 s clips of 512 x 128 log-mel)
+_VITLENS_L = {"image": ImageProcessor, "text": TextProcessor, "pc": PointCloudProcessor, "depth": DepthProcessor,
+              "audio": AudioProcessor, "tactile": TactileProcessor, "eeg": EEGProcessor}
 
 
 def vitlensL_processors():
-    return dict(
-        image=ImageProcessor(image_size=224, image_mean=None, image_std=None, transform=None),
-        text=TextProcessor(cfg=SimpleNamespace(model="ViT-L-14")),
-        pc=PointCloudProcessor(n_sample_points=8192, uniform=True),
-        depth=DepthProcessor(),
-        audio=AudioProcessor(),
-        tactile=TactileProcessor(),
-        eeg=EEGProcessor(),
-    )
+    return {modality: cls() for modality, cls in _VITLENS_L.items()}
 
 
 def vitlensB_processors():

@@ -16,6 +16,9 @@ def lib_path() -> str:
 
 P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
 
+# include/vitlens_hip.h: VL_ABI_VERSION (tests/test_abi.py compares the two)
+ABI_VERSION = 600
+
 # name -> argtypes (all functions return int status unless listed in _RET)
 SIGNATURES = {
     "vl_version": [],
@@ -109,6 +112,10 @@ def load_library():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = args
         fn.restype = _RET.get(name, I)
+    got = int(lib.vl_version())
+    if got != ABI_VERSION:
+        raise RuntimeError(f"{path} reports ABI version {got}, this binding was written for {ABI_VERSION} "
+                           "(include/vitlens_hip.h: VL_ABI_VERSION): rebuild the library (`make -C vit-lens_amd/csrc`)")
     _LIB = lib
     return lib
 

@@ -329,7 +329,7 @@ class TextEngine:
       "f16"    (default, round 5) every GEMM / attention operand IEEE half, fp32 residual stream, fp32 accumulation: three
                more mantissa bits on ALL four sources at the bf16 MFMA rate - 1.3-2.0e-4 emulated on four seeds.  (The
                reference converts CLIP to fp16 itself: convert_weights_to_fp16, model.py:393-419.)  Needs head dim 64 and a
-               width that is a multiple of 256 (every CLIP text tower); otherwise falls back to "bf16x2"
+               width that is a multiple of 256 and >= 512 (every CLIP text tower); otherwise falls back to "bf16x2"
       "bf16x2" (round 4) weights as the sum of TWO bf16 terms, fp32 residual stream: 6.1-8.1e-4 measured at twice the GEMM
                flops and twice the LayerNorm passes (+17 ms per C3 step)
       "bf16"   the reference's amp_bf16 arithmetic."""
@@ -341,7 +341,9 @@ class TextEngine:
             arith = "bf16x2" if wsplit else "bf16"
         if arith not in ("f16", "bf16x2", "bf16"):
             raise ValueError(f"TextEngine: arith must be 'f16', 'bf16x2' or 'bf16', got {arith!r}")
-        if arith == "f16" and (cfg.width % 256 or cfg.width // cfg.heads != 64 or cfg.embed_dim % 256 or cfg.context_length > 288):
+        # (vl_gemm_f16 is the persistent kernel only: whole 256-wide tiles and K >= 512 - the in-projection's K is the width)
+        if arith == "f16" and (cfg.width % 256 or cfg.width < 512 or cfg.width // cfg.heads != 64 or cfg.embed_dim % 256
+                               or cfg.context_length > 288):
             arith = "bf16x2"
         self.arith = arith
         self.wsplit = arith == "bf16x2"
