@@ -231,6 +231,53 @@ def test_c3_step_at_bench_geometry_is_finite_and_split_invariant(res_dtype):
     assert not bad, bad
 
 
+def test_c3_at_its_literal_configuration_b1024_as_4x256_with_adamw():
+    """BASELINE.json configs[2] exactly as bench.py runs it: batch 1024 per GPU in FOUR micro-batches of 256, first 4 blocks +
+    adapter + logit_scale trainable, bf16 streams, the frozen towers beside the trainable one on a second stream, one AdamW
+    step.  Until round 6 only bench.py ran nmb = 4: a micro-batch-index bug that appears at 4 but not at 2 would have been
+    found by the driver's bench, not by a test.  Checked: finite loss near 2 ln 1024 and finite gradients; loss and gradients
+    equal the SAME batch as two micro-batches of 512 up to bf16 summation-order noise; every micro-batch contributes (the
+    adapter gradient changes when any one quarter of the depth batch is replaced); AdamW moves every master and a second
+    step runs.  142 GB of activations per configuration: the two step objects live one after the other."""
+    from vitlens_hip import engine as E, step as ST
+    lens = O.LensSpec(modality="depth", perceiver_identity=True)
+    sd, tower, text, g = _weights(lens, seed=11)
+    B = 1024
+    img = torch.randn(B, 3, 224, 224, generator=g).cuda(); dep = torch.randn(B, 1, 224, 224, generator=g).cuda()
+    txt = O.synth_text(B, g).cuda()
+    bf = torch.bfloat16
+    res = {}
+    for mb in (256, 512):
+        st = ST.TriModalDepthStep(sd, E.TowerCfg(), E.TextCfg(), "cuda", micro_batch=mb, unlock_first_n=4,
+                                  train_res_dtype=bf, frozen_res_dtype=bf)
+        assert st._overlap_active                                  # the product default
+        loss = st.forward_backward(img, txt, dep)
+        assert len(st.trainers) == B // mb
+        assert torch.isfinite(loss), float(loss)
+        assert all(bool(torch.isfinite(v).all()) for v in st.grads.values())
+        res[mb] = (float(loss), {k: v.detach().clone() for k, v in st.grads.items()})
+        if mb == 256:
+            before = {k: v.clone() for k, v in st.masters.items()}
+            st.optimizer_step()
+            still = [k for k, v in st.masters.items() if torch.equal(v, before[k]) and k != "logit_scale"]
+            assert not still, still
+            # each quarter of the batch reaches the gradients: replace one micro-batch's depth maps, the adapter gradient moves
+            base = res[256][1]["visual.visual_adapter.conv1.weight_gemm"]
+            st.load_state_dict(sd)
+            for q in range(4):
+                dep2 = dep.clone(); dep2[q * 256:(q + 1) * 256].mul_(-1.0)
+                st.forward_backward(img, txt, dep2)
+                assert relerr(st.grads["visual.visual_adapter.conv1.weight_gemm"], base) > 1e-2, q
+            loss2 = st.step(img, txt, dep)
+            assert torch.isfinite(loss2)
+        del st
+        torch.cuda.empty_cache()
+    assert abs(res[256][0] - 2 * math.log(B)) < 1.0, res[256][0]
+    assert abs(res[256][0] - res[512][0]) < 2e-3, (res[256][0], res[512][0])
+    bad = {k: relerr(res[512][1][k], v) for k, v in res[256][1].items() if relerr(res[512][1][k], v) > 5e-2}
+    assert not bad, bad
+
+
 def test_c5_pc_backward_vitl_given_forward_routing_and_upstream_gradient():
     """C5's BACKWARD at ViT-L geometry with the two things that make the end-to-end comparison loose taken out (round 4):
     (1) the ROUTING - the max-pools' arg-max rows are read from the HIP forward's own activations and the oracle's autograd

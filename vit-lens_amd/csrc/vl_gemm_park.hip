@@ -59,6 +59,35 @@ using IC = std::integral_constant<int, I>;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// ---- k-rotation ("stagger", round 6) ----
+// Every workgroup used to walk its tile's reduction from k = 0 upwards, so at any instant all 256 CUs asked the memory system
+// for the SAME 128-byte column slab of rows that lie a whole row pitch apart (8 KB at K = 4096): addresses that differ only
+// above bit 13 land on the same L2 / fabric channels, and the K = 4096 launches ran 2 830-3 030 cycles per k-step against
+// 2 470 for the same tile streamed from Infinity-Cache-resident rows (profiles/r05_kstep_probe.log; padding the rows by 128
+// bytes recovered a third, r05_stride_probe.log).  The vendor's 256x256x64 kernel (hipBLASLt, same macro tile) reaches
+// 1 530 TF/s on this shape where this kernel reached 1 254 (profiles/r06_vendor_gemm_yardstick.log) - it staggers the start
+// of the reduction per workgroup.  Here: tile (tm, tn) starts at k-step (tm * PK_KSTAG_STEP) mod nk and wraps around; the
+// offset is a function of the ROW tile only, so the workgroups that share an A row tile through their XCD's L2 stay in
+// phase.  The sum over k is the same set of products in a rotated order: results differ from the unrotated kernel in the
+// last fp32 bits, deterministically (a pure function of the tile index), and launch-to-launch bit identity holds.
+#ifndef PK_KSTAG_MODE
+#define PK_KSTAG_MODE 1          // 0 off, 1 by row tile, 2 by workgroup slot
+#endif
+#ifndef PK_KSTAG_STEP
+#define PK_KSTAG_STEP 2          // k-steps (of 128 bytes) between neighbouring offsets
+#endif
+#ifdef VL_GEMM_PROBE
+}  // namespace
+extern "C" { int vl_gemm_probe_kstag[2] = {PK_KSTAG_MODE, PK_KSTAG_STEP}; }     // probe builds only: tools/kstagger_probe.py flips it
+namespace {
+#define PK_KSTAG_ARGS , int kstag_mode, int kstag_step
+#define PK_KSTAG_PASS , vl_gemm_probe_kstag[0], vl_gemm_probe_kstag[1]
+#else
+#define PK_KSTAG_ARGS
+#define PK_KSTAG_PASS
+constexpr int kstag_mode = PK_KSTAG_MODE, kstag_step = PK_KSTAG_STEP;
+#endif
+
 // ACT (EPI_BF16 only): 0 none, 1 GELU, 2 ReLU, 3 GELU with the pre-activation also written to out2 (saved for backward),
 // 4 GELU with gelu'(pre-activation) written to out2.  EPI_DGELU: ACT 4 = the aux operand is that saved gelu'.
 // The main loop runs on `v_mfma_f32_16x16x32_*` (32 MFMAs of 16 384 flop per 32-deep half k-step from 8 + 4 fragments): against
@@ -72,7 +101,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // cosine matrix to 1-2e-4 of the fp32 CPU path at ONE product per weight (two-term bf16 weights: 6-8e-4 at two).
 template <int EPI, int ACT, bool F16>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-    gemm_nt_pk_kernel(const GemmP p PK_PROF_ARG) {
+    gemm_nt_pk_kernel(const GemmP p PK_PROF_ARG PK_KSTAG_ARGS) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool HAS_AUX = (EPI == EPI_RES_BF16 || EPI == EPI_DGELU);   // second operand of the output's shape
   // LayerNorm folding (round 4; GemmP::ln_*): ACT 10 / 11 / 14 = ACT 0 / 1 / 4 with the row-statistics epilogue
@@ -121,6 +150,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int gn = min(tiles_n - first_n, GN);
     const int tm = rem / gn;
     m0 = tm << 8; n0 = (first_n + (rem - tm * gn)) << 8;
+  };
+
+  // first k-step of a tile's rotated reduction (see PK_KSTAG_MODE above)
+  auto k_offset = [&](int ti, int m0) -> int {
+    if (kstag_mode == 0) return 0;
+    if constexpr (EPI == EPI_F32) return 0;        // split-K partial products (weight gradients): no SGPRs to spare in that instantiation
+    const unsigned id = kstag_mode == 1 ? (unsigned)(m0 >> 8) : (unsigned)(ti * G + slot);
+    return (int)((id * (unsigned)kstag_step) % (unsigned)nk);
   };
 
   // ---- LDS-DMA: unit i of an operand = rows i*64 + wid*8 + (lane>>3), 16-byte chunk (lane&7) ^ swizzle(row) ----
@@ -214,15 +251,18 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   // therefore enters the next tile at kt = nk-2: that tile's descriptors are prepared once per tile, outside the k-loop
   __amdgpu_buffer_rsrc_t rsA_n = rsA, rsW_n = rsW;
   int dti = 0, dkt = 0;
+  int dk = k_offset(0, cur_m0), dk_n = dk;          // rotated k-step the next DMA batch loads; first one of the next tile
   auto dma_step = [&](unsigned char* stage) {
-    const int kbyte = dkt << 7;
+    constexpr bool ROT = EPI != EPI_F32;           // (the split-K instantiation keeps the plain order: see k_offset)
+    const int kbyte = (ROT ? dk : dkt) << 7;
+    if constexpr (ROT) { ++dk; if (dk == nk) dk = 0; }
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(stage + (i * NW + wid) * 1024), 16, voffA, kbyte + i * a_unit, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(stage + PK_ABYTES + (i * NW + wid) * 1024), 16, voffW, kbyte + i * w_unit, 0, 0);
     }
     ++dkt;
-    if (dkt == nk) { dkt = 0; ++dti; rsA = rsA_n; rsW = rsW_n; }
+    if (dkt == nk) { dkt = 0; ++dti; rsA = rsA_n; rsW = rsW_n; if constexpr (ROT) dk = dk_n; }
   };
   // hipcc does not wait for this builtin's LDS writes in front of a barrier: wait by hand.  The barrier is the raw
   // instruction: __syncthreads() carries a release fence, i.e. a compiler vmcnt(0)/lgkmcnt(0) for everything else, which
@@ -296,6 +336,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       int nm0, nn0, nsp;
       tile_origin(ti + 1, nm0, nn0, nsp);
       make_rsrc(nm0, nn0, nsp, rsA_n, rsW_n);
+      if constexpr (EPI != EPI_F32) dk_n = k_offset(ti + 1, nm0);
     }
     set_aux();
     PK_PROF_T(t_a);
@@ -556,7 +597,7 @@ hipError_t launch_pk(const GemmP& p, int ncu, hipStream_t s) {
   const int tiles = (p.M >> 8) * (p.N >> 8) * ((EPI == EPI_F32 && p.ksplit_len) ? (p.K >> 6) / p.ksplit_len : 1);
   int G = ncu & ~7;
   if (tiles < G) G = (tiles + 7) & ~7;
-  hipLaunchKernelGGL(kern, dim3(G), dim3(512), PK_LDS, s, p PK_PROF_PASS);
+  hipLaunchKernelGGL(kern, dim3(G), dim3(512), PK_LDS, s, p PK_PROF_PASS PK_KSTAG_PASS);
   return hipGetLastError();
 }
 
