@@ -76,17 +76,12 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #ifndef PK_KSTAG_STEP
 #define PK_KSTAG_STEP 2          // k-steps (of 128 bytes) between neighbouring offsets
 #endif
-#ifdef VL_GEMM_PROBE
-}  // namespace
-extern "C" { int vl_gemm_probe_kstag[2] = {PK_KSTAG_MODE, PK_KSTAG_STEP}; }     // probe builds only: tools/kstagger_probe.py flips it
-namespace {
-#define PK_KSTAG_ARGS , int kstag_mode, int kstag_step
-#define PK_KSTAG_PASS , vl_gemm_probe_kstag[0], vl_gemm_probe_kstag[1]
-#else
-#define PK_KSTAG_ARGS
-#define PK_KSTAG_PASS
-constexpr int kstag_mode = PK_KSTAG_MODE, kstag_step = PK_KSTAG_STEP;
+#ifndef PK_AUX_PF
+#define PK_AUX_PF 1              // second operand of row block 0 requested in the last k-step (prefetch_aux0)
 #endif
+// (compile-time only: A/B variants of these are separate builds of the library, tools/build_variant.sh - the product has no knob)
+constexpr int kstag_mode = PK_KSTAG_MODE, kstag_step = PK_KSTAG_STEP;
+constexpr bool aux_pf = PK_AUX_PF != 0;
 
 // ACT (EPI_BF16 only): 0 none, 1 GELU, 2 ReLU, 3 GELU with the pre-activation also written to out2 (saved for backward),
 // 4 GELU with gelu'(pre-activation) written to out2.  EPI_DGELU: ACT 4 = the aux operand is that saved gelu'.
@@ -101,7 +96,7 @@ constexpr int kstag_mode = PK_KSTAG_MODE, kstag_step = PK_KSTAG_STEP;
 // cosine matrix to 1-2e-4 of the fp32 CPU path at ONE product per weight (two-term bf16 weights: 6-8e-4 at two).
 template <int EPI, int ACT, bool F16>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-    gemm_nt_pk_kernel(const GemmP p PK_PROF_ARG PK_KSTAG_ARGS) {
+    gemm_nt_pk_kernel(const GemmP p PK_PROF_ARG) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool HAS_AUX = (EPI == EPI_RES_BF16 || EPI == EPI_DGELU);   // second operand of the output's shape
   // LayerNorm folding (round 4; GemmP::ln_*): ACT 10 / 11 / 14 = ACT 0 / 1 / 4 with the row-statistics epilogue
@@ -237,6 +232,28 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
   };
 
+  // Row block 0's second operand, requested in the LAST k-step of the tile (round 6): the four loads are independent of the
+  // accumulators, and until now they were issued at the start of the epilogue, BEHIND the next tile's first DMA batch in the
+  // in-order vector-memory queue (128 KB per CU) - the residual / gelu' epilogues waited 8-9 k cycles per tile more than the
+  // plain one for them (tools/gemm_phase_prof.py: 13.3 k against 5.0 k; the matrix pipes idle meanwhile).  They go out at the
+  // start of the k-step's third phase - the W fragments of the first half are dead by then and, this being the last k-step,
+  // no fragments of a next stage are loaded into them - i.e. in FRONT of that DMA batch, and the barrier of this k-step waits
+  // `vmcnt(4)`: everything older than these four loads (the DMA this barrier is for) has landed, the four may still fly.
+  // (Round 2's "2 loads per k-step over the last 8 steps" polluted the whole k-loop's queue and lost; this touches one step.)
+  auto prefetch_aux0 = [&]() {
+    if constexpr (HAS_AUX) {
+      int el = lane;
+      asm volatile("" : "+v"(el));              // (laundered: nothing of this may be hoisted above the k-loop)
+      const unsigned lo = (unsigned)(((el >> 3) * p.ldo + (el & 7) * 8) * 2);
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass)
+        aux[0][pass] = *(const u32x4*)(aux_src + (size_t)(chunk_row(pass) * ldo2) + lo);
+    }
+  };
+  auto aux_wait_and_barrier = [&]() {
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+
   int cur_m0, cur_n0, cur_sp;
   tile_origin(0, cur_m0, cur_n0, cur_sp);
   auto set_aux = [&]() {
@@ -319,9 +336,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     mma16(IC<1>{}, 1, 0);
     __builtin_amdgcn_sched_barrier(0);
     ldA16(cur, 1, 1, 1);
+    if constexpr (last && HAS_AUX && aux_pf) prefetch_aux0();
     mma16(IC<0>{}, 0, 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (after_epi) { first_wait_and_barrier(); after_epi = false; } else dma_wait_and_barrier();
+    if (after_epi) { first_wait_and_barrier(); after_epi = false; }
+    else if constexpr (last && HAS_AUX && aux_pf) aux_wait_and_barrier();
+    else dma_wait_and_barrier();
     // (at the last k-step of a tile BOTH wave groups issue at once: the batch must sit in front of the epilogue's stores)
     if (dti < my_tiles) { if (!grpB || last) dma_step(cur); else pendB = true; }
     if constexpr (!last) first_frags(oth);
@@ -354,9 +374,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       prow = el >> 3; pcol = (el & 7) * 8;
       lo_out = (unsigned)((prow * pe.ldo + pcol) * 2);
       const int fr16 = el & 15, fq = el >> 4;      // shadow the main loop's copies
-      if constexpr (HAS_AUX) {
-        load_block(IC<0>{});
-      }
+      // (HAS_AUX: row block 0's second operand was requested in the last k-step - prefetch_aux0)
+      if constexpr (HAS_AUX && !aux_pf) load_block(IC<0>{});
       unsigned char* const slab = smem + 2 * PK_STAGE + wid * SLAB;
       // branch-free optional bias: read SOMETHING valid (the weight matrix) and select zero
       const bool has_bias = pe.bias != nullptr;
@@ -597,7 +616,7 @@ hipError_t launch_pk(const GemmP& p, int ncu, hipStream_t s) {
   const int tiles = (p.M >> 8) * (p.N >> 8) * ((EPI == EPI_F32 && p.ksplit_len) ? (p.K >> 6) / p.ksplit_len : 1);
   int G = ncu & ~7;
   if (tiles < G) G = (tiles + 7) & ~7;
-  hipLaunchKernelGGL(kern, dim3(G), dim3(512), PK_LDS, s, p PK_PROF_PASS PK_KSTAG_PASS);
+  hipLaunchKernelGGL(kern, dim3(G), dim3(512), PK_LDS, s, p PK_PROF_PASS);
   return hipGetLastError();
 }
 

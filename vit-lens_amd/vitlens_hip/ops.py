@@ -297,15 +297,68 @@ def gemm_dw_tn(dy, x, g, alpha=1.0):
     return True
 
 
-def tn_splits(nk: int, tiles: int) -> int:
+def tn_splits(nk: int, tiles: int, few_tiles_ok: bool = False) -> int:
     """K slices for the token-major dW kernel: the smallest of 1, 2, 4, 8, 16 that gives >= 192 work items (tiles x slices) with
     >= 16 steps of 64 tokens per slice; slices are ceil(nk / splits) steps long, the last one may be shorter but not below the
-    4 steps the kernel's DMA look-ahead needs (vl_gemm_tn_splitk_accum_f32 checks the same).  0 = the shape does not fit."""
-    for splits in (1, 2, 4, 8, 16):
-        ln = -(-nk // splits)
-        if tiles * splits >= 192 and nk // splits >= 16 and nk - (-(-nk // ln) - 1) * ln >= 4:
+    4 steps the kernel's DMA look-ahead needs (vl_gemm_tn_splitk_accum_f32 checks the same).  0 = the shape does not fit.
+    few_tiles_ok (round 6: the Perceiver's narrow projections, 1-8 output tiles over 32 k-512 k tokens): up to 64 slices, and when
+    even those do not fill the chip, the largest admissible count."""
+    valid = lambda splits: (nk // splits >= 16 and nk - (-(-nk // (-(-nk // splits))) - 1) * (-(-nk // splits)) >= 4)
+    cands = (1, 2, 4, 8, 16, 32, 64) if few_tiles_ok else (1, 2, 4, 8, 16)
+    best = 0
+    for splits in cands:
+        if not valid(splits):
+            continue
+        if tiles * splits >= 192:
             return splits
-    return 0
+        best = splits
+    return best if few_tiles_ok else 0
+
+
+_pad_cache = {}
+
+
+def _zero_padded(t, cols, tag):
+    """t [R, c] bf16 -> a [R, cols] bf16 buffer (cached per shape and role) whose first c columns are t and the rest zero."""
+    key = (tag, t.device, t.shape[0], cols)
+    buf = _pad_cache.get(key)
+    if buf is None:
+        buf = torch.zeros(t.shape[0], cols, device=t.device, dtype=torch.bfloat16)      # the pad columns are written once: zeros
+        _pad_cache[key] = buf
+    buf[:, :t.shape[1]].copy_(t)
+    return buf
+
+
+def gemm_dw_tn_any(dy, x, g, alpha=1.0):
+    """g[N_out, K_in] += dy^T x like gemm_dw_tn, for operands whose column counts are NOT multiples of 256 (the Perceiver's
+    cross-attention projections: 64 / 128 columns; a 384-wide context): the narrow operand is zero-padded to whole 256-column
+    tiles - a copy of the SMALL matrix - instead of transposing BOTH operands for the NT kernel (a 64-134 MB round trip of the
+    large one per call, `transpose64_kernel` in the C4 / C5 kernel statistics of round 5).  Returns False when the shape does
+    not fit (rows not a multiple of 64, non-bf16 operands)."""
+    if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or g.dtype != torch.float32 or dy.dim() != 2 or x.dim() != 2:
+        return False
+    R, M = dy.shape
+    N = x.shape[1]
+    if x.shape[0] != R or R % 64 or tuple(g.shape) != (M, N) or dy.stride(1) != 1 or x.stride(1) != 1:
+        return False
+    Mp, Np = (M + 255) // 256 * 256, (N + 255) // 256 * 256
+    if Mp == M and Np == N and gemm_dw_tn(dy, x, g, alpha):
+        return True
+    if dy.stride(0) % 8 or x.stride(0) % 8 or dy.data_ptr() % 16 or x.data_ptr() % 16:
+        return False
+    splits = tn_splits(R // 64, (Mp // 256) * (Np // 256), few_tiles_ok=True)
+    if not splits:
+        return False
+    dyp = dy if Mp == M else _zero_padded(dy, Mp, "dy")
+    xp = x if Np == N else _zero_padded(x, Np, "x")
+    direct = Mp == M and Np == N and g.stride(1) == 1 and g.stride(0) % 4 == 0
+    gp = g if direct else torch.zeros(Mp, Np, device=g.device, dtype=torch.float32)
+    ws = torch.empty(splits * Mp * Np, device=g.device, dtype=torch.float32)
+    check(_lib.vl_gemm_tn_splitk_accum_f32(_p(dyp), _p(xp), _p(gp), Mp, Np, R, dyp.stride(0), xp.stride(0), gp.stride(0),
+                                           float(alpha), splits, _p(ws), _stream()))
+    if not direct:
+        g += gp[:M, :N]
+    return True
 
 
 def _bhld_strides(*views):

@@ -535,7 +535,8 @@ class PerceiverTrainer:
     def _dw(self, name, dy, x, rows):
         g = self.grad_buffer(name, (dy.shape[1], x.shape[1]))
         rp = (rows + 63) // 64 * 64
-        if rows == dy.shape[0] == x.shape[0] and ops.gemm_dw_tn(dy, x, g):      # token-major operands, no transposed copies
+        # token-major operands, no transposed copies (narrow projections: the small operand zero-padded to whole tiles)
+        if rows == dy.shape[0] == x.shape[0] and ops.gemm_dw_tn_any(dy, x, g):
             return
         ops.gemm_dw(ops.transpose_to_bf16(dy, ldo=rp), ops.transpose_to_bf16(x, ldo=rp), g, cfg=self.pe.gemm_cfg)
 
