@@ -28,18 +28,6 @@ def relerr(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def same_products_other_order(x, y):
-    """x, y = the same GEMM from two kernels that add the SAME bf16 products in fp32 in a different order (round 6: the
-    persistent 256x256 kernel walks each tile's reduction from a rotated start, vl_gemm_park.hip PK_KSTAG_*; until then it was
-    bit-identical to the round-1 kernel): 16-bit outputs agree except where the fp32 sums straddle a rounding boundary -
-    never more than one ulp of the 16-bit format apart, and on at most 2 % of the elements."""
-    xf, yf = x.float(), y.float()
-    if x.dtype == torch.float32:
-        return bool(((xf - yf).abs() <= 4e-6 * yf.abs().clamp_min(1.0)).all())
-    ulp = torch.maximum(xf.abs(), yf.abs()) * 2.0 ** -7 + 1e-30           # one bf16 ulp is 2^-7 .. 2^-8 of the value
-    return bool(((xf - yf).abs() <= ulp).all()) and float((xf != yf).float().mean()) < 0.02
-
-
 def test_p4_identity_is_bit_exact(pcfg):
     """A = [I; 2I; ...] (K = 512): C rows are W^T scaled by powers of two -> exact in bf16; catches any row/column/chunk mix-up
     of the LDS transpose and of the parked-store addressing."""
@@ -72,7 +60,7 @@ def test_p4_bf16_epilogues(M, N, K, pcfg):
     assert relerr(u, acc) < 4e-3 and relerr(out, torch.nn.functional.gelu(u.float())) < 4e-3
     # same results as the 8-wave kernel up to the bf16 rounding point of the GELU (fp32 vs bf16-rounded pre-activation)
     old = ops.gemm(a, w, bias, epi=ops.EPI_BF16, cfg=5)
-    assert same_products_other_order(old, ops.gemm(a, w, bias, epi=ops.EPI_BF16, cfg=pcfg))
+    assert torch.equal(old, ops.gemm(a, w, bias, epi=ops.EPI_BF16, cfg=pcfg))
 
 
 @pytest.mark.parametrize("M,N,K", [(256 * 40, 1024, 1024), (256 * 5, 768, 3072), (256 * 257, 256, 512)])
@@ -81,11 +69,11 @@ def test_p4_residual_and_dgelu(M, N, K, pcfg):
     a = rnd(M, K, seed=4).bfloat16().cuda(); w = rnd(N, K, seed=5, scale=K ** -0.5).bfloat16().cuda()
     bias = rnd(N, seed=6).cuda()
     acc = a.float() @ w.float().t()
-    # bf16 residual, out of place and in place (x += ...); the 8-wave kernel adds the same products in another order
+    # bf16 residual, out of place and in place (x += ...), bit-identical to the 8-wave kernel
     res = rnd(M, N, seed=7).bfloat16().cuda()
     o1 = ops.gemm(a, w, bias, res=res, epi=ops.EPI_RES_BF16, cfg=pcfg)
     assert relerr(o1, res.float() + acc + bias) < 4e-3
-    assert same_products_other_order(o1, ops.gemm(a, w, bias, res=res, epi=ops.EPI_RES_BF16, cfg=5))
+    assert torch.equal(o1, ops.gemm(a, w, bias, res=res, epi=ops.EPI_RES_BF16, cfg=5))
     x = res.clone()
     ops.gemm(a, w, bias, out=x, res=x, epi=ops.EPI_RES_BF16, cfg=pcfg)
     assert torch.equal(x, o1)
@@ -95,7 +83,7 @@ def test_p4_residual_and_dgelu(M, N, K, pcfg):
     uf = u.float().requires_grad_(True)
     torch.nn.functional.gelu(uf).sum().backward()
     assert relerr(out, acc * uf.grad) < 4e-3
-    assert same_products_other_order(out, ops.gemm(a, w, None, res=u, epi=ops.EPI_DGELU, cfg=5, out=torch.empty_like(out)))
+    assert torch.equal(out, ops.gemm(a, w, None, res=u, epi=ops.EPI_DGELU, cfg=5, out=torch.empty_like(out)))
 
 
 @pytest.mark.parametrize("cfg", [8, 10, 0, 1, 5, -1])

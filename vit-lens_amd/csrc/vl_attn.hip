@@ -54,9 +54,17 @@ struct AttnP {
 // MULTI: more keys than one LDS chunk (the chunk loop restages inside the accumulation; kept out of the common
 // single-chunk instantiations, where its 12 loads in flight would push the tile loop's registers to scratch)
 // F16: q, k, v and the output are IEEE half (vl_attn_fwd_f16; the frozen text tower), P is rounded to half for the P.V product
-template <int DH, bool TAILQ, bool MULTI, bool F16 = false>
+// DMA (round 6; head dim 64, one chunk, bf16 - the ViT towers' and the Perceiver latents' self-attention): K and V rows go
+// HBM -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`), both as ROW images; the V^T fragments of the P.V product come out of
+// gfx950's transpose read (`ds_read_b64_tr_b16`, the fused backward's addressing) instead of a transposed image that every
+// thread built with 2-byte LDS stores from 12 loads held in registers.  The phase timeline of round 5 had 11.4 k of a
+// workgroup's 33.2 k cycles in "load + stage" (profiles/r05_attn_phase_timeline.log): with the DMA the staging is the
+// memory round trip and nothing else.  The shared last row's per-wave share runs BEFORE the tile loop and the wave that
+// merges the partials does so after its own tiles, without a workgroup barrier at the end of the kernel.
+template <int DH, bool TAILQ, bool MULTI, bool F16 = false, bool DMA = false>
 __global__ void __launch_bounds__(NWMAX * 64, DH == 128 ? 2 : 4) attn_fwd_kernel(const AttnP p) {
   static_assert(!F16 || (!TAILQ && DH == 64), "half operands: head dim 64, no shared last row (the text tower's shape)");
+  static_assert(!DMA || (DH == 64 && !MULTI && !F16), "LDS-DMA staging: head dim 64, one key chunk, bf16");
   constexpr int RB = DH * 2;          // K row bytes in LDS
   constexpr int CH = RB / 16;         // 16-byte chunks per row
   constexpr int RSH = Rsh<DH>::v;     // rows per 256-B bank row = 2^RSH
@@ -103,13 +111,52 @@ __global__ void __launch_bounds__(NWMAX * 64, DH == 128 ? 2 : 4) attn_fwd_kernel
   if constexpr (TAILQ) {
     if (tid < nch) tailraw = *(const u32x4*)(Qb + (long)(p.Lq - 1) * p.q.sr + tid * 8);
   }
+  unsigned char* const sVr = (unsigned char*)sV;       // DMA: V as a row image [KC][128 B], chunks swizzled by vswz(row)
+  auto vswz = [](int row) { const int x = (row >> 1) & 7; return ((x & 1) << 2) | (x >> 1); };      // (= the fused backward's fb_swz)
+  if constexpr (DMA) {
+    // unit u = rows 8u .. 8u+7 of K and of V: one 1 KB LDS-DMA instruction each (lane -> row 8u + lane/8, 16-byte slot lane%8,
+    // which holds the row's chunk slot ^ swizzle(row)); rows beyond Lk are not fetched - K's stay whatever they were (their
+    // scores are replaced by -inf), V's are zeroed (0 * garbage could be NaN)
+    typedef __attribute__((address_space(3))) void* lds_p;
+    const int nrows = ((p.Lk + 31) >> 5) << 5;
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kg, 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vg, 0, 0x7ffffff0, 0x00020000);
+    for (int u = wid; u * 8 < p.Lk; u += nwq) {
+      const int row = u * 8 + (lane >> 3), sl = lane & 7;
+      if (row < p.Lk) {
+        const unsigned offK = (unsigned)(row * (int)p.k.sr + ((sl ^ ((row >> 1) & 7)) << 3)) * 2u;
+        const unsigned offV = (unsigned)(row * (int)p.v.sr + ((sl ^ vswz(row)) << 3)) * 2u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_p)(sK + u * 1024), 16, offK, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_p)(sVr + u * 1024), 16, offV, 0, 0, 0);
+      }
+    }
+    for (int i = tid; i < (nrows - p.Lk) * 8; i += nthr)
+      *(u32x4*)(sVr + (p.Lk + (i >> 3)) * 128 + ((i & 7) << 4)) = u32x4{0u, 0u, 0u, 0u};
+    // (hipcc does not model the LDS write of the DMA builtin: wait for it by hand in front of the barrier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
   // first chunk: staged before the accumulators exist (12 x 16-byte loads in flight per thread need the registers)
   stage2<DH, KC, true, false, false, true>(StageSrc{sK, nullptr, Kg, p.k.sr, 1.f, nch}, StageSrc{nullptr, sV, Vg, p.v.sr, 1.f, nch},
                                            0, p.Lk, tid, nthr);
+  }
   if constexpr (TAILQ) {
     if (tid < CH) *(u32x4*)(sTailQ + tid * 8) = tailraw;
   }
   VL_PROF_STAMP(p, 1);
+  // V^T fragment in accumulator order out of the row image (DMA): this lane's column d = t*32 + (lane & 31), the 8 keys
+  // tile*32 + 16c + 4fg + (e & 3) + 8(e >> 2): two transpose reads of 4 rows each (vl_attn_bwd_fused.hip: trQG)
+  [[maybe_unused]] const int li = lane & 15, lb3 = (li >> 3) & 1;
+  [[maybe_unused]] const unsigned aTr = (unsigned)((fg * 4 + (li >> 2)) * 128) +
+                                        (((unsigned)(((lane >> 4) & 1) * 2 + ((li >> 1) & 1)) ^ (unsigned)((lb3 << 2) | fg)) << 4) + (unsigned)((li & 1) << 3);
+  auto trV = [&](int tile, int c, int t) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+    struct { s16x4 lo, hi; } f;
+    const unsigned a = (aTr + (unsigned)(tile * 4096)) ^ (unsigned)(t * 64);
+    f.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sVr + a + c * 2048));
+    f.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sVr + (a ^ 32u) + c * 2048 + 1024));
+    return __builtin_bit_cast(bf16x8, f);
+  };
   bf16x8 qf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
@@ -127,106 +174,13 @@ __global__ void __launch_bounds__(NWMAX * 64, DH == 128 ? 2 : 4) attn_fwd_kernel
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   bool first = true;
 
-  const int q_hi = q0 + 31;  // last query row of this wave's tile
-  const int blk_q_hi = min(p.lq_main - 1, (int)(blockIdx.x * nwq + nwq) * 32 - 1);
-
-  for (int kc0 = 0; kc0 < (MULTI ? p.Lk : 1); kc0 += KC) {
-    if (MULTI && p.causal && kc0 > blk_q_hi) break;   // uniform across the workgroup
-    if constexpr (MULTI) {
-      if (kc0 > 0) {
-        __syncthreads();
-        // (one item per round here: the accumulators are live and 12 loads in flight would spill them)
-        stage2<DH, KC, true, false, false, true, 1>(StageSrc{sK, nullptr, Kg, p.k.sr, 1.f, nch},
-                                                    StageSrc{nullptr, sV, Vg, p.v.sr, 1.f, nch}, kc0, p.Lk, tid, nthr);
-      }
-    }
-    __syncthreads();
-    VL_PROF_STAMP(p, 2);
-    if (!wave_active) continue;
-
-    int ntile = (min(p.Lk - kc0, KC) + 31) >> 5;
-    if (p.causal) ntile = min(ntile, ((q_hi - kc0) >> 5) + 1);
-    const int ksw = (fr >> RSH) & (CH - 1);
-    for (int kt = 0; kt < ntile; ++kt) {
-      // ---- S^T tile (rows = keys, cols = queries), relative to the running maximum ----
-      const unsigned char* kbase = sK + (kt * 32 + fr) * RB;
-      bf16x8 kf[KS];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8*)(kbase + (((ks * 2 + fg) ^ ksw) * 16));
-      f32x16 s = mfma32<F16>(kf[0], qf[0], negm);
-#pragma unroll
-      for (int ks = 1; ks < KS; ++ks) s = mfma32<F16>(kf[ks], qf[ks], s);
-      // V^T fragments of the first 16-key slice: issued before the softmax arithmetic so that they land under it
-      // (the second slice is fetched after the exponentials, into the registers the scores vacate)
-      bf16x8 vf0[DT];
-#pragma unroll
-      for (int t = 0; t < DT; ++t) vf0[t] = *(const bf16x8*)(sV + (t * 32 + fr) * VSP + kt * 32 + fg * 8);
-      const int key0 = kc0 + kt * 32 + fg * 4;
-      const bool need_mask = (key0 - fg * 4 + 32 > p.Lk) || (p.causal && key0 - fg * 4 + 31 > q0);
-      if (need_mask) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = key0 + (r & 3) + 8 * (r >> 2);
-          if (key >= p.Lk || (p.causal && key > qidx)) s[r] = -INFINITY;
-        }
-      }
-      float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);      // v_max3_f32 chain (file is built with -fno-honor-nans)
-#pragma unroll
-      for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
-      mx = fmaxf(mx, s[15]);
-      mx = xhalf_max(mx);
-      if (__builtin_amdgcn_ballot_w64(first || mx > RESCALE_THR) != 0) {
-        // the maximum moved: shift this tile's scores, the C block and the accumulated sums (rare after the first tiles)
-        const float d = first ? mx : fmaxf(mx, 0.f);
-        const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-d);
-        m_run += d;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] -= d; negm[r] -= d; }
-#pragma unroll
-        for (int t = 0; t < DT; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-        l2 *= alpha;
-        first = false;
-      }
-      float pv[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r]);
-      {
-        vl_f32x2 a0 = {pv[0], pv[1]}, a1 = {pv[2], pv[3]}, a2 = {pv[4], pv[5]}, a3 = {pv[6], pv[7]};
-        const vl_f32x2 a4 = {pv[8], pv[9]}, a5 = {pv[10], pv[11]}, a6 = {pv[12], pv[13]}, a7 = {pv[14], pv[15]};
-        a0 += a4; a1 += a5; a2 += a6; a3 += a7;
-        a0 += a2; a1 += a3;
-        l2 += a0 + a1;
-      }
-      // ---- O^T += V^T . P^T ----
-      bf16x8 vf1[DT];
-#pragma unroll
-      for (int t = 0; t < DT; ++t) vf1[t] = *(const bf16x8*)(sV + (t * 32 + fr) * VSP + kt * 32 + 16 + fg * 8);
-      {
-        const bf16x8 pf = pack8x<F16>(pv);
-#pragma unroll
-        for (int t = 0; t < DT; ++t) o[t] = mfma32<F16>(vf0[t], pf, o[t]);
-      }
-      {
-        const bf16x8 pf = pack8x<F16>(pv + 8);
-#pragma unroll
-        for (int t = 0; t < DT; ++t) o[t] = mfma32<F16>(vf1[t], pf, o[t]);
-      }
-    }
-  }
-
-  VL_PROF_STAMP(p, 3);
-  if (wave_active) {
-    const float l_tot = xhalf_sum(l2[0] + l2[1]);
-    const float inv = 1.0f / l_tot;
-    store_rows_t<DT, F16>(o, inv, p.out + ((size_t)b * p.Lq + qrow) * (p.H * dhr) + h * dhr, fg, qidx < p.lq_main, nch);
-    if (p.lse && fg == 0 && qidx < p.lq_main)
-      p.lse[bh * p.Lq + qidx] = (m_run + __log2f(l_tot)) * 0.6931471805599453f;
-  }
-
-  VL_PROF_STAMP(p, 4);
-  if constexpr (TAILQ) {
+  // ---- the shared last row (query Lq-1, sees every key; host guarantees Lk <= KC and one workgroup per (b,h)) ----
+  // Its per-wave share (wave w: the row's scores against key tile w, one more MFMA pair against V, a (max, sum, O) partial
+  // in LDS) runs right behind the staging barrier, BEFORE the wave's own tiles; one workgroup barrier there; wave 0 merges
+  // the partials after its own tiles.  (Until round 6 all of it ran after the tiles: every wave waited at a barrier for the
+  // slowest one and then for wave 0's merge - 8.2 k of a workgroup's 33.2 k cycles, profiles/r05_attn_phase_timeline.log.)
+  auto tail_partials = [&]() {
+    if constexpr (TAILQ) {
     // ---- the shared last row (query Lq-1, sees every key; host guarantees Lk <= KC and one workgroup per (b,h)) ----
     const int qT = p.Lq - 1;
     const int ntile = (p.Lk + 31) >> 5;
@@ -280,7 +234,7 @@ __global__ void __launch_bounds__(NWMAX * 64, DH == 128 ? 2 : 4) attn_fwd_kernel
 #pragma unroll
         for (int t = 0; t < DT; ++t)
           ot[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              pa, *(const bf16x8*)(sV + (t * 32 + fr) * VSP + kt * 32 + c * 16 + fg * 8), ot[t], 0, 0, 0);
+              pa, DMA ? trV(kt, c, t) : *(const bf16x8*)(sV + (t * 32 + fr) * VSP + kt * 32 + c * 16 + fg * 8), ot[t], 0, 0, 0);
       }
       __builtin_amdgcn_wave_barrier();
       float* part = sPart + kt * (2 + DH);
@@ -290,23 +244,136 @@ __global__ void __launch_bounds__(NWMAX * 64, DH == 128 ? 2 : 4) attn_fwd_kernel
         for (int t = 0; t < DT; ++t) part[2 + t * 32 + fr] = ot[t][0];
       }
     }
-    __syncthreads();
-    if (wid == 0) {
-      float M = -INFINITY;
-      for (int kt = 0; kt < ntile; ++kt) M = fmaxf(M, sPart[kt * (2 + DH)]);
-      for (int d = lane; d < dhr; d += 64) {           // (one pass for head dims up to 64)
-        float L = 0.f, acc = 0.f;
-        for (int kt = 0; kt < ntile; ++kt) {
-          const float* part = sPart + kt * (2 + DH);
-          const float w = __builtin_amdgcn_exp2f(part[0] - M);
-          L = fmaf(part[1], w, L);
-          acc = fmaf(part[2 + d], w, acc);
+    }
+  };
+  auto tail_merge = [&]() {
+    if constexpr (TAILQ) {
+      const int qT = p.Lq - 1;
+      const int ntile = (p.Lk + 31) >> 5;
+      if (wid == 0) {
+        float M = -INFINITY;
+        for (int kt = 0; kt < ntile; ++kt) M = fmaxf(M, sPart[kt * (2 + DH)]);
+        for (int d = lane; d < dhr; d += 64) {           // (one pass for head dims up to 64)
+          float L = 0.f, acc = 0.f;
+          for (int kt = 0; kt < ntile; ++kt) {
+            const float* part = sPart + kt * (2 + DH);
+            const float w = __builtin_amdgcn_exp2f(part[0] - M);
+            L = fmaf(part[1], w, L);
+            acc = fmaf(part[2 + d], w, acc);
+          }
+          p.out[((size_t)b * p.Lq + qT) * (p.H * dhr) + h * dhr + d] = f2bf(acc / L);
+          if (p.lse && d == 0) p.lse[bh * p.Lq + qT] = (M + __log2f(L)) * 0.6931471805599453f;
         }
-        p.out[((size_t)b * p.Lq + qT) * (p.H * dhr) + h * dhr + d] = f2bf(acc / L);
-        if (p.lse && d == 0) p.lse[bh * p.Lq + qT] = (M + __log2f(L)) * 0.6931471805599453f;
+      }
+    }
+  };
+  const int q_hi = q0 + 31;  // last query row of this wave's tile
+  const int blk_q_hi = min(p.lq_main - 1, (int)(blockIdx.x * nwq + nwq) * 32 - 1);
+
+  for (int kc0 = 0; kc0 < (MULTI ? p.Lk : 1); kc0 += KC) {
+    if (MULTI && p.causal && kc0 > blk_q_hi) break;   // uniform across the workgroup
+    if constexpr (MULTI) {
+      if (kc0 > 0) {
+        __syncthreads();
+        // (one item per round here: the accumulators are live and 12 loads in flight would spill them)
+        stage2<DH, KC, true, false, false, true, 1>(StageSrc{sK, nullptr, Kg, p.k.sr, 1.f, nch},
+                                                    StageSrc{nullptr, sV, Vg, p.v.sr, 1.f, nch}, kc0, p.Lk, tid, nthr);
+      }
+    }
+    __syncthreads();
+    VL_PROF_STAMP(p, 2);
+    if constexpr (TAILQ) { tail_partials(); __syncthreads(); }      // (TAILQ: one chunk, every wave active)
+    if (!wave_active) continue;
+
+    int ntile = (min(p.Lk - kc0, KC) + 31) >> 5;
+    if (p.causal) ntile = min(ntile, ((q_hi - kc0) >> 5) + 1);
+    const int ksw = (fr >> RSH) & (CH - 1);
+    for (int kt = 0; kt < ntile; ++kt) {
+      // ---- S^T tile (rows = keys, cols = queries), relative to the running maximum ----
+      const unsigned char* kbase = sK + (kt * 32 + fr) * RB;
+      bf16x8 kf[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8*)(kbase + (((ks * 2 + fg) ^ ksw) * 16));
+      f32x16 s = mfma32<F16>(kf[0], qf[0], negm);
+#pragma unroll
+      for (int ks = 1; ks < KS; ++ks) s = mfma32<F16>(kf[ks], qf[ks], s);
+      // V^T fragments of the first 16-key slice: issued before the softmax arithmetic so that they land under it
+      // (the second slice is fetched after the exponentials, into the registers the scores vacate)
+      bf16x8 vf0[DT];
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        if constexpr (DMA) vf0[t] = trV(kt, 0, t);
+        else vf0[t] = *(const bf16x8*)(sV + (t * 32 + fr) * VSP + kt * 32 + fg * 8);
+      }
+      const int key0 = kc0 + kt * 32 + fg * 4;
+      const bool need_mask = (key0 - fg * 4 + 32 > p.Lk) || (p.causal && key0 - fg * 4 + 31 > q0);
+      if (need_mask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + (r & 3) + 8 * (r >> 2);
+          if (key >= p.Lk || (p.causal && key > qidx)) s[r] = -INFINITY;
+        }
+      }
+      float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);      // v_max3_f32 chain (file is built with -fno-honor-nans)
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+      mx = fmaxf(mx, s[15]);
+      mx = xhalf_max(mx);
+      if (__builtin_amdgcn_ballot_w64(first || mx > RESCALE_THR) != 0) {
+        // the maximum moved: shift this tile's scores, the C block and the accumulated sums (rare after the first tiles)
+        const float d = first ? mx : fmaxf(mx, 0.f);
+        const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-d);
+        m_run += d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] -= d; negm[r] -= d; }
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        l2 *= alpha;
+        first = false;
+      }
+      float pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r]);
+      {
+        vl_f32x2 a0 = {pv[0], pv[1]}, a1 = {pv[2], pv[3]}, a2 = {pv[4], pv[5]}, a3 = {pv[6], pv[7]};
+        const vl_f32x2 a4 = {pv[8], pv[9]}, a5 = {pv[10], pv[11]}, a6 = {pv[12], pv[13]}, a7 = {pv[14], pv[15]};
+        a0 += a4; a1 += a5; a2 += a6; a3 += a7;
+        a0 += a2; a1 += a3;
+        l2 += a0 + a1;
+      }
+      // ---- O^T += V^T . P^T ----
+      bf16x8 vf1[DT];
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        if constexpr (DMA) vf1[t] = trV(kt, 1, t);
+        else vf1[t] = *(const bf16x8*)(sV + (t * 32 + fr) * VSP + kt * 32 + 16 + fg * 8);
+      }
+      {
+        const bf16x8 pf = pack8x<F16>(pv);
+#pragma unroll
+        for (int t = 0; t < DT; ++t) o[t] = mfma32<F16>(vf0[t], pf, o[t]);
+      }
+      {
+        const bf16x8 pf = pack8x<F16>(pv + 8);
+#pragma unroll
+        for (int t = 0; t < DT; ++t) o[t] = mfma32<F16>(vf1[t], pf, o[t]);
       }
     }
   }
+
+  VL_PROF_STAMP(p, 3);
+  if (wave_active) {
+    const float l_tot = xhalf_sum(l2[0] + l2[1]);
+    const float inv = 1.0f / l_tot;
+    store_rows_t<DT, F16>(o, inv, p.out + ((size_t)b * p.Lq + qrow) * (p.H * dhr) + h * dhr, fg, qidx < p.lq_main, nch);
+    if (p.lse && fg == 0 && qidx < p.lq_main)
+      p.lse[bh * p.Lq + qidx] = (m_run + __log2f(l_tot)) * 0.6931471805599453f;
+  }
+
+  VL_PROF_STAMP(p, 4);
+  tail_merge();
   VL_PROF_STAMP(p, 5);
 }
 
@@ -314,14 +381,14 @@ __global__ void __launch_bounds__(NWMAX * 64, DH == 128 ? 2 : 4) attn_fwd_kernel
 
 extern "C" int vl_set_error(const char* msg);
 
-template <int DH, bool TAILQ, bool MULTI, bool F16 = false>
+template <int DH, bool TAILQ, bool MULTI, bool F16 = false, bool DMA = false>
 static int launch_fwd(const AttnP& p, int gx, int nwq, hipStream_t stream) {
   const size_t smem = (size_t)KC * DH * 2 + (size_t)DH * VSP * 2 + (size_t)NWMAX * 32 * 4 + (size_t)(KC / 32) * (2 + DH) * 4 +
                       (size_t)DH * 2;
-  static const hipError_t attr = hipFuncSetAttribute((const void*)attn_fwd_kernel<DH, TAILQ, MULTI, F16>,
+  static const hipError_t attr = hipFuncSetAttribute((const void*)attn_fwd_kernel<DH, TAILQ, MULTI, F16, DMA>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (attr != hipSuccess) return vl_set_error(hipGetErrorString(attr));
-  hipLaunchKernelGGL((attn_fwd_kernel<DH, TAILQ, MULTI, F16>), dim3(gx, p.H, p.B), dim3(nwq * 64), smem, stream, p);
+  hipLaunchKernelGGL((attn_fwd_kernel<DH, TAILQ, MULTI, F16, DMA>), dim3(gx, p.H, p.B), dim3(nwq * 64), smem, stream, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : vl_set_error(hipGetErrorString(e));
 }
@@ -351,6 +418,9 @@ extern "C" int vl_attn_fwd_bf16(const void* q, const void* k, const void* v, con
 #define VL_FWD(DHV)                                                                  \
   (tailq ? launch_fwd<DHV, true, false>(p, gx, nwq, stream)                          \
          : (multi ? launch_fwd<DHV, false, true>(p, gx, nwq, stream) : launch_fwd<DHV, false, false>(p, gx, nwq, stream)))
+  // head dim 64, one key chunk: K / V staged by LDS-DMA, V^T fragments by transpose reads (DMA = true)
+  if (dh == 64 && !multi)
+    return tailq ? launch_fwd<64, true, false, false, true>(p, gx, nwq, stream) : launch_fwd<64, false, false, false, true>(p, gx, nwq, stream);
   return dh == 64 ? VL_FWD(64) : (dh == 32 ? VL_FWD(32) : VL_FWD(128));
 #undef VL_FWD
 }

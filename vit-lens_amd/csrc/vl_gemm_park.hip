@@ -25,6 +25,15 @@
 //    the k-loop (2 loads per k-step over the last 8 steps) was built and measured: 0.74 ms against 0.67 ms (c_fc shape,
 //    bf16 residual) - same lesson as for the stores: keep the k-loop's vector-memory queue for the DMA.
 //
+//  * Round 6, measured and NOT kept (profiles/r06_kstagger_probe.log, r06_step_ab_kstagger_auxprefetch.log): (a) walking each
+//    tile's reduction from a rotated start (tile row * 2 k-steps, the vendor kernel's "StaggerU") so that the 256 workgroups
+//    do not ask for the same 128-byte column slab of rows 8 KB apart at the same instant: +3.6 % on c_proj + residual, +2.9 %
+//    on the dX of c_fc, +3.2 % at 8192^3 in isolation, nothing on the K = 1024 shapes; (b) requesting row block 0's second
+//    operand in the last k-step, in front of the next tile's first DMA batch.  Interleaved in the C3 step on one box, as
+//    separately built libraries (tools/build_variant.sh, tools/lib_ab.sh): 592.1 / 592.5 ms without either, 592.8 / 592.5 with
+//    both, 593.3 / 593.4 rotation only, 592.1 / 593.2 prefetch only - the board returns main-loop cycles as clock (DESIGN.md
+//    7.1).  The rotation also ends the bit-equality with the round-1 kernel that the parity tests use; both were removed.
+//
 // Replaces: nn.Linear / MultiheadAttention in/out projections of ResidualAttentionBlock
 // (open_clip/transformer.py:215,226-234,252-272) in forward and dX-backward at ViT-L sizes.
 #include <type_traits>
@@ -58,30 +67,6 @@ template <int I>
 using IC = std::integral_constant<int, I>;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-// ---- k-rotation ("stagger", round 6) ----
-// Every workgroup used to walk its tile's reduction from k = 0 upwards, so at any instant all 256 CUs asked the memory system
-// for the SAME 128-byte column slab of rows that lie a whole row pitch apart (8 KB at K = 4096): addresses that differ only
-// above bit 13 land on the same L2 / fabric channels, and the K = 4096 launches ran 2 830-3 030 cycles per k-step against
-// 2 470 for the same tile streamed from Infinity-Cache-resident rows (profiles/r05_kstep_probe.log; padding the rows by 128
-// bytes recovered a third, r05_stride_probe.log).  The vendor's 256x256x64 kernel (hipBLASLt, same macro tile) reaches
-// 1 530 TF/s on this shape where this kernel reached 1 254 (profiles/r06_vendor_gemm_yardstick.log) - it staggers the start
-// of the reduction per workgroup.  Here: tile (tm, tn) starts at k-step (tm * PK_KSTAG_STEP) mod nk and wraps around; the
-// offset is a function of the ROW tile only, so the workgroups that share an A row tile through their XCD's L2 stay in
-// phase.  The sum over k is the same set of products in a rotated order: results differ from the unrotated kernel in the
-// last fp32 bits, deterministically (a pure function of the tile index), and launch-to-launch bit identity holds.
-#ifndef PK_KSTAG_MODE
-#define PK_KSTAG_MODE 1          // 0 off, 1 by row tile, 2 by workgroup slot
-#endif
-#ifndef PK_KSTAG_STEP
-#define PK_KSTAG_STEP 2          // k-steps (of 128 bytes) between neighbouring offsets
-#endif
-#ifndef PK_AUX_PF
-#define PK_AUX_PF 1              // second operand of row block 0 requested in the last k-step (prefetch_aux0)
-#endif
-// (compile-time only: A/B variants of these are separate builds of the library, tools/build_variant.sh - the product has no knob)
-constexpr int kstag_mode = PK_KSTAG_MODE, kstag_step = PK_KSTAG_STEP;
-constexpr bool aux_pf = PK_AUX_PF != 0;
 
 // ACT (EPI_BF16 only): 0 none, 1 GELU, 2 ReLU, 3 GELU with the pre-activation also written to out2 (saved for backward),
 // 4 GELU with gelu'(pre-activation) written to out2.  EPI_DGELU: ACT 4 = the aux operand is that saved gelu'.
@@ -145,14 +130,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int gn = min(tiles_n - first_n, GN);
     const int tm = rem / gn;
     m0 = tm << 8; n0 = (first_n + (rem - tm * gn)) << 8;
-  };
-
-  // first k-step of a tile's rotated reduction (see PK_KSTAG_MODE above)
-  auto k_offset = [&](int ti, int m0) -> int {
-    if (kstag_mode == 0) return 0;
-    if constexpr (EPI == EPI_F32) return 0;        // split-K partial products (weight gradients): no SGPRs to spare in that instantiation
-    const unsigned id = kstag_mode == 1 ? (unsigned)(m0 >> 8) : (unsigned)(ti * G + slot);
-    return (int)((id * (unsigned)kstag_step) % (unsigned)nk);
   };
 
   // ---- LDS-DMA: unit i of an operand = rows i*64 + wid*8 + (lane>>3), 16-byte chunk (lane&7) ^ swizzle(row) ----
@@ -232,28 +209,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
   };
 
-  // Row block 0's second operand, requested in the LAST k-step of the tile (round 6): the four loads are independent of the
-  // accumulators, and until now they were issued at the start of the epilogue, BEHIND the next tile's first DMA batch in the
-  // in-order vector-memory queue (128 KB per CU) - the residual / gelu' epilogues waited 8-9 k cycles per tile more than the
-  // plain one for them (tools/gemm_phase_prof.py: 13.3 k against 5.0 k; the matrix pipes idle meanwhile).  They go out at the
-  // start of the k-step's third phase - the W fragments of the first half are dead by then and, this being the last k-step,
-  // no fragments of a next stage are loaded into them - i.e. in FRONT of that DMA batch, and the barrier of this k-step waits
-  // `vmcnt(4)`: everything older than these four loads (the DMA this barrier is for) has landed, the four may still fly.
-  // (Round 2's "2 loads per k-step over the last 8 steps" polluted the whole k-loop's queue and lost; this touches one step.)
-  auto prefetch_aux0 = [&]() {
-    if constexpr (HAS_AUX) {
-      int el = lane;
-      asm volatile("" : "+v"(el));              // (laundered: nothing of this may be hoisted above the k-loop)
-      const unsigned lo = (unsigned)(((el >> 3) * p.ldo + (el & 7) * 8) * 2);
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass)
-        aux[0][pass] = *(const u32x4*)(aux_src + (size_t)(chunk_row(pass) * ldo2) + lo);
-    }
-  };
-  auto aux_wait_and_barrier = [&]() {
-    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  };
-
   int cur_m0, cur_n0, cur_sp;
   tile_origin(0, cur_m0, cur_n0, cur_sp);
   auto set_aux = [&]() {
@@ -268,18 +223,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   // therefore enters the next tile at kt = nk-2: that tile's descriptors are prepared once per tile, outside the k-loop
   __amdgpu_buffer_rsrc_t rsA_n = rsA, rsW_n = rsW;
   int dti = 0, dkt = 0;
-  int dk = k_offset(0, cur_m0), dk_n = dk;          // rotated k-step the next DMA batch loads; first one of the next tile
   auto dma_step = [&](unsigned char* stage) {
-    constexpr bool ROT = EPI != EPI_F32;           // (the split-K instantiation keeps the plain order: see k_offset)
-    const int kbyte = (ROT ? dk : dkt) << 7;
-    if constexpr (ROT) { ++dk; if (dk == nk) dk = 0; }
+    const int kbyte = dkt << 7;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(stage + (i * NW + wid) * 1024), 16, voffA, kbyte + i * a_unit, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(stage + PK_ABYTES + (i * NW + wid) * 1024), 16, voffW, kbyte + i * w_unit, 0, 0);
     }
     ++dkt;
-    if (dkt == nk) { dkt = 0; ++dti; rsA = rsA_n; rsW = rsW_n; if constexpr (ROT) dk = dk_n; }
+    if (dkt == nk) { dkt = 0; ++dti; rsA = rsA_n; rsW = rsW_n; }
   };
   // hipcc does not wait for this builtin's LDS writes in front of a barrier: wait by hand.  The barrier is the raw
   // instruction: __syncthreads() carries a release fence, i.e. a compiler vmcnt(0)/lgkmcnt(0) for everything else, which
@@ -336,12 +288,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     mma16(IC<1>{}, 1, 0);
     __builtin_amdgcn_sched_barrier(0);
     ldA16(cur, 1, 1, 1);
-    if constexpr (last && HAS_AUX && aux_pf) prefetch_aux0();
     mma16(IC<0>{}, 0, 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (after_epi) { first_wait_and_barrier(); after_epi = false; }
-    else if constexpr (last && HAS_AUX && aux_pf) aux_wait_and_barrier();
-    else dma_wait_and_barrier();
+    if (after_epi) { first_wait_and_barrier(); after_epi = false; } else dma_wait_and_barrier();
     // (at the last k-step of a tile BOTH wave groups issue at once: the batch must sit in front of the epilogue's stores)
     if (dti < my_tiles) { if (!grpB || last) dma_step(cur); else pendB = true; }
     if constexpr (!last) first_frags(oth);
@@ -356,7 +305,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       int nm0, nn0, nsp;
       tile_origin(ti + 1, nm0, nn0, nsp);
       make_rsrc(nm0, nn0, nsp, rsA_n, rsW_n);
-      if constexpr (EPI != EPI_F32) dk_n = k_offset(ti + 1, nm0);
     }
     set_aux();
     PK_PROF_T(t_a);
@@ -374,8 +322,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       prow = el >> 3; pcol = (el & 7) * 8;
       lo_out = (unsigned)((prow * pe.ldo + pcol) * 2);
       const int fr16 = el & 15, fq = el >> 4;      // shadow the main loop's copies
-      // (HAS_AUX: row block 0's second operand was requested in the last k-step - prefetch_aux0)
-      if constexpr (HAS_AUX && !aux_pf) load_block(IC<0>{});
+      if constexpr (HAS_AUX) {
+        load_block(IC<0>{});
+      }
       unsigned char* const slab = smem + 2 * PK_STAGE + wid * SLAB;
       // branch-free optional bias: read SOMETHING valid (the weight matrix) and select zero
       const bool has_bias = pe.bias != nullptr;
