@@ -320,7 +320,7 @@ _pad_cache = {}
 
 def _zero_padded(t, cols, tag):
     """t [R, c] bf16 -> a [R, cols] bf16 buffer (cached per shape and role) whose first c columns are t and the rest zero."""
-    key = (tag, t.device, t.shape[0], cols)
+    key = (tag, t.device, t.shape[0], t.shape[1], cols)      # (the source width is part of the key: the pad columns must stay zero)
     buf = _pad_cache.get(key)
     if buf is None:
         buf = torch.zeros(t.shape[0], cols, device=t.device, dtype=torch.bfloat16)      # the pad columns are written once: zeros
