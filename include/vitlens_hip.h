@@ -54,7 +54,6 @@ typedef struct ihipStream_t* hipStream_t;
 #define VL_GEMM_AUTO (-1)
 #define VL_GEMM_PERSIST 8
 #define VL_GEMM_PINGPONG 10
-#define VL_GEMM_LONGK 14
 
 const char* vl_last_error(void);
 /* ABI version of THIS header: bumped whenever an exported signature changes (round 5 changed vl_ln_row_stats and added the
@@ -73,8 +72,6 @@ int vl_version(void);
  *    8 VL_GEMM_PERSIST  vl_gemm_park.hip: persistent, 256x256 tiles, LDS-DMA two k-steps ahead, 16x16x32 MFMA, burst of
  *                       non-temporal stores; M % 256 == N % 256 == 0, K >= 512
  *   10 VL_GEMM_PINGPONG vl_gemm_pp.hip: two 4-wave workgroups per CU on 256x128 tiles (widths that are multiples of 128 only)
- *   14 VL_GEMM_LONGK    vl_gemm_w4.hip (round 6): persistent, 256x256 tiles, ONE wave per SIMD on 128x128 wave tiles; K >= 2048,
- *                       plain bf16 / bf16-residual epilogues; what -1 uses for such launches
  *    5 (4 = alias)      round-1 persistent kernel (any shape) | 6: the same on 256x128 tiles
  *    0 / 1              one 256x256 / 128x128 LDS-DMA tile per workgroup | 2 / 3: the same with register staging
  *    9                  split-K tail kernel (32x32 tile per workgroup) | 11 / 12: 64x64 / 128x64 tiles

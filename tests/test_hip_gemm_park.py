@@ -350,49 +350,3 @@ def test_many_tiles_lnfold_variants():
     of = plain.float()
     assert float((s[:, :, 0].sum(1) - of.sum(1)).abs().max()) < 2e-2 * float(of.abs().sum(1).max())
     assert relerr(s[:, :, 1].sum(1), (of * of).sum(1)) < 1e-4
-
-
-@pytest.mark.parametrize("M,N,K", [(256 * 40, 1024, 4096), (256 * 3, 512, 2048), (256 * 257, 256, 2048), (65536, 4096, 2048)])
-def test_longk_one_wave_per_simd_kernel(M, N, K):
-    """vl_gemm_w4.hip (round 6; cfg 14, and what cfg -1 picks for K >= 2048): one wave per SIMD on 128x128 wave tiles, plain
-    bf16 and bf16-residual epilogues, the latter also with the LayerNorm folding's partial row sums.  Against fp32 torch on
-    the same bf16 operands; BIT-identical to the 8-wave kernel (same products, same order); bit-identical from launch to
-    launch; 1 to 16 tiles per workgroup (the tile hand-over: DMA across the boundary, stores left draining behind the first
-    barrier of the next tile); in place."""
-    ops = _ops()
-    a = rnd(M, K, seed=71).bfloat16().cuda(); w = rnd(N, K, seed=72, scale=K ** -0.5).bfloat16().cuda()
-    bias = rnd(N, seed=73).cuda()
-    res = rnd(M, N, seed=74).bfloat16().cuda()
-    acc = a.float() @ w.float().t()
-    o14 = ops.gemm(a, w, bias, epi=ops.EPI_BF16, cfg=14)
-    assert relerr(o14, acc + bias) < 4e-3
-    assert torch.equal(o14, ops.gemm(a, w, bias, epi=ops.EPI_BF16, cfg=8))
-    assert torch.equal(o14, ops.gemm(a, w, bias, epi=ops.EPI_BF16, cfg=14))
-    if M % 256 == 0 and (M // 256) * (N // 256) % 256 == 0:
-        assert torch.equal(o14, ops.gemm(a, w, bias, epi=ops.EPI_BF16))                  # the auto dispatch takes this kernel
-    assert relerr(ops.gemm(a, w, None, epi=ops.EPI_BF16, cfg=14, alpha=0.5), 0.5 * acc) < 4e-3
-    r14 = ops.gemm(a, w, bias, res=res, epi=ops.EPI_RES_BF16, cfg=14)
-    assert relerr(r14, res.float() + acc + bias) < 4e-3
-    assert torch.equal(r14, ops.gemm(a, w, bias, res=res, epi=ops.EPI_RES_BF16, cfg=8))
-    x = res.clone()
-    ops.gemm(a, w, bias, out=x, res=x, epi=ops.EPI_RES_BF16, cfg=14)                      # in place
-    assert torch.equal(x, r14)
-    # + partial row sums of what it stores (vl_gemm_res_rowstats_bf16 routes K >= 2048 here)
-    part = torch.full((M * (N // 64) * 2,), float("nan"), device="cuda")
-    out = torch.empty_like(res)
-    mm = ops.gemm_res_rowstats(a, w, bias, out, res, part)
-    assert mm > 0 and torch.equal(out[:mm], r14[:mm])
-    mean = torch.empty(M, device="cuda"); rstd = torch.empty(M, device="cuda")
-    ops.ln_row_stats(part, out, mm, mean, rstd)
-    of = out.float()
-    assert float((mean - of.mean(1)).abs().max()) < 2e-5 * (1 + float(of.mean(1).abs().max()))
-    assert float((rstd / (of.var(1, unbiased=False) + 1e-5).rsqrt() - 1).abs().max()) < 2e-4
-    part2 = torch.empty_like(part); out2 = torch.empty_like(res)
-    ops.gemm_res_rowstats(a, w, bias, out2, res, part2)
-    n = mm * (N // 64) * 2
-    assert torch.equal(part[:n], part2[:n]) and torch.equal(out, out2)
-    # refusals: short reductions and epilogues it does not carry stay on the 8-wave kernel
-    with pytest.raises(RuntimeError):
-        ops.gemm(a[:, :1024].contiguous(), w[:, :1024].contiguous(), bias, epi=ops.EPI_BF16, cfg=14)
-    with pytest.raises(RuntimeError):
-        ops.gemm(a, w, bias, epi=ops.EPI_BF16, act=ops.ACT_GELU, cfg=14)

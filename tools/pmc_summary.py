@@ -12,7 +12,7 @@ csv.field_size_limit(1 << 30)
 
 
 def short(name):
-    m = re.search(r"(gemm_nt_pk4?_kernel<[^>]*>|gemm_nt_w4_kernel<[^>]*>|gemm_tn_kernel[^(]*|attn_\w+_kernel(<[^>]*>)?)", name)
+    m = re.search(r"(gemm_nt_pk4?_kernel<[^>]*>|gemm_tn_kernel[^(]*|attn_\w+_kernel(<[^>]*>)?)", name)
     if m:
         return m.group(1)
     m = re.search(r"(Cijk_\w*MT\d+x\d+x\d+\w*)", name)          # vendor (Tensile) kernels: tools/vendor_gemm_yardstick.py

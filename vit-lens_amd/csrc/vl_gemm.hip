@@ -731,10 +731,6 @@ int vl_gemm_park_launch(int epi, const void* params, int ncu, hipStream_t s);
 // vl_gemm_pp.hip: the round-3 ping-pong kernel (two 4-wave workgroups per CU, 256x128 tiles, K >= 128)
 bool vl_gemm_pp_supported(int epi, const void* params);
 int vl_gemm_pp_launch(int epi, const void* params, int ncu, hipStream_t s);
-// vl_gemm_w4.hip: the round-6 one-wave-per-SIMD kernel (128x128 wave tiles) for long reductions (K >= 2048; plain bf16 and
-// bf16-residual epilogues, the latter with the LayerNorm folding's partial row sums)
-bool vl_gemm_w4_supported(int epi, const void* params);
-int vl_gemm_w4_launch(int epi, const void* params, int ncu, hipStream_t s);
 namespace {
 
 // the persistent kernel for a problem whose M is a whole number of tiles: the round-3 / round-2 kernels where they apply
@@ -743,11 +739,6 @@ hipError_t launch_best_persist(const GemmP& p0, hipStream_t s) {
   const GemmP& p = p0;
   // 256x256 tiles where N allows them (fewer operand bytes per flop: the chip is power-bound on these GEMMs, DESIGN.md
   // section 7); the ping-pong kernel's 256x128 tiles take N % 256 == 128 (ViT-bigG: 1664 = 13 x 128)
-  // long reductions (K >= 2048): one wave per SIMD, 128x128 wave tiles (vl_gemm_w4.hip; the 8-wave kernel waits for
-  // HBM-sourced operand rows there)
-#ifndef VL_NO_W4          // (measurement builds only: tools/build_variant.sh now4 -DVL_NO_W4 vl_gemm.hip - the A/B partner of the product)
-  if (vl_gemm_w4_supported(EPI, &p)) return (hipError_t)vl_gemm_w4_launch(EPI, &p, num_cus(), s);
-#endif
   if (vl_gemm_park_supported(EPI, &p)) return (hipError_t)vl_gemm_park_launch(EPI, &p, num_cus(), s);
   if (vl_gemm_pp_supported(EPI, &p)) return (hipError_t)vl_gemm_pp_launch(EPI, &p, num_cus(), s);
   return launch_persist<EPI>(p, s);
@@ -762,10 +753,6 @@ hipError_t dispatch(const GemmP& p, int cfg, hipStream_t s) {
   if (cfg == 10) {
     if (!vl_gemm_pp_supported(EPI, &p)) return hipErrorInvalidValue;
     return (hipError_t)vl_gemm_pp_launch(EPI, &p, num_cus(), s);
-  }
-  if (cfg == 14) {
-    if (!vl_gemm_w4_supported(EPI, &p)) return hipErrorInvalidValue;
-    return (hipError_t)vl_gemm_w4_launch(EPI, &p, num_cus(), s);
   }
   // cfg bit0: 0 = 256x256 tile (8 waves), 1 = 128x128 tile (4 waves); bit1: 1 = register staging
   if (cfg == 4 || cfg == 5) return launch_persist<EPI>(p, s);       // 4: historical alias
@@ -879,13 +866,7 @@ extern "C" int vl_gemm_res_rowstats_bf16(const void* A, const void* W, const flo
   p.row_part = row_part;
   const GemmP& q = p;
   VL_CHECK_ARG(vl_gemm_park_supported(EPI_RES_BF16, &q), "vl_gemm_res_rowstats_bf16: whole 256x256 tiles, K >= 512, 16-byte aligned operands required");
-#ifndef VL_NO_W4
-  const bool longk = vl_gemm_w4_supported(EPI_RES_BF16, &q);
-#else
-  const bool longk = false;
-#endif
-  const hipError_t e = longk ? (hipError_t)vl_gemm_w4_launch(EPI_RES_BF16, &q, num_cus(), stream)
-                             : (hipError_t)vl_gemm_park_launch(EPI_RES_BF16, &q, num_cus(), stream);
+  const hipError_t e = (hipError_t)vl_gemm_park_launch(EPI_RES_BF16, &q, num_cus(), stream);
   if (e != hipSuccess) return vl_set_error(hipGetErrorString(e));
   return 0;
 }

@@ -33,6 +33,19 @@
 //    separately built libraries (tools/build_variant.sh, tools/lib_ab.sh): 592.1 / 592.5 ms without either, 592.8 / 592.5 with
 //    both, 593.3 / 593.4 rotation only, 592.1 / 593.2 prefetch only - the board returns main-loop cycles as clock (DESIGN.md
 //    7.1).  The rotation also ends the bit-equality with the round-1 kernel that the parity tests use; both were removed.
+//  * Round 6, the vendor yardstick and a second one-wave-per-SIMD kernel (vl_gemm_w4.hip, in the history at commit "vl_gemm_w4.hip:
+//    one wave per SIMD ..."): hipBLASLt's 256x256x64 kernel (4 waves of 128x128, 512 registers, fragments of half a k-step
+//    resident) runs (65 536, 1 024, 4 096) at 1 491-1 530 TF/s and 8192^3 at 1 647 where this kernel reaches 1 228-1 254 and
+//    1 464 - and on the K = 1 024 shapes this kernel is 2-3 % ahead, 16-18 % at M = 65 792 (profiles/r06_vendor_gemm_yardstick.log,
+//    counters: r06_vendor_vs_ours_pmc.txt - same L2 traffic, matrix pipe busy 0.84 against 0.67 at K = 4 096).  The rebuilt
+//    one-wave-per-SIMD kernel (one fragment read or one DMA instruction behind every second MFMA, two barriers per k-step,
+//    bit-identical results) reached 1 113-1 147 on the K = 4 096 launches and cost the C3 step 8 ms (591.3 against 583.5 ms,
+//    profiles/r06_step_ab_w4_longk_kernel.log).  Ablation builds of it say where its k-loop goes (r06_w4_ablation*.log, dX of
+//    c_fc / 8192^3): as built 1 139 / 1 551; without the 16 DMA instructions per wave and k-step 1 603 / 1 893; without
+//    barriers 1 256 / 1 593; without fragment reads 1 189 / 1 664; bare MFMAs 1 730 / 2 070; the XOR-permuted chunk order on
+//    the global side of the DMA makes no difference (1 091 against 1 098).  With one wave per SIMD every LDS-DMA issue idles
+//    the matrix pipe, here the partner wave covers it; how the vendor's hand-scheduled stream issues the same 16 pieces per
+//    wave without that cost is not visible in its disassembly.  Removed; the 8-wave kernel stays the product for every shape.
 //
 // Replaces: nn.Linear / MultiheadAttention in/out projections of ResidualAttentionBlock
 // (open_clip/transformer.py:215,226-234,252-272) in forward and dX-backward at ViT-L sizes.
