@@ -75,6 +75,9 @@ def parse():
                          "the per-launch `roofline` figures come from a short SERIAL pass after the timed region (a launch's "
                          "HIP-event duration only measures that launch when it owns the chip); `roofline.measured_on` says which")
     ap.add_argument("--overlap-frozen", dest="overlap_frozen", action="store_true", help="(round-5 spelling; now the default)")
+    ap.add_argument("--no-overlap-backward", dest="overlap_backward", action="store_false", default=True,
+                    help="c3 / c4 / c5: the two halves of the micro-batches run their backward on ONE stream (default: on two, "
+                         "round 6; same arithmetic either way)")
     ap.add_argument("--serial-steps", type=int, default=2, help="steps of the serial roofline pass (overlap on only)")
     ap.add_argument("--force-dist", action="store_true",
                     help="--gpus 1 only: initialise a ONE-rank RCCL communicator and run the step's multi-rank code path on it "
@@ -565,7 +568,7 @@ def main():
             audio = (torch.randn(a.batch, 512, 128, generator=g) * 0.5).to(dev)
             trainer = vstep.DualAudioStep(sd, tower_cfg, engine.TextCfg(), lens_cfg, dev, micro_batch=a.micro_batch,
                                           rank=rank, world_size=world, gemm_cfg=a.gemm_cfg, frozen_res_dtype=res_dtype, train_res_dtype=res_dtype, comm=comm,
-                                          force_comm=a.force_dist, text_arith=a.text_arith, overlap_frozen=a.overlap_frozen)
+                                          force_comm=a.force_dist, text_arith=a.text_arith, overlap_frozen=a.overlap_frozen, overlap_backward=a.overlap_backward)
 
             def step():
                 return trainer.step(audio, texts)
@@ -576,7 +579,7 @@ def main():
             start = torch.randint(0, 8192, (a.batch,), generator=g).to(dev)
             trainer = vstep.TriModalPCStep(sd, tower_cfg, engine.TextCfg(), lens_cfg, dev, micro_batch=a.micro_batch,
                                            rank=rank, world_size=world, gemm_cfg=a.gemm_cfg, bn_training=True, frozen_res_dtype=res_dtype, train_res_dtype=res_dtype, comm=comm,
-                                           bn_sync=a.bn_sync, force_comm=a.force_dist, text_arith=a.text_arith, overlap_frozen=a.overlap_frozen)
+                                           bn_sync=a.bn_sync, force_comm=a.force_dist, text_arith=a.text_arith, overlap_frozen=a.overlap_frozen, overlap_backward=a.overlap_backward)
 
             def step():
                 return trainer.step(images, texts, pts, start)
@@ -614,7 +617,7 @@ def main():
         texts = synth_text(a.batch, g).to(dev)
         trainer = vstep.TriModalDepthStep(sd, engine.TowerCfg(), engine.TextCfg(), dev, micro_batch=a.micro_batch,
                                           unlock_first_n=4, rank=rank, world_size=world, gemm_cfg=a.gemm_cfg, frozen_res_dtype=res_dtype, train_res_dtype=res_dtype, comm=comm,
-                                          force_comm=a.force_dist, text_arith=a.text_arith, overlap_frozen=a.overlap_frozen)
+                                          force_comm=a.force_dist, text_arith=a.text_arith, overlap_frozen=a.overlap_frozen, overlap_backward=a.overlap_backward)
 
         def step():
             return trainer.step(images, texts, depths)
@@ -645,7 +648,7 @@ def main():
     if overlapped:
         # per-launch roofline figures: the SAME step with the frozen towers in the launch stream, outside the timed region
         # (`value` / `ms_per_step` above are the default, overlapped path); every rank runs it - the step has collectives
-        trainer_obj.overlap_frozen = False
+        trainer_obj.overlap_frozen = False              # (one stream for everything: `_overlap_active` is False)
         step(); torch.cuda.synchronize()
         timer.on = True
         ts = time.perf_counter()
@@ -722,6 +725,8 @@ def main():
                           "text_tower_operands": {"f16": "fp16", "bf16x2": "bf16 x 2 weight terms", "bf16": "bf16"}[a.text_arith] if a.workload != "c2" else "n/a",
                           "layernorm": "folded into the GEMMs (frozen blocks)" if LN_FOLDED else "own passes",
                           "frozen_towers": ("second HIP stream beside the trainable tower's forward" if overlapped else "launch stream"),
+                          "backward": ("two halves of the micro-batches on two HIP streams" if (overlapped and a.overlap_backward and a.batch // a.micro_batch >= 2)
+                                       else "one stream"),
                           **({"force_dist": True} if a.force_dist else {})},
                "roofline": roof}
         if a.workload != "c2":

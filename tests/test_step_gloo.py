@@ -84,6 +84,7 @@ def _fake_ops():
         p.addcdiv_(m / (1 - b1 ** step), (v / (1 - b2 ** step)).sqrt() + eps, value=-lr)
     o.adamw_step = adamw_step
     o.clamp_scalar = lambda t, lo, hi: t.clamp_(lo, hi)
+    o.axpy = lambda y, x, alpha=1.0: y.add_(x, alpha=alpha)
     o.cast_bf16 = lambda x, out=None: x if out is None else out.copy_(x)
     return o
 
@@ -184,8 +185,8 @@ def _worker(rank, world, port, recipe, local_loss, gwg, ret, overlap=False):
             self.masters["visual.W"] = Wv.clone()
             self._mk = lambda: _LinearTower(self.masters["visual.W"], self.grads, "visual.W")
 
-        def _bind_grads(self, t):
-            t.grads = self.grads
+        def _bind_grads(self, t, grads=None):
+            t.grads = self.grads if grads is None else grads
 
     kw = dict(micro_batch=2, lr=1e-2, rank=rank, world_size=world, comm=comm, local_loss=local_loss, gather_with_grad=gwg,
               overlap_frozen=overlap)

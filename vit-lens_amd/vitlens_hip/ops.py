@@ -320,7 +320,8 @@ _pad_cache = {}
 
 def _zero_padded(t, cols, tag):
     """t [R, c] bf16 -> a [R, cols] bf16 buffer (cached per shape and role) whose first c columns are t and the rest zero."""
-    key = (tag, t.device, t.shape[0], t.shape[1], cols)      # (the source width is part of the key: the pad columns must stay zero)
+    # (the source width is part of the key: the pad columns must stay zero; the stream too: two backwards run side by side)
+    key = (tag, t.device, torch.cuda.current_stream(t.device).cuda_stream, t.shape[0], t.shape[1], cols)
     buf = _pad_cache.get(key)
     if buf is None:
         buf = torch.zeros(t.shape[0], cols, device=t.device, dtype=torch.bfloat16)      # the pad columns are written once: zeros
@@ -557,10 +558,12 @@ _colreduce_ws = {}
 def _ws_for(device, rows, cols, planes):
     """Workspace of the deterministic two-stage column reductions (cached per device, grown on demand)."""
     need = int(_lib.vl_colreduce_ws_floats(rows, cols, planes))             # the kernels' own slab geometry, not a copy of it
-    t = _colreduce_ws.get(device)
+    # one workspace per device AND stream: two micro-batches' backwards run on two HIP streams (step.py, round 6)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    t = _colreduce_ws.get(key)
     if t is None or t.numel() < need:
         t = torch.empty(need, device=device, dtype=torch.float32)
-        _colreduce_ws[device] = t
+        _colreduce_ws[key] = t
     return t
 
 

@@ -93,7 +93,7 @@ class _StepState:
     and `optimizer.state_dict()`)."""
 
     def _init_host(self, sd, device, micro_batch, rank, world_size, comm=None, local_loss=False, gather_with_grad=False,
-                   force_comm=False, overlap_frozen=False):
+                   force_comm=False, overlap_frozen=False, overlap_backward=True):
         """Everything of a step that is HOST state - flags, the communicator, the (still empty apart from logit_scale) master
         table, the gradient-bucket bookkeeping - and nothing that touches an engine or a kernel.  Every step's `__init__`
         runs this first and then its `_build()` (engines, masters of the trainable set); tests/test_step_gloo.py drives the
@@ -109,6 +109,8 @@ class _StepState:
         # `_overlap_active` says whether this device can honour it (a CPU device - the gloo tests - runs the serial order,
         # the same arithmetic)
         self.overlap_frozen = bool(overlap_frozen)
+        # with it: the two halves of a step's micro-batches run their BACKWARD on the two streams too (_backward_all)
+        self.overlap_backward = bool(overlap_backward)
         self._side = None
         self._base_sd = {k: v.detach() for k, v in sd.items()}
         self.logit_scale = sd["logit_scale"].detach().float().reshape(1).to(device).clone()
@@ -338,10 +340,11 @@ class TriModalDepthStep(_StepState):
                  rank: int = 0, world_size: int = 1, gemm_cfg: int = -1, comm=None, frozen_res_dtype=torch.float32,
                  local_loss: bool = False, gather_with_grad: bool = False, train_res_dtype=torch.float32,
                  grad_checkpointing: bool = False, force_comm: bool = False, text_wsplit: Optional[bool] = None, text_arith: str = "f16",
-                 overlap_frozen: bool = True):
+                 overlap_frozen: bool = True, overlap_backward: bool = True):
         """overlap_frozen (default ON since round 6): the image / text towers' forwards run on a second HIP stream beside
         the trainable tower's forward (`_frozen_beside`); results are bit-identical to the serial order."""
-        self._init_host(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad, force_comm, overlap_frozen)
+        self._init_host(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad, force_comm, overlap_frozen,
+                        overlap_backward)
         self.grad_checkpointing = bool(grad_checkpointing)      # block recompute in the trainable tower (transformer.py:366-368)
         self.unlock_first_n = unlock_first_n
         self._build(sd, tower, text, gemm_cfg=gemm_cfg, frozen_res_dtype=frozen_res_dtype, train_res_dtype=train_res_dtype,
@@ -396,6 +399,12 @@ class TriModalDepthStep(_StepState):
         off = 0
         for k, v in self.masters.items():
             self.grads[k] = self.flat_grad[off:off + v.numel()].view(v.shape)
+            off += al(v.numel())
+        # a second buffer of the same layout: the first half of a step's micro-batches accumulates here (forward_backward)
+        self.flat_grad_b = torch.zeros_like(self.flat_grad)
+        self.grads_b, off = {}, 0
+        for k, v in self.masters.items():
+            self.grads_b[k] = self.flat_grad_b[off:off + v.numel()].view(v.shape)
             off += al(v.numel())
         for t in self.trainers:
             t.tower.grads = self.grads
@@ -519,13 +528,64 @@ class TriModalDepthStep(_StepState):
         l2, _, dv2, ds2 = pair_loss_and_grads(self.comm, self.rank, self.world, ft, fv, at, av, scale, **kw)
         loss = l1 + l2
         dvraw = ops.l2_normalize_bwd(fv, dv1 + dv2, vnorm)
-        for i in range(nmb):
-            # gradients accumulate over micro-batches: a block's bucket is final once the LAST micro-batch has passed it
-            cb = self._start_block_reduce if (i == nmb - 1 and self.dist and self.unlock_first_n > 0) else None
-            self._trainer(i).backward(dvraw[i * mb:(i + 1) * mb].contiguous(), cb)
+        self._backward_all(dvraw, nmb, mb)
         # logit_scale is exp()'d in forward (model.py:619); with the device-side scale pair_backward returns d/d(log-scale)
         self.grads["logit_scale"] += ds1 + ds2
         return loss
+
+    def _backward_all(self, dvraw, nmb, mb):
+        """Backward of every micro-batch; parameter gradients accumulate over them.
+
+        With two or more micro-batches the FIRST half accumulates into a second gradient buffer (`flat_grad_b`) and the second
+        half into `flat_grad`; a block's bucket is merged (and, across ranks, its all-reduce started) when the LAST micro-batch
+        of the second half has passed the block, the rest (adapter, position table) at the end.  That makes the two halves
+        independent streams of work: with `overlap_frozen` on a GPU the first half runs on the second HIP stream beside the
+        second half - the backward is a chain of chip-filling GEMMs with latency-bound kernels between them (fused attention
+        backward, LayerNorm backward, leftover rows, the drain of every persistent launch), exactly what the forward's two
+        towers fill for each other.  The arithmetic - which products are added in which order - is the same on one stream
+        and on two: results are bit-identical (tests/test_hip_train.py).  Reference: loss.backward() over the micro-batches
+        of the accumulation loop, training/train.py:154-210 (gradients of all micro-batches summed into .grad)."""
+        dist_cb = self.dist and self.unlock_first_n > 0
+        dv = lambda i: dvraw[i * mb:(i + 1) * mb].contiguous()
+        half = nmb // 2
+        for i in range(nmb):
+            self._trainer(i).tower.grads = self.grads_b if i < half else self.grads
+        if half == 0:
+            self._trainer(0).backward(dv(0), self._start_block_reduce if dist_cb else None)
+            return
+        self.flat_grad_b.zero_()
+        two_streams = self._overlap_active and self.overlap_backward
+        passed = {}          # block -> event on the first half's stream: its last micro-batch has passed the block
+
+        def first_done(l):
+            if two_streams:
+                passed[l] = torch.cuda.Event()
+                passed[l].record()
+
+        def second_done(l):
+            if two_streams:
+                torch.cuda.current_stream(self.dev).wait_event(passed[l])
+            lo, hi = self._block_range(l)
+            ops.axpy(self.flat_grad[lo:hi], self.flat_grad_b[lo:hi])
+            if dist_cb:
+                self._start_block_reduce(l)
+
+        def first_half():
+            for i in range(half):
+                self._trainer(i).backward(dv(i), first_done if i == half - 1 else None)
+
+        def second_half():
+            for i in range(half, nmb):
+                self._trainer(i).backward(dv(i), second_done if i == nmb - 1 else None)
+        if two_streams:
+            self._frozen_beside(first_half, second_half)      # (first closure on the second stream, joined at the end)
+        else:
+            first_half(); second_half()
+        n = self.flat_grad.numel()
+        lo, hi = self._rest_ranges() if self.unlock_first_n > 0 else (0, 0)
+        for a, b in ((0, lo), (hi, n)):
+            if b > a:
+                ops.axpy(self.flat_grad[a:b], self.flat_grad_b[a:b])
 
 
 class _PerceiverLensStep(_StepState):
@@ -578,17 +638,48 @@ class _PerceiverLensStep(_StepState):
             self.trainers.append(t)
         return self.trainers[i]
 
-    def _bind_grads(self, t):
-        t.tower.grads = self.grads; t.perc.grads = self.grads
+    def _bind_grads(self, t, grads=None):
+        g = self.grads if grads is None else grads
+        t.tower.grads = g; t.perc.grads = g
 
     def _alloc_flat_grads(self):
         al = lambda n: (n + 3) // 4 * 4                       # every view starts 16-byte aligned
         self.flat_grad = torch.zeros(sum(al(v.numel()) for v in self.masters.values()), device=self.dev, dtype=torch.float32)
-        off = 0
+        self.flat_grad_b = torch.zeros_like(self.flat_grad)  # the first half of a step's micro-batches accumulates here (_backward_all)
+        self.grads_b, off = {}, 0
         for k, v in self.masters.items():
-            self.grads[k] = self.flat_grad[off:off + v.numel()].view(v.shape); off += al(v.numel())
+            self.grads[k] = self.flat_grad[off:off + v.numel()].view(v.shape)
+            self.grads_b[k] = self.flat_grad_b[off:off + v.numel()].view(v.shape)
+            off += al(v.numel())
         for t in self.trainers:
             self._bind_grads(t)
+
+    def _backward_all(self, dvraw, nmb, mb):
+        """Backward of every micro-batch (TriModalDepthStep._backward_all): the first half of the micro-batches accumulates into
+        `flat_grad_b`, the second into `flat_grad`, one merge at the end; with `overlap_frozen` on a GPU the two halves run on
+        two HIP streams.  Same arithmetic on one stream and on two.  Not with SyncBatchNorm (its backward exchanges data on the
+        communicator from inside the micro-batch: one stream)."""
+        dv = lambda i: dvraw[i * mb:(i + 1) * mb].contiguous()
+        half = nmb // 2
+        for i in range(nmb):
+            self._bind_grads(self._trainer(i), self.grads_b if i < half else self.grads)
+        if half == 0:
+            self._trainer(0).backward(dv(0))
+            return
+        self.flat_grad_b.zero_()
+
+        def first_half():
+            for i in range(half):
+                self._trainer(i).backward(dv(i))
+
+        def second_half():
+            for i in range(half, nmb):
+                self._trainer(i).backward(dv(i))
+        if getattr(self, "_one_stream_backward", False) or not self.overlap_backward:
+            first_half(); second_half()
+        else:
+            self._frozen_beside(first_half, second_half)
+        ops.axpy(self.flat_grad, self.flat_grad_b)
 
     def _prepare(self, B):
         mb = min(self.mb, B)
@@ -647,8 +738,9 @@ class DualAudioStep(_PerceiverLensStep):
                  betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.2, rank: int = 0, world_size: int = 1,
                  gemm_cfg: int = -1, comm=None, frozen_res_dtype=torch.float32, local_loss: bool = False,
                  gather_with_grad: bool = False, train_res_dtype=torch.float32, force_comm: bool = False, text_wsplit: Optional[bool] = None, text_arith: str = "f16",
-                 overlap_frozen: bool = True):
-        self._init_host(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad, force_comm, overlap_frozen)
+                 overlap_frozen: bool = True, overlap_backward: bool = True):
+        self._init_host(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad, force_comm, overlap_frozen,
+                        overlap_backward)
         self._build(sd, tower, text, lens, gemm_cfg=gemm_cfg, frozen_res_dtype=frozen_res_dtype, train_res_dtype=train_res_dtype,
                     text_wsplit=text_wsplit, text_arith=text_arith)
         self.opt = AdamW(self.masters, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
@@ -696,8 +788,7 @@ class DualAudioStep(_PerceiverLensStep):
         loss, dv, _, ds = pair_loss_and_grads(self.comm, self.rank, self.world, fv, ft, av, at, scale,    # ClipLossGeneral(x=visual, y=text)
                                               local_loss=self.local_loss, gather_with_grad=self.gather_with_grad, need_y=False, dist=self.dist)
         dvraw = ops.l2_normalize_bwd(fv, dv, vnorm)
-        for i in range(nmb):
-            self._trainer(i).backward(dvraw[i * mb:(i + 1) * mb].contiguous())
+        self._backward_all(dvraw, nmb, mb)
         self.grads["logit_scale"] += ds
         return loss
 
@@ -721,8 +812,9 @@ class TriModalPCStep(_PerceiverLensStep):
                  gemm_cfg: int = -1, bn_training: bool = True, unlock_cls: bool = False, comm=None,
                  frozen_res_dtype=torch.float32, local_loss: bool = False, gather_with_grad: bool = False,
                  train_res_dtype=torch.float32, bn_sync: bool = False, force_comm: bool = False, text_wsplit: Optional[bool] = None, text_arith: str = "f16",
-                 overlap_frozen: bool = True):
-        self._init_host(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad, force_comm, overlap_frozen)
+                 overlap_frozen: bool = True, overlap_backward: bool = True):
+        self._init_host(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad, force_comm, overlap_frozen,
+                        overlap_backward)
         self._build(sd, tower, text, lens, gemm_cfg=gemm_cfg, frozen_res_dtype=frozen_res_dtype, train_res_dtype=train_res_dtype,
                     text_wsplit=text_wsplit, text_arith=text_arith, bn_training=bn_training, bn_sync=bn_sync, unlock_cls=unlock_cls)
         self.opt = AdamW(self.masters, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
@@ -737,14 +829,16 @@ class TriModalPCStep(_PerceiverLensStep):
         self.lens = LensEngine(sd, "visual.", tower, lens, device, gemm_cfg=gemm_cfg, res_dtype=train_res_dtype)
         self.tok = PointTokenizerTrainer(sd, "visual.visual_adapter.", lens, device, gemm_cfg=gemm_cfg, bn_training=bn_training,
                                          bn_sync=self.comm if bn_sync and self.dist else None, world_size=self.world)
+        self._one_stream_backward = bool(bn_sync and self.dist)       # SyncBatchNorm's backward talks to the communicator
         self._mk = lambda: PCLensTrainer(self.lens, self.tok, train_cls=unlock_cls)
         if unlock_cls:
             self.masters["visual.class_embedding"] = self.lens.vit.cls
         self.masters.update(self.tok.masters)
         self._collect_perceiver(sd)
 
-    def _bind_grads(self, t):
-        t.tower.grads = self.grads; t.perc.grads = self.grads; t.tok.grads = self.grads
+    def _bind_grads(self, t, grads=None):
+        g = self.grads if grads is None else grads
+        t.tower.grads = g; t.perc.grads = g; t.tok.grads = g
         self.tok.grads = self.grads
 
     def _refresh_operands(self):
@@ -783,8 +877,7 @@ class TriModalPCStep(_PerceiverLensStep):
         l1, _, dv1, ds1 = pair_loss_and_grads(self.comm, self.rank, self.world, fi, fv, ai, av, scale, **kw)
         l2, _, dv2, ds2 = pair_loss_and_grads(self.comm, self.rank, self.world, ft, fv, at, av, scale, **kw)
         dvraw = ops.l2_normalize_bwd(fv, dv1 + dv2, vnorm)
-        for i in range(nmb):
-            self._trainer(i).backward(dvraw[i * mb:(i + 1) * mb].contiguous())
+        self._backward_all(dvraw, nmb, mb)
         self.grads["logit_scale"] += ds1 + ds2
         return l1 + l2
 
