@@ -171,7 +171,7 @@ def test_c4_audio_step_vitl_vs_oracle_autograd():
     lc = E.LensCfg(modality="audio", perceiver_identity=False, depth=2, self_per_cross=3)
     st = ST.DualAudioStep(sd, E.TowerCfg(), E.TextCfg(), lc, "cuda", micro_batch=2)
     loss = st.forward_backward(aud.cuda(), txt.cuda())
-    st.grads.update(st.trainers[0].perc.reference_named_grads())
+    st.grads.update(st.reference_named_grads())          # (two micro-batches: the merged buffer, not one trainer's)
     _check(st, ref_loss, ref_grads, loss, names, tol=4e-2, cos_min=0.999, tag="c4")
 
 
@@ -198,7 +198,7 @@ def test_c5_pc_step_vitl_vs_oracle_autograd():
     lc = E.LensCfg(modality="pc", perceiver_identity=False, depth=4, self_per_cross=1, input_chan=384)
     st = ST.TriModalPCStep(sd, E.TowerCfg(), E.TextCfg(), lc, "cuda", micro_batch=2, bn_training=False)
     loss = st.forward_backward(img.cuda(), txt.cuda(), pts.cuda(), start.cuda())
-    st.grads.update(st.trainers[0].perc.reference_named_grads())
+    st.grads.update(st.reference_named_grads())
     _check(st, ref_loss, ref_grads, loss, names, tol=1.4e-1, cos_min=0.992, tag="c5")
 
 

@@ -745,7 +745,7 @@ def test_pc_tri_modal_step_vs_reference_grads(bn_train):
     loss = st.forward_backward(*args)
     assert abs(float(loss) - float(outs["step_loss"])) < 3e-2, (float(loss), float(outs["step_loss"]))
     got = dict(st.grads)
-    got.update(st.trainers[0].perc.reference_named_grads())
+    got.update(st.reference_named_grads())
     n = 0
     errs = {}
     for name, ref in grads.items():

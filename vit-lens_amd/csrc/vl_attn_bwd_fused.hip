@@ -164,6 +164,9 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_fused_kernel(const FusedBwdP 
 
   const int nthr = blockDim.x, nt = nthr >> 6;
   const int nitems = p0.B * p0.H;
+  // (Round 6: every workgroup's item takes the same time, so all 256 CUs stage at the same instant; starting every second
+  //  workgroup 8-32 k cycles late to spread that demand changed nothing - 0.439-0.447 ms with and without at L = 257,
+  //  profiles/r06_attn_bwd_stagger.log - and was removed.)
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
   if (item != (int)blockIdx.x) __syncthreads();      // the previous item's last LDS reads (lone-row finish) are done
   const FusedBwdP p = fb_reload_params();

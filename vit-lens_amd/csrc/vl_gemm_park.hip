@@ -251,8 +251,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   // is what we want to control here.  The only cross-wave LDS traffic is the DMA (vmcnt) and fragment READS (lgkmcnt).
   // vmcnt(0) also retires the previous tile's output stores (in-order counter): they have ~1.5 k-steps to drain before
   // they can delay a barrier.
+#ifdef PK_X_NOBAR      // timing-only ablation builds (tools/pk_ablation.py; results are garbage): no s_barrier / no DMA / no fragment reads
+#define PK_BAR ""
+#else
+#define PK_BAR "\n\ts_barrier"
+#endif
   auto dma_wait_and_barrier = [&]() {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" PK_BAR ::: "memory");
   };
   // The FIRST barrier of a tile behind an epilogue (round 4): the DMA it needs (k-step 1 of this tile) was issued in front of
   // the epilogue, i.e. it is OLDER than the epilogue's output stores in the in-order vmcnt queue - waiting for "at most
@@ -275,7 +280,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   static_assert(NCH == 4 * 4 && NST <= 63, "NST = stores per wave and tile; vmcnt is a 6-bit counter");
   static_assert(!(EPI == EPI_BF16 && (ACTB == 3 || ACTB == 4)) || ST_PER_CHUNK == 2, "two-output epilogues store twice per chunk");
   auto first_wait_and_barrier = [&]() {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NST) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" PK_BAR ::"n"(NST) : "memory");
   };
 
   zero_acc();
@@ -291,9 +296,18 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     constexpr bool last = decltype(LAST)::value;
     unsigned char* cur = smem + par * PK_STAGE;
     unsigned char* oth = smem + (par ^ 1) * PK_STAGE;
+#ifndef PK_X_NODMA
     if (grpB && pendB) { dma_step(oth); pendB = false; }
+#endif
     __builtin_amdgcn_sched_barrier(0);
     // four phases of 16 MFMAs: (k half 0, rows 0-63) (0, 64-127) (1, 0-63) (1, 64-127); W fragments of a half stay for both
+#ifdef PK_X_NOREAD
+    mma16(IC<0>{}, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma16(IC<1>{}, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma16(IC<0>{}, 0, 1);
+#else
     ldA16(cur, 0, 1, 1); ldW16(cur, 1, 1, IC<0>{}, IC<2>{});
     mma16(IC<0>{}, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -302,11 +316,16 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     __builtin_amdgcn_sched_barrier(0);
     ldA16(cur, 1, 1, 1);
     mma16(IC<0>{}, 0, 1);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     if (after_epi) { first_wait_and_barrier(); after_epi = false; } else dma_wait_and_barrier();
     // (at the last k-step of a tile BOTH wave groups issue at once: the batch must sit in front of the epilogue's stores)
+#ifndef PK_X_NODMA
     if (dti < my_tiles) { if (!grpB || last) dma_step(cur); else pendB = true; }
+#endif
+#ifndef PK_X_NOREAD
     if constexpr (!last) first_frags(oth);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     mma16(IC<1>{}, 1, 1);
     __builtin_amdgcn_sched_barrier(0);

@@ -654,6 +654,10 @@ class _PerceiverLensStep(_StepState):
         for t in self.trainers:
             self._bind_grads(t)
 
+    def reference_named_grads(self):
+        """The step's gradients (all micro-batches, after `forward_backward`) under the reference's parameter names / layouts."""
+        return self.trainers[0].perc.reference_named_grads(self.grads)
+
     def _backward_all(self, dvraw, nmb, mb):
         """Backward of every micro-batch (TriModalDepthStep._backward_all): the first half of the micro-batches accumulates into
         `flat_grad_b`, the second into `flat_grad`, one merge at the end; with `overlap_frozen` on a GPU the two halves run on

@@ -623,11 +623,12 @@ class PerceiverTrainer:
         ops.batch_rowsum(st["dx"], self.grad_buffer(P + "latents", (n, D)), B, n, D, n, 0)
         return st["ddata"]
 
-    def reference_named_grads(self) -> Dict[str, torch.Tensor]:
-        """Gradients under the reference's parameter names/layouts (de-interleaved GEGLU, split to_q/to_kv)."""
+    def reference_named_grads(self, grads: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """Gradients under the reference's parameter names/layouts (de-interleaved GEGLU, split to_q/to_kv); `grads`: another
+        dictionary in the kernels' layout (a fused step's merged buffer) instead of this trainer's own."""
         out = {}
         c = self.pe.cfg
-        for k, g in self.grads.items():
+        for k, g in (self.grads if grads is None else grads).items():
             if k.endswith("net.0.weight_il"):
                 out[k[:-3]] = deinterleave_geglu(g)
             elif k.endswith("net.0.bias_il"):
