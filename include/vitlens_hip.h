@@ -60,7 +60,7 @@ const char* vl_last_error(void);
  * VL_F16 tag and the fp16 / fp32 entries without bumping it; round 6 starts counting: 600 = round 6, first revision).
  * vl_version() returns the library's value; a client built against this header must find them equal before its first
  * call - the Python binding (vitlens_hip/_lib.py) and tests/native/abi_c_client.c both refuse to run otherwise. */
-#define VL_ABI_VERSION 600
+#define VL_ABI_VERSION 601
 int vl_version(void);
 
 /* C[M,N] = A[M,K] · W[N,K]^T with fused epilogue.  A, W bf16.  K % 64 == 0, N % 4 == 0.
@@ -394,6 +394,26 @@ int vl_scale_exp_f32(const float* x, float* out, long n, const float* log_scale,
 /* out[t,:] += sum_b x[b*batch_stride_rows + row_offset + t, :]   (positional-embedding gradients) */
 int vl_batch_rowsum(const float* x, float* out, int B, int T, int D, long batch_stride_rows, long row_offset,
                     hipStream_t stream);
+
+/* ---- the contrastive exchange over RCCL (csrc/vl_comm.cpp) ----
+ * One process per GPU, one communicator per process; RCCL (librccl.so.1) is resolved at run time.  These are the three
+ * collectives of a training step of the hot path, for a host that is not Python (the Python host makes the same calls
+ * through torch.distributed, or - vitlens_hip.step.AbiComm - through these entries):
+ *   vl_allgather_embed     the packed unit features of the step, [b, k*E] f32 per rank -> [W*b, k*E] in rank order
+ *                          (replaces gather_features' 2-4 dist.all_gather calls, open_clip/loss.py:20-78); count = floats per rank
+ *   vl_reducescatter_grad  backward of that gather under --gather-with-grad: full [W*b, E] f32 -> this rank's [b, E] slice of the
+ *                          sum over ranks (loss.py:55-61: torch.distributed.nn.all_gather's autograd)
+ *   vl_allreduce_grad      sum of a flat fp32 gradient bucket over the ranks, in place (DistributedDataParallel's all-reduce;
+ *                          the 1 / world of its mean is applied by the optimizer step, vl_adamw_step's grad_scale)
+ * vl_comm_unique_id fills 128 bytes on ONE rank; the host ships them to the others (its own channel: file, socket, MPI) and
+ * every rank calls vl_comm_create (collective).  All calls are asynchronous on `stream`. */
+typedef struct vl_comm* vl_comm_t;
+int vl_comm_unique_id(void* id128);
+int vl_comm_create(vl_comm_t* comm, const void* id128, int rank, int world);
+int vl_comm_destroy(vl_comm_t comm);
+int vl_allgather_embed(vl_comm_t comm, const float* local, float* gathered, long count, hipStream_t stream);
+int vl_reducescatter_grad(vl_comm_t comm, const float* full, float* mine, long count_per_rank, hipStream_t stream);
+int vl_allreduce_grad(vl_comm_t comm, float* buf, long count, hipStream_t stream);
 
 #ifdef __cplusplus
 }

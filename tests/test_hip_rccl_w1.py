@@ -51,3 +51,47 @@ def test_bench_force_dist_reports_the_collectives():
     coll = out["collective_ms_per_step"]
     assert "all_gather" in coll and ("all_reduce_wait" in coll or "all_reduce" in coll), coll
     assert out["value"] > 0
+
+
+def test_abi_collectives_on_a_one_rank_communicator():
+    """The C ABI's own exchange entries (include/vitlens_hip.h: vl_comm_create, vl_allgather_embed, vl_reducescatter_grad,
+    vl_allreduce_grad; csrc/vl_comm.cpp - RCCL resolved at run time) on ONE GPU through `vitlens_hip.step.AbiComm`: at world size
+    1 every collective is the identity; then the depth step with `force_comm=True` on that communicator - packed all-gather,
+    reduce-scatter under gather_with_grad, async per-block buckets on the communicator's stream, the flat remainder - must be
+    BIT-equal to the step without a communicator.  Own process: the RCCL communicator must not leak into the pytest session."""
+    code = r'''
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(sys.argv[1])))
+for p in (ROOT, os.path.join(ROOT, "vit-lens_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch
+from rccl_w1_worker import cfgs
+from vitlens_hip import step as ST
+comm = ST.AbiComm(0, 1)
+x = torch.randn(6, 5, device="cuda"); g = torch.empty(6, 5, device="cuda")
+comm.all_gather(g, x); torch.cuda.synchronize(); assert torch.equal(g, x)
+r = torch.empty(6, 5, device="cuda"); comm.reduce_scatter_sum(r, x); torch.cuda.synchronize(); assert torch.equal(r, x)
+y = x.clone(); comm.all_reduce_sum(y); torch.cuda.synchronize(); assert torch.equal(y, x)
+z = x.clone(); h = comm.all_reduce_sum_async(z); h.wait(); torch.cuda.synchronize(); assert torch.equal(z, x)
+sd, ins, tc, xc, lc = cfgs("tiny_depth.npz")
+args = (ins["image"].cuda(), ins["text"].cuda(), ins["visual_x"].cuda())
+res = {}
+for gwg in (False, True):
+    runs = []
+    for c in (None, comm):
+        st = ST.TriModalDepthStep(sd, tc, xc, "cuda", micro_batch=2, unlock_first_n=1, lr=1e-3, comm=c, force_comm=c is not None,
+                                  gather_with_grad=gwg)
+        losses = [float(st.step(*args)) for _ in range(3)]
+        torch.cuda.synchronize()
+        runs.append((losses, {k: v.clone() for k, v in st.masters.items()}))
+    same = runs[0][0] == runs[1][0] and all(torch.equal(runs[0][1][k], runs[1][1][k]) for k in runs[0][1])
+    res[str(gwg)] = same
+comm.close()
+print(json.dumps(res))
+'''
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", code, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-5000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out == {"False": True, "True": True}, out

@@ -17,7 +17,7 @@ def lib_path() -> str:
 P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
 
 # include/vitlens_hip.h: VL_ABI_VERSION (tests/test_abi.py compares the two)
-ABI_VERSION = 600
+ABI_VERSION = 601
 
 # name -> argtypes (all functions return int status unless listed in _RET)
 SIGNATURES = {
@@ -88,6 +88,13 @@ SIGNATURES = {
     "vl_axpy_f32": [P, P, F, L, P],
     "vl_scale_exp_f32": [P, P, L, P, F, P],
     "vl_batch_rowsum": [P, P, I, I, I, L, L, P],
+    # RCCL exchange (csrc/vl_comm.cpp): comm handles are opaque pointers
+    "vl_comm_unique_id": [P],
+    "vl_comm_create": [C.POINTER(P), P, I, I],
+    "vl_comm_destroy": [P],
+    "vl_allgather_embed": [P, P, P, L, P],
+    "vl_reducescatter_grad": [P, P, P, L, P],
+    "vl_allreduce_grad": [P, P, L, P],
 }
 
 

@@ -55,6 +55,93 @@ class TorchComm:
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
 
+class AbiComm:
+    """The same collectives through the library's OWN RCCL entry points (include/vitlens_hip.h: vl_comm_create,
+    vl_allgather_embed, vl_reducescatter_grad, vl_allreduce_grad; csrc/vl_comm.cpp) instead of torch.distributed - the calls a
+    non-Python host of the C ABI makes, driven from Python so that they are tested with the steps.  fp32 payloads (what the steps
+    exchange).  The 128-byte unique id is made on rank 0 and shipped by the caller: `AbiComm.over_torch_distributed()` uses an
+    initialised process group (any backend) for that one broadcast; a one-rank communicator needs no shipping."""
+
+    def __init__(self, rank: int = 0, world: int = 1, unique_id: Optional[bytes] = None, device=None):
+        import ctypes as C
+        from ._lib import check, load_library
+        self._lib, self._check, self._C = load_library(), check, C
+        self.rank, self.world = rank, world
+        if device is not None:
+            torch.cuda.set_device(device)
+        if unique_id is None:
+            if world != 1:
+                raise ValueError("AbiComm: ranks > 0 need the unique id rank 0 made (AbiComm.make_unique_id / over_torch_distributed)")
+            unique_id = self.make_unique_id()
+        if len(unique_id) != 128:
+            raise ValueError("AbiComm: the unique id is 128 bytes")
+        self._h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        check(self._lib.vl_comm_create(C.byref(self._h), buf, rank, world))
+        self._stream = None          # the bucket all-reduces run on their own stream, beside the backward
+
+    @staticmethod
+    def make_unique_id() -> bytes:
+        import ctypes as C
+        from ._lib import check, load_library
+        buf = C.create_string_buffer(128)
+        check(load_library().vl_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def over_torch_distributed(cls, device=None):
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [cls.make_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls(rank, world, box[0], device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.vl_comm_destroy(self._h)
+            self._h = self._C.c_void_p()
+
+    def _s(self):
+        return self._C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _f32(t, name):
+        if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError(f"AbiComm.{name}: contiguous fp32 GPU tensors only")
+        return t
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
+        self._f32(out, "all_gather"); inp = self._f32(inp.contiguous(), "all_gather")
+        self._check(self._lib.vl_allgather_embed(self._h, inp.data_ptr(), out.data_ptr(), inp.numel(), self._s()))
+
+    def all_reduce_sum(self, t: torch.Tensor):
+        self._f32(t, "all_reduce_sum")
+        self._check(self._lib.vl_allreduce_grad(self._h, t.data_ptr(), t.numel(), self._s()))
+
+    def reduce_scatter_sum(self, out: torch.Tensor, inp: torch.Tensor):
+        self._f32(out, "reduce_scatter_sum"); inp = self._f32(inp.contiguous(), "reduce_scatter_sum")
+        self._check(self._lib.vl_reducescatter_grad(self._h, inp.data_ptr(), out.data_ptr(), out.numel(), self._s()))
+
+    def all_reduce_sum_async(self, t: torch.Tensor):
+        """The bucket's all-reduce on the communicator's own stream behind what the launch stream has enqueued so far;
+        .wait() makes the launch stream wait for it."""
+        self._f32(t, "all_reduce_sum_async")
+        if self._stream is None:
+            self._stream = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        ready, done = torch.cuda.Event(), torch.cuda.Event()
+        ready.record(main)
+        self._stream.wait_event(ready)
+        with torch.cuda.stream(self._stream):
+            self.all_reduce_sum(t)
+            done.record(self._stream)
+
+        class _Handle:
+            def wait(self_h):
+                torch.cuda.current_stream().wait_event(done)
+        return _Handle()
+
+
 # ------------------------------------------------------------------------------------------------ checkpointing
 def _master_from_sd(name: str, sd, like: torch.Tensor) -> torch.Tensor:
     """Value of master `name` (kernel layout) from a reference-layout state_dict."""
