@@ -230,7 +230,7 @@ def hbm_traffic(dom):
     collected by tools/gpu_evidence_r03.sh with this very command and corrected per the MI355X guide by
     tools/traffic_summary.py).  PMC collection cannot run inside the timed process, so the number is read from
     profiles/; None when no summary for this kernel shape has been committed."""
-    for name in ("r05_hbm_traffic_c3.json", "r04b_hbm_traffic_c3.json", "r04_hbm_traffic_c3.json", "hbm_traffic.json"):        # newest summary first
+    for name in ("r06_hbm_traffic_c3.json", "r05_hbm_traffic_c3.json", "r04b_hbm_traffic_c3.json", "r04_hbm_traffic_c3.json", "hbm_traffic.json"):        # newest summary first
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
             for e in t.get("shapes", [t]):
@@ -258,8 +258,8 @@ def pmc_mfma_busy(dom):
     fold_act = {(3, 0): 20, (0, 1): 11, (0, 4): 14, (0, 0): 10}.get(base)
     cands = []
     if LN_FOLDED and fold_act is not None:
-        cands.append(("r05_gemm_pmc.json", f"gemm_nt_pk_kernel<{epi}, {fold_act}, false>"))
-    cands.append(("r05_gemm_pmc.json", f"gemm_nt_pk_kernel<{epi}, {act}, false>"))
+        cands += [(f, f"gemm_nt_pk_kernel<{epi}, {fold_act}, false>") for f in ("r06_gemm_pmc.json", "r05_gemm_pmc.json")]
+    cands += [(f, f"gemm_nt_pk_kernel<{epi}, {act}, false>") for f in ("r06_gemm_pmc.json", "r05_gemm_pmc.json")]
     for src in ("r04b_gemm_pmc.json", "r04_gemm_pmc.json", "r03d_gemm_pmc.json", "r03c_gemm_pmc.json"):   # r04: round-4 epilogue; r03d: 16x16x32 main loop
         cands.append((src, f"gemm_nt_pk_kernel<{epi}, {act}, true>"))
         cands.append((src, f"gemm_nt_pk_kernel<{epi}, {act}>"))

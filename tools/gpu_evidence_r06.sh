@@ -80,4 +80,10 @@ for WL in c2 c4 c5; do
   cut -c1-1200 gpurun_out/r06_bench_${WL}_train_step.json
 done
 fi
+stamp "micro-batch size on the two-stream schedule (128 / 512 against the default 256)"
+for MB in 128 512; do
+  timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --micro-batch $MB 2>&1 | tail -1 | python -c "
+import json,sys
+j=json.loads(sys.stdin.readline()); print('micro-batch $MB:', j['ms_per_step'], 'ms/step', j['value'], 'triplets/s')" | tee -a gpurun_out/r06_microbatch_sweep.log
+done
 stamp "done"
