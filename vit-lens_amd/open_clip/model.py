@@ -540,6 +540,36 @@ class _TowerFn(torch.autograd.Function):
         return (None, None, None, None, *outs)
 
 
+class _TextFn(torch.autograd.Function):
+    """The text tower as one autograd node (round 6): forward = the HIP forward with saved activations on bf16 operands,
+    backward = vitlens_hip.train.TextTowerTrainer; a gradient for every text parameter that requires grad.  Used only when
+    the text tower is NOT locked (`encode_text` under grad mode with trainable text parameters; training/train.py:212-235
+    trains whatever requires grad - every ViT-Lens recipe locks it and takes the frozen fp16 engine instead)."""
+
+    @staticmethod
+    def forward(ctx, model, text, names, *params):
+        tr = model._text_trainer()
+        model._text_gen += 1
+        ctx.model, ctx.names, ctx.gen = model, names, model._text_gen
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return tr.forward(text).clone()
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        m = ctx.model
+        if m._text_gen != ctx.gen:
+            raise RuntimeError("the text tower ran another forward before this backward: its saved activations were overwritten")
+        tr = m._text_trainer_obj
+        for g in tr.grads.values():
+            g.zero_()
+        tr.backward(dfeat.contiguous().float())
+        outs = []
+        for n, shp in zip(ctx.names, ctx.shapes):
+            g = tr.grads.get(n)
+            outs.append(None if g is None else g.reshape(shp).clone())
+        return (None, None, None, *outs)
+
+
 class _NormalizeFn(torch.autograd.Function):
     """F.normalize(dim=-1) (model.py:522-540) with its backward, both on the HIP kernels."""
 
@@ -707,32 +737,90 @@ class TriCLIP(nn.Module):
         features = self.visual(visual_x, **kwargs)
         return _normalize(features) if normalize else features
 
+    def _text_trainer(self):
+        """The trainable text tower (bf16 operands, saved activations), rebuilt when a text parameter changed."""
+        from vitlens_hip import engine as E, train as TR
+        dev = self.positional_embedding.device
+        if dev.type != "cuda":
+            raise RuntimeError("the ViT-Lens towers run on the MI355X kernels only: move the model to a GPU")
+        prm = dict(self.named_parameters())
+        names = [n for n in prm if not n.startswith(("image.", "visual.")) and n != "logit_scale"]
+        key = (str(dev), tuple(prm[n]._version for n in names))
+        if getattr(self, "_text_trainer_obj", None) is None or key != self._text_trainer_key:
+            sd = {k: v for k, v in self.state_dict().items() if not k.startswith(("image.", "visual."))}
+            t = self.text_cfg
+            cfg = E.TextCfg(context_length=t.context_length, vocab_size=t.vocab_size, width=t.width, heads=t.heads, layers=t.layers,
+                            embed_dim=self.text_projection.shape[1])
+            old = getattr(self, "_text_trainer_obj", None)
+            eng = E.TextEngine(sd, cfg, dev, res_dtype=torch.float32, arith="bf16")
+            tr = TR.TextTowerTrainer(eng)
+            if old is not None:
+                tr._saved = old._saved          # keep the activation buffers (only the operands changed)
+            self._text_trainer_obj, self._text_trainer_key = tr, key
+        return self._text_trainer_obj
+
+    _text_gen = 0
+
     def encode_text(self, text, normalize: bool = False):
-        if torch.is_grad_enabled() and not getattr(self, "_warned_text_frozen", False):
-            names = [n for n, p in self.named_parameters() if p.requires_grad and not n.startswith(("image.", "visual."))
-                     and n != "logit_scale"]
-            if names:
-                # every ViT-Lens recipe locks the text tower (TRAIN_INFERENCE.md); a model built without `--lock-text` still
-                # has requires_grad set on it.  The HIP text tower is inference-only: features come back detached, said once.
-                import warnings
-                warnings.warn("the HIP text tower is inference-only: text features carry no gradient although "
-                              f"{len(names)} text parameters have requires_grad=True ({names[0]}, ...); lock the text tower "
-                              "(lock_text_tower()) to silence this", stacklevel=2)
-                self._warned_text_frozen = True
+        if torch.is_grad_enabled():
+            trainable = [(n, p) for n, p in self.named_parameters() if p.requires_grad and not n.startswith(("image.", "visual."))
+                         and n != "logit_scale"]
+            if trainable:
+                # a text tower that is NOT locked trains (training/train.py:212-235); every ViT-Lens recipe locks it and runs the
+                # frozen fp16 engine below
+                features = _TextFn.apply(self, text.to(self.positional_embedding.device), tuple(n for n, _ in trainable),
+                                         *[p for _, p in trainable])
+                return _normalize(features) if normalize else features
         features = self._text().encode_text(text.to(self.positional_embedding.device))
         return _normalize(features) if normalize else features
 
+    # The frozen towers' forwards on a second HIP stream beside the trainable tower's (round 6; what the fused steps do by
+    # default, vitlens_hip/step.py `_frozen_beside`): on when a tower of this call carries a graph and the others do not.
+    overlap_frozen = True
+
+    def _frozen_side_stream(self, image, text, visual_x):
+        """-> the side stream when this call has independent frozen and trainable work on a GPU, else None."""
+        if not self.overlap_frozen or visual_x is None or (image is None and text is None) or not torch.is_grad_enabled():
+            return None
+        if not torch.is_tensor(visual_x) or self.positional_embedding.device.type != "cuda":
+            return None
+        if any(p.requires_grad for p in self.image.parameters()) or not any(p.requires_grad for p in self.visual.parameters()):
+            return None
+        if any(p.requires_grad for n, p in self.named_parameters() if not n.startswith(("image.", "visual.")) and n != "logit_scale"):
+            return None
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.positional_embedding.device)
+        return self._side
+
     def forward(self, image=None, text=None, visual_x=None):
-        image_features = None
-        if image is not None and image.ndim == 5:
-            # [b, t, c, h, w]: normalise every frame's feature, mean over frames, normalise again (model.py:588-600)
-            n_img = image.size(1)
-            f = self.encode_image(image.reshape(-1, *image.shape[2:]), normalize=True)
-            image_features = _normalize(f.reshape(-1, n_img, f.shape[-1]).mean(1).contiguous())
-        elif image is not None:
-            image_features = self.encode_image(image, normalize=True)
-        text_features = self.encode_text(text, normalize=True) if text is not None else None
-        visual_features = self.encode_visual(visual_x, normalize=True) if visual_x is not None else None
+        def frozen():
+            image_features = None
+            if image is not None and image.ndim == 5:
+                # [b, t, c, h, w]: normalise every frame's feature, mean over frames, normalise again (model.py:588-600)
+                n_img = image.size(1)
+                f = self.encode_image(image.reshape(-1, *image.shape[2:]), normalize=True)
+                image_features = _normalize(f.reshape(-1, n_img, f.shape[-1]).mean(1).contiguous())
+            elif image is not None:
+                image_features = self.encode_image(image, normalize=True)
+            text_features = self.encode_text(text, normalize=True) if text is not None else None
+            return image_features, text_features
+        side = self._frozen_side_stream(image, text, visual_x)
+        if side is None:
+            image_features, text_features = frozen()
+            visual_features = self.encode_visual(visual_x, normalize=True) if visual_x is not None else None
+        else:
+            main = torch.cuda.current_stream()
+            ready, done = torch.cuda.Event(), torch.cuda.Event()
+            ready.record(main)
+            side.wait_event(ready)                    # the inputs exist
+            with torch.cuda.stream(side), torch.no_grad():
+                image_features, text_features = frozen()
+                done.record(side)
+            visual_features = self.encode_visual(visual_x, normalize=True)
+            main.wait_event(done)
+            for t in (image_features, text_features):
+                if t is not None:
+                    t.record_stream(main)             # allocated on the side stream's pool, consumed by the loss on this one
         if self.output_dict:
             return {"image_features": image_features, "text_features": text_features,
                     "visual_features": visual_features, "logit_scale": self.logit_scale.exp()}

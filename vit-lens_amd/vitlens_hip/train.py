@@ -83,6 +83,7 @@ class TowerTrainer:
     def __init__(self, eng: VitEngine, train_blocks: Iterable[int] = (), train_cls=False, train_pos=False,
                  param_prefix: str = "visual.", train_ln_pre=False, train_ln_post=False, train_proj=False, checkpoint=False):
         self.eng, self.prefix = eng, param_prefix
+        self.causal = False                         # (TextTowerTrainer: the text transformer's additive causal mask, transformer.py:870-876)
         self.checkpoint = bool(checkpoint)          # activation recompute per block (Transformer.forward, transformer.py:366-368)
         self.train_blocks = sorted(set(train_blocks))
         self.train_cls, self.train_pos = train_cls, train_pos
@@ -177,7 +178,7 @@ class TowerTrainer:
             ops.ln_row_stats(S.part, x0, mm0, m1, r1, **k_in)
             ops.gemm_lnfold(x0, w["in_f"], m1, r1, S.qkv[l], w["in_w"], w["in_b"], w["ln1_w"], w["ln1_b"], S.h, cfg=cfg,
                             h_ready=bool(k_in))
-            ops.attn_fwd(S.q[l], S.k[l], S.v[l], S.a[l], lse=S.lse[l], qscale=dh ** -0.5 * ops.LOG2E)
+            ops.attn_fwd(S.q[l], S.k[l], S.v[l], S.a[l], lse=S.lse[l], causal=self.causal, qscale=dh ** -0.5 * ops.LOG2E)
             mm = ops.gemm_res_rowstats(S.a[l], w["out_w"], w["out_b"], x1, x0, S.part, cfg=cfg)
             k_fc = dict(ln_w=w["ln2_w"], ln_b=w["ln2_b"], h_left=S.h, h_row0=r_fc) if mm <= r_fc else {}
             ops.ln_row_stats(S.part, x1, mm, m2, r2, **k_fc)
@@ -186,7 +187,7 @@ class TowerTrainer:
         else:
             ops.layernorm(S.X[2 * l], w["ln1_w"], w["ln1_b"], h1, B * L, D, mean=m1, rstd=r1)
             ops.gemm(h1, w["in_w"], w["in_b"], out=S.qkv[l], epi=ops.EPI_BF16, cfg=cfg)
-            ops.attn_fwd(S.q[l], S.k[l], S.v[l], S.a[l], lse=S.lse[l], qscale=dh ** -0.5 * ops.LOG2E)
+            ops.attn_fwd(S.q[l], S.k[l], S.v[l], S.a[l], lse=S.lse[l], causal=self.causal, qscale=dh ** -0.5 * ops.LOG2E)
             ops.gemm(S.a[l], w["out_w"], w["out_b"], out=S.X[2 * l + 1], res=S.X[2 * l], epi=res_epi, cfg=cfg)
             ops.layernorm(S.X[2 * l + 1], w["ln2_w"], w["ln2_b"], h2, B * L, D, mean=m2, rstd=r2)
             # S.u[l] = gelu'(fc output): all the backward needs of the pre-activation, evaluated next to gelu() from the same
@@ -242,6 +243,27 @@ class TowerTrainer:
         # only the cls rows (row b*L) of the final residual receive gradient: write them in place
         ops.layernorm_bwd(dpooled, S.X[2 * self.layers], S.post_stats[0], S.post_stats[1], e.ln_post[0], B, D,
                           dx=S.dx, x_row_stride=L * D, dx_row_stride=L * D)
+        self._blocks_backward(S, B, L, on_block_done)
+        # ---- ln_pre and the [cls; tokens] + pos assembly ----
+        dxpre = torch.empty(S.dx.shape, device=S.dx.device, dtype=torch.float32)
+        if self.train_ln_pre:
+            ops.layernorm_bwd_params(S.dx, S.xpre, S.pre_stats[0], S.pre_stats[1], self.grad_buffer(P + "ln_pre.weight", e.ln_pre[0]),
+                                     self.grad_buffer(P + "ln_pre.bias", e.ln_pre[1]), rows, D)
+        ops.layernorm_bwd(S.dx, S.xpre, S.pre_stats[0], S.pre_stats[1], e.ln_pre[0], rows, D, dx=dxpre)
+        if self.train_cls:
+            ops.batch_rowsum(dxpre, self.grad_buffer(P + "class_embedding", e.cls).view(1, D), B, 1, D, L, 0)
+        if self.train_pos:
+            ops.batch_rowsum(dxpre, self.grad_buffer(P + "positional_embedding", e.pos), B, L, D, L, 0)
+        self.dxpre = dxpre
+        return dxpre.view(B, L, D)[:, 1:, :].reshape(B * T, D)
+
+    def _blocks_backward(self, S, B, L, on_block_done=None):
+        """S.dx (the gradient of the last block's output, residual-stream dtype) -> S.dx = the gradient of the first block's
+        input, through every ResidualAttentionBlock in reverse; parameter gradients of the trainable blocks into self.grads."""
+        e, D, H = self.eng, self.D, self.H
+        rows = B * L
+        cfg = e.gemm_cfg
+        P = self.prefix
         f32_stream = S.dx.dtype == torch.float32
         dxb_out = S.dxb if f32_stream else None
         if f32_stream:
@@ -268,7 +290,7 @@ class TowerTrainer:
                 self._dw(bp + "attn.out_proj.weight", S.dx, S.a[l], rows, bp + "attn.out_proj.bias")
             ops.gemm(S.dxb, wT["out_w"], None, out=S.dOm, epi=ops.EPI_BF16, cfg=cfg)                        # dO
             ops.attn_bwd(S.q[l], S.k[l], S.v[l], S.dO, S.av[l], S.lse[l], S.delta,
-                         S.dqkv, S.dqkv[:, D:], S.dqkv[:, 2 * D:], 3 * D, 3 * D)
+                         S.dqkv, S.dqkv[:, D:], S.dqkv[:, 2 * D:], 3 * D, 3 * D, causal=self.causal)
             if trainable:
                 self._dw(bp + "attn.in_proj_weight", S.dqkv, S.h1[l], rows, bp + "attn.in_proj_bias")
             ops.gemm(S.dqkv, wT["in_w"], None, out=S.dh, epi=ops.EPI_BF16, cfg=cfg)                         # dh1
@@ -278,18 +300,6 @@ class TowerTrainer:
             ops.layernorm_bwd(S.dh, S.X[2 * l], m1, r1, w["ln1_w"], rows, D, dres=S.dx, dx=S.dx, dx_bf16=dxb_out)
             if trainable and on_block_done is not None:
                 on_block_done(l)
-        # ---- ln_pre and the [cls; tokens] + pos assembly ----
-        dxpre = torch.empty(S.dx.shape, device=S.dx.device, dtype=torch.float32)
-        if self.train_ln_pre:
-            ops.layernorm_bwd_params(S.dx, S.xpre, S.pre_stats[0], S.pre_stats[1], self.grad_buffer(P + "ln_pre.weight", e.ln_pre[0]),
-                                     self.grad_buffer(P + "ln_pre.bias", e.ln_pre[1]), rows, D)
-        ops.layernorm_bwd(S.dx, S.xpre, S.pre_stats[0], S.pre_stats[1], e.ln_pre[0], rows, D, dx=dxpre)
-        if self.train_cls:
-            ops.batch_rowsum(dxpre, self.grad_buffer(P + "class_embedding", e.cls).view(1, D), B, 1, D, L, 0)
-        if self.train_pos:
-            ops.batch_rowsum(dxpre, self.grad_buffer(P + "positional_embedding", e.pos), B, L, D, L, 0)
-        self.dxpre = dxpre
-        return dxpre.view(B, L, D)[:, 1:, :].reshape(B * T, D)
 
 
 class DepthLensTrainer:
@@ -353,6 +363,74 @@ class ImageTowerTrainer:
             g = self.tower.grad_buffer("visual.conv1.weight_gemm", torch.empty(dtok.shape[1], cols.shape[1]))
             rp = (dtok.shape[0] + 63) // 64 * 64
             ops.gemm_dw(ops.transpose_to_bf16(dtok, ldo=rp), ops.transpose_to_bf16(cols, ldo=rp), g, cfg=self.eng.gemm_cfg)
+
+
+class _TextAsTower:
+    """What TowerTrainer reads of an engine, for the text tower (a `TextEngine(arith="bf16")`: bf16 operands, fp32 residual stream)."""
+
+    def __init__(self, te):
+        from types import SimpleNamespace
+        c = te.cfg
+        self.cfg = SimpleNamespace(width=c.width, heads=c.heads, mlp_ratio=4.0, layers=c.layers)
+        self.device, self.res_dtype, self.gemm_cfg = te.device, torch.float32, te.gemm_cfg
+        self.blocks, self.projT, self.ln_post = te.blocks, te.projT, te.ln_final
+        self.tok, self.pos = te.tok, te.pos
+
+
+class TextTowerTrainer(TowerTrainer):
+    """Forward with saved activations and backward of the TEXT tower (TriCLIP.encode_text, open_clip/model.py:528-540: token
+    embedding + positional embedding -> 12 causal ResidualAttentionBlocks -> ln_final -> the EOT token's row @ text_projection)
+    for runs that do NOT lock it (every ViT-Lens recipe does; `training/train.py:212-235` trains whatever requires grad).  The
+    blocks are TowerTrainer's, with the additive causal mask (transformer.py:870-876) in the attention kernels; gradients come
+    out under the reference's parameter names: token_embedding.weight, positional_embedding, transformer.resblocks.*, ln_final.*,
+    text_projection.  bf16 operands on an fp32 residual stream (the frozen tower's fp16 operands are an inference choice)."""
+
+    def __init__(self, text_engine):
+        if getattr(text_engine, "arith", "bf16") != "bf16":
+            raise ValueError("TextTowerTrainer needs a TextEngine(arith='bf16')")
+        eng = _TextAsTower(text_engine)
+        super().__init__(eng, train_blocks=range(eng.cfg.layers), param_prefix="", train_ln_post=True, train_proj=True)
+        self.causal = True
+
+    def forward(self, text: torch.Tensor) -> torch.Tensor:
+        e, D = self.eng, self.D
+        B, L = text.shape
+        S = self.saved(B, L)
+        text = text.to(e.device).contiguous()
+        ops.text_embed(text, e.tok, e.pos, S.X[0])
+        for l in range(self.layers):
+            self._block_forward(S, l, B, L)
+        eot = text.argmax(dim=-1).contiguous()            # index-exact EOT position (model.py:539)
+        ops.layernorm(S.X[2 * self.layers], e.ln_post[0], e.ln_post[1], S.pooled, B, D, x_row_stride=D, row_index=eot, row_mul=L,
+                      mean=S.post_stats[0], rstd=S.post_stats[1])
+        feat = ops.gemm(S.pooled, e.projT, None, epi=ops.EPI_F32, cfg=e.gemm_cfg)
+        self.ctx = (B, L, text, eot)
+        return feat
+
+    def backward(self, dfeat: torch.Tensor):
+        """dfeat f32 [B, E]; fills self.grads (every text parameter)."""
+        e, D = self.eng, self.D
+        B, L, text, eot = self.ctx
+        S = self.saved(B, L)
+        cfg = e.gemm_cfg
+        dfb = ops.cast_bf16(dfeat.contiguous())
+        dpooled = ops.gemm(dfb, self.proj, None, epi=ops.EPI_BF16, cfg=cfg)                                  # [B, D]
+        bp = (B + 63) // 64 * 64
+        ops.gemm_dw(ops.transpose_to_bf16(S.pooled, ldo=bp), ops.transpose_to_bf16(dfb, ldo=bp),
+                    self.grad_buffer("text_projection", torch.empty(D, dfeat.shape[1])), cfg=cfg)
+        # ln_final acts on ONE row per caption, the EOT token's (an arbitrary position: gathered / scattered by index)
+        rows = torch.arange(B, device=e.device) * L + eot
+        x_eot = S.X[2 * self.layers].index_select(0, rows).contiguous()
+        ops.layernorm_bwd_params(dpooled, x_eot, S.post_stats[0], S.post_stats[1], self.grad_buffer("ln_final.weight", e.ln_post[0]),
+                                 self.grad_buffer("ln_final.bias", e.ln_post[1]), B, D)
+        dx_eot = torch.empty(B, D, device=e.device, dtype=torch.float32)
+        ops.layernorm_bwd(dpooled, x_eot, S.post_stats[0], S.post_stats[1], e.ln_post[0], B, D, dx=dx_eot)
+        S.dx.zero_()
+        S.dx.index_copy_(0, rows, dx_eot)
+        self._blocks_backward(S, B, L)
+        # x0 = token_embedding[text] + positional_embedding
+        ops.batch_rowsum(S.dx, self.grad_buffer("positional_embedding", e.pos), B, L, D, L, 0)
+        self.grad_buffer("token_embedding.weight", e.tok).index_add_(0, text.reshape(-1), S.dx)
 
 
 class AdamW:
