@@ -302,6 +302,17 @@ class TowerTrainer:
                 on_block_done(l)
 
 
+def conv_weight_grad(dtok: torch.Tensor, cols: torch.Tensor, g: torch.Tensor, gemm_cfg: int = -1):
+    """g[D, Kp] += dtok^T cols: the weight gradient of a stride-patch convolution run as im2col + GEMM (dtok f32 [R, D] = the
+    gradient of its output tokens, cols bf16 [R, Kp] = the im2col rows the forward kept).  Token-major operands for the dW
+    kernel (the fp32 gradient cast to bf16 - the values a transposed copy would hold too); the transposing NT path where the
+    shape does not fit."""
+    if ops.gemm_dw_tn_any(ops.cast_bf16(dtok.contiguous()), cols, g):
+        return
+    rp = (dtok.shape[0] + 63) // 64 * 64
+    ops.gemm_dw(ops.transpose_to_bf16(dtok, ldo=rp), ops.transpose_to_bf16(cols, ldo=rp), g, cfg=gemm_cfg)
+
+
 class DepthLensTrainer:
     """`visual.` tower of the depth recipe: DepthTokenizer conv1 + pos_emb -> ViT trunk (Perceiver = Identity)."""
 
@@ -329,8 +340,7 @@ class DepthLensTrainer:
         T, D = dtok.shape[0] // B, dtok.shape[1]
         t = self.tower
         g = t.grad_buffer("visual.visual_adapter.conv1.weight_gemm", torch.empty(D, cols.shape[1]))
-        rp = (dtok.shape[0] + 63) // 64 * 64
-        ops.gemm_dw(ops.transpose_to_bf16(dtok, ldo=rp), ops.transpose_to_bf16(cols, ldo=rp), g, cfg=self.le.gemm_cfg)
+        conv_weight_grad(dtok, cols, g, self.le.gemm_cfg)
         ops.batch_rowsum(t.dxpre, t.grad_buffer("visual.visual_adapter.pos_emb", self.le.adapter_pos), B, T, D, T + 1, 1)
 
 
@@ -361,8 +371,7 @@ class ImageTowerTrainer:
         if self.train_conv:
             cols = self.ctx
             g = self.tower.grad_buffer("visual.conv1.weight_gemm", torch.empty(dtok.shape[1], cols.shape[1]))
-            rp = (dtok.shape[0] + 63) // 64 * 64
-            ops.gemm_dw(ops.transpose_to_bf16(dtok, ldo=rp), ops.transpose_to_bf16(cols, ldo=rp), g, cfg=self.eng.gemm_cfg)
+            conv_weight_grad(dtok, cols, g, self.eng.gemm_cfg)
 
 
 class _TextAsTower:
@@ -626,7 +635,9 @@ class PerceiverTrainer:
         """x_{xi+1} = x_xi + W2 geglu(W0 LN(x_xi) + b0) + b2 ; st['dx'] holds dL/dx_{xi+1} on entry, dL/dx_xi on exit."""
         X, cfg = st["X"], self.pe.gemm_cfg
         ops.geglu_bf16(hsave, st["hid"])
-        self._dw(pname + "1.fn.net.2.weight", st["dx"], st["hid"], rows)
+        # (dy = the bf16 copy of the residual gradient the dX GEMMs read: token-major operands for the dW kernel - the fp32
+        #  stream would be rounded to the same bf16 values on its way through a transposed copy)
+        self._dw(pname + "1.fn.net.2.weight", st["dxb"], st["hid"], rows)
         ops.colsum(st["dx"], self.grad_buffer(pname + "1.fn.net.2.bias", (D,)))
         ops.gemm(st["dxb"], wT["w2"], None, out=st["dh8"], res=hsave, epi=ops.EPI_DGEGLU, cfg=cfg)     # d(pre-activation), interleaved
         ops.layernorm(X[xi], norm[0], norm[1], st["h"], rows, D)
@@ -659,7 +670,7 @@ class PerceiverTrainer:
                 a, A = sl["attn"], T["attn"]
                 H, dh = c.latent_heads, c.latent_dim_head
                 inner = H * dh
-                self._dw(pn + "0.fn.to_out.weight", st["dx"], A.a, rows)
+                self._dw(pn + "0.fn.to_out.weight", st["dxb"], A.a, rows)
                 ops.colsum(st["dx"], self.grad_buffer(pn + "0.fn.to_out.bias", (D,)))
                 ops.gemm(st["dxb"], w["out"], None, out=A.dOm, epi=ops.EPI_BF16, cfg=cfg)
                 dqkv = st["dqkv"]
@@ -678,7 +689,7 @@ class PerceiverTrainer:
             a, A, w = lay["x_attn"], S["x_attn"], wT["x"]
             H, dh = c.cross_heads, c.cross_dim_head
             inner = H * dh
-            self._dw(pn + "0.fn.to_out.weight", st["dx"], A.a, rows)
+            self._dw(pn + "0.fn.to_out.weight", st["dxb"], A.a, rows)
             ops.colsum(st["dx"], self.grad_buffer(pn + "0.fn.to_out.bias", (D,)))
             ops.gemm(st["dxb"], w["out"], None, out=A.dOm, epi=ops.EPI_BF16, cfg=cfg)
             dkv = st["dkv"]
@@ -755,8 +766,7 @@ class AudioLensTrainer:
         ddata = self.perc.backward(dlat)                          # f32 [B*T, D]
         D = ddata.shape[1]
         g = self.tower.grad_buffer("visual.visual_adapter.conv1.weight_gemm", torch.empty(D, cols.shape[1]))
-        rp = (ddata.shape[0] + 63) // 64 * 64
-        ops.gemm_dw(ops.transpose_to_bf16(ddata, ldo=rp), ops.transpose_to_bf16(cols, ldo=rp), g, cfg=self.le.gemm_cfg)
+        conv_weight_grad(ddata, cols, g, self.le.gemm_cfg)
         ops.batch_rowsum(ddata, self.tower.grad_buffer("visual.visual_adapter.pos_emb", self.le.adapter_pos), B, T, D, T, 0)
 
 
@@ -782,8 +792,7 @@ class EEGLensTrainer(AudioLensTrainer):
         ddata = self.perc.backward(dlat)                          # f32 [B*T, D]: gradient of tokens + pos
         D = ddata.shape[1]
         g = self.tower.grad_buffer("visual.visual_adapter.proj.weight_gemm", torch.empty(D, cols.shape[1]))
-        rp = (ddata.shape[0] + 63) // 64 * 64
-        ops.gemm_dw(ops.transpose_to_bf16(ddata, ldo=rp), ops.transpose_to_bf16(cols, ldo=rp), g, cfg=self.le.gemm_cfg)
+        conv_weight_grad(ddata, cols, g, self.le.gemm_cfg)
         ops.colsum(ddata, self.tower.grad_buffer("visual.visual_adapter.proj.bias", self.le.conv_b))
         ops.batch_rowsum(ddata, self.tower.grad_buffer("visual.visual_adapter.pos_emb", self.le.adapter_pos), B, T, D, T, 0)
 
