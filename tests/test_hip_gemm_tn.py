@@ -83,3 +83,26 @@ def test_bias_gradient_column_sum(R, C, stride):
     ops.colsum(a, out, 0.25)
     ref = 3.0 + 0.25 * a.double().sum(0)
     assert relerr(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("R,M,N", [(256 * 64, 64, 1024),      # Perceiver to_q / to_k gradient: 64 output columns
+                                   (512 * 64, 1024, 128),     # to_out: a 128-column operand on the x side
+                                   (196 * 64, 1024, 384),     # a 384-wide context (1.5 tiles)
+                                   (64 * 64, 768, 608)])      # patch-convolution columns: 588 = 3 * 14 * 14 padded to 608 by im2col
+def test_narrow_operands_through_the_padded_path(R, M, N):
+    """`gemm_dw_tn_any`: operands whose column counts are not whole 256-column tiles go through a zero-padded copy of the
+    narrow one; the result accumulates into `g` with `alpha` exactly like the whole-tile path.  Small integers: bit-exact."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(R + M + N)
+    dy = torch.randint(-2, 3, (R, M), generator=g).float().bfloat16().cuda()
+    x = torch.randint(-2, 3, (R, N), generator=g).float().bfloat16().cuda()
+    out = torch.full((M, N), 3.0, device="cuda")
+    assert ops.gemm_dw_tn_any(dy, x, out, alpha=0.5)
+    ref = 3.0 + 0.5 * (dy.float().t() @ x.float())
+    assert torch.equal(out, ref)
+    # random data, a second call on the same shapes (the padded staging buffers are reused: stale pad columns would show)
+    dy2 = torch.randn(R, M, generator=g).bfloat16().cuda(); x2 = torch.randn(R, N, generator=g).bfloat16().cuda()
+    out2 = torch.zeros(M, N, device="cuda")
+    assert ops.gemm_dw_tn_any(dy2, x2, out2)
+    assert relerr(out2, dy2.double().t() @ x2.double()) < 2e-6
+    assert not ops.gemm_dw_tn_any(dy2[:100], x2[:100], out2)               # rows not a multiple of 64: refused, no launch

@@ -775,7 +775,7 @@ class TriCLIP(nn.Module):
         return _normalize(features) if normalize else features
 
     # The frozen towers' forwards on a second HIP stream beside the trainable tower's (round 6; what the fused steps do by
-    # default, vitlens_hip/step.py `_frozen_beside`): on when a tower of this call carries a graph and the others do not.
+    # default, vitlens_hip/step.py `_side_by_side`): on when a tower of this call carries a graph and the others do not.
     overlap_frozen = True
 
     def _frozen_side_stream(self, image, text, visual_x):

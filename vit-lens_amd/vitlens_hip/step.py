@@ -101,6 +101,12 @@ class AbiComm:
             self._lib.vl_comm_destroy(self._h)
             self._h = self._C.c_void_p()
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:          # interpreter shutdown: the library or ctypes may already be gone
+            pass
+
     def _s(self):
         return self._C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -217,12 +223,15 @@ class _StepState:
     def _overlap_active(self) -> bool:
         return self.overlap_frozen and self.dev.type == "cuda"
 
-    def _frozen_beside(self, frozen, trainable):
-        """Run the two closures of a step's forward: `frozen()` (the locked towers: forward only, results into buffers the
-        caller allocated) and `trainable()` (the Lens tower with saved activations).  Independent work.  With
-        `overlap_frozen` on a GPU the frozen towers go to a second HIP stream: one tower's low-power phases (attention,
-        LayerNorm, leftover rows) sit beside the other's GEMMs on a board that is power-limited in its GEMM phases
-        (-1.35 % per C3 step, bit-equal results: tests/test_hip_train.py).  Otherwise: one after the other."""
+    def _side_by_side(self, beside, here):
+        """Run two closures of independent work: `beside()` on the step's second HIP stream, `here()` on the launch stream,
+        joined by events on both ends (one after the other on a CPU device or with `overlap_frozen` off).  Two callers: the
+        forward (`beside` = the locked towers, forward only, results into buffers the caller allocated; `here` = the Lens
+        tower with saved activations) and the backward (`_backward_all`: the two halves of the micro-batches, each into its
+        own gradient buffer).  One closure's low-power phases (attention, LayerNorm, leftover rows) sit beside the other's
+        GEMMs on a board that is power-limited in its GEMM phases (-1.35 % per C3 step for the forward, -3.2 % with the
+        backward; bit-equal results: tests/test_hip_train.py)."""
+        frozen, trainable = beside, here
         if not self._overlap_active:
             frozen(); trainable()
             return
@@ -429,7 +438,7 @@ class TriModalDepthStep(_StepState):
                  grad_checkpointing: bool = False, force_comm: bool = False, text_wsplit: Optional[bool] = None, text_arith: str = "f16",
                  overlap_frozen: bool = True, overlap_backward: bool = True):
         """overlap_frozen (default ON since round 6): the image / text towers' forwards run on a second HIP stream beside
-        the trainable tower's forward (`_frozen_beside`); results are bit-identical to the serial order."""
+        the trainable tower's forward (`_side_by_side`); results are bit-identical to the serial order."""
         self._init_host(sd, device, micro_batch, rank, world_size, comm, local_loss, gather_with_grad, force_comm, overlap_frozen,
                         overlap_backward)
         self.grad_checkpointing = bool(grad_checkpointing)      # block recompute in the trainable tower (transformer.py:366-368)
@@ -600,7 +609,7 @@ class TriModalDepthStep(_StepState):
             for i in range(nmb):
                 s = slice(i * mb, (i + 1) * mb)
                 vraw[s] = self._trainer(i).forward(depths[s])
-        self._frozen_beside(frozen, trainable)
+        self._side_by_side(frozen, trainable)
         ops.l2_normalize(vraw, out=fv, norms=vnorm)
         scale = self.logit_scale          # the log-temperature, on the device: exp() is applied inside the loss section
         if self.dist:
@@ -665,7 +674,7 @@ class TriModalDepthStep(_StepState):
             for i in range(half, nmb):
                 self._trainer(i).backward(dv(i), second_done if i == nmb - 1 else None)
         if two_streams:
-            self._frozen_beside(first_half, second_half)      # (first closure on the second stream, joined at the end)
+            self._side_by_side(first_half, second_half)      # (first closure on the second stream, joined at the end)
         else:
             first_half(); second_half()
         n = self.flat_grad.numel()
@@ -769,7 +778,7 @@ class _PerceiverLensStep(_StepState):
         if getattr(self, "_one_stream_backward", False) or not self.overlap_backward:
             first_half(); second_half()
         else:
-            self._frozen_beside(first_half, second_half)
+            self._side_by_side(first_half, second_half)
         ops.axpy(self.flat_grad, self.flat_grad_b)
 
     def _prepare(self, B):
@@ -867,7 +876,7 @@ class DualAudioStep(_PerceiverLensStep):
             for i in range(nmb):
                 s = slice(i * mb, (i + 1) * mb)
                 vraw[s] = self._trainer(i).forward(audio[s])
-        self._frozen_beside(frozen, trainable)
+        self._side_by_side(frozen, trainable)
         ops.l2_normalize(vraw, out=fv, norms=vnorm)
         scale = self.logit_scale          # device-side log-temperature (see TriModalDepthStep)
         if self.dist:
@@ -955,7 +964,7 @@ class TriModalPCStep(_PerceiverLensStep):
             for i in range(nmb):
                 s = slice(i * mb, (i + 1) * mb)
                 vraw[s] = self._trainer(i).forward(points[s], None if fps_start is None else fps_start[s])
-        self._frozen_beside(frozen, trainable)
+        self._side_by_side(frozen, trainable)
         ops.l2_normalize(vraw, out=fv, norms=vnorm)
         scale = self.logit_scale          # device-side log-temperature (see TriModalDepthStep)
         if self.dist:
