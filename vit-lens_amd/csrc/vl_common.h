@@ -81,13 +81,48 @@ __device__ __forceinline__ float gelu_grad_from_parts(float x, const GeluParts g
 }
 __device__ __forceinline__ float gelu_erf(float x) { return gelu_from_parts(x, gelu_parts(x)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) { return gelu_grad_from_parts(x, gelu_parts(x)); }
+// The same arithmetic on PAIRS of values in packed-fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32: two IEEE operations per
+// lane per issue, the same roundings as the scalar forms above - results are bit-identical, tests/test_hip_gemm_park.py): the
+// epilogues that evaluate GELU on whole tiles spend 20-35 % of a launch in this arithmetic with the matrix pipes idle.
+struct GeluParts2 { vl_f32x2 q, e; };
+__device__ __forceinline__ GeluParts2 gelu_parts2(vl_f32x2 x) {
+  const vl_f32x2 ax = __builtin_elementwise_abs(x);
+  const vl_f32x2 d = __builtin_elementwise_fma((vl_f32x2)(0.23164190f), ax, (vl_f32x2)(1.0f));
+  const vl_f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  vl_f32x2 p = __builtin_elementwise_fma((vl_f32x2)(0.5307027145f), t, (vl_f32x2)(-0.7265760135f));
+  p = __builtin_elementwise_fma(p, t, (vl_f32x2)(0.7107068705f));
+  p = __builtin_elementwise_fma(p, t, (vl_f32x2)(-0.142248368f));
+  p = __builtin_elementwise_fma(p, t, (vl_f32x2)(0.127414796f));
+  const vl_f32x2 zs = x * 0.84932180f;
+  const vl_f32x2 z2 = zs * zs;
+  GeluParts2 r;
+  r.q = p * t;
+  r.e = vl_f32x2{__builtin_amdgcn_exp2f(-z2[0]), __builtin_amdgcn_exp2f(-z2[1])};
+  return r;
+}
+__device__ __forceinline__ vl_f32x2 gelu_from_parts2(vl_f32x2 x, const GeluParts2 g) {
+  const vl_f32x2 m = {fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
+  return __builtin_elementwise_fma(-(__builtin_elementwise_abs(x) * g.q), g.e, m);
+}
+__device__ __forceinline__ vl_f32x2 gelu_grad_from_parts2(vl_f32x2 x, const GeluParts2 g) {
+  const float x0 = x[0], x1 = x[1];      // (scalars first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 both times)
+  const vl_f32x2 step = {(__builtin_bit_cast(int, x0) >= 0) ? 1.0f : 0.0f, (__builtin_bit_cast(int, x1) >= 0) ? 1.0f : 0.0f};
+  const vl_f32x2 sq = {copysignf(g.q[0], x0), copysignf(g.q[1], x1)};
+  return __builtin_elementwise_fma(g.e, __builtin_elementwise_fma((vl_f32x2)(0.3989422804014327f), x, -sq), step);
+}
+__device__ __forceinline__ vl_f32x2 gelu_erf2(vl_f32x2 x) { return gelu_from_parts2(x, gelu_parts2(x)); }
+__device__ __forceinline__ vl_f32x2 gelu_erf_grad2(vl_f32x2 x) { return gelu_grad_from_parts2(x, gelu_parts2(x)); }
+__device__ __forceinline__ vl_f32x2 unpack2bf(unsigned int w) { return vl_f32x2{bf2f((bf16_t)(w & 0xffff)), bf2f((bf16_t)(w >> 16))}; }
+__device__ __forceinline__ unsigned int pack2bf(vl_f32x2 v) {
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, vl_bf16x2));
+}
 // One packed pair of bf16 pre-activations -> packed bf16 (gelu, gelu'): the pair the forward of a TRAINED MLP leaves behind
 // (VL_ACT_GELU_DSAVE), so that the dX GEMM's epilogue is a multiplication instead of a second erf evaluation.
 __device__ __forceinline__ void gelu_and_grad_pk(unsigned int w, unsigned int& y, unsigned int& d) {
-  const float lo = bf2f((bf16_t)(w & 0xffff)), hi = bf2f((bf16_t)(w >> 16));
-  const GeluParts a = gelu_parts(lo), b = gelu_parts(hi);
-  y = pack2bf(gelu_from_parts(lo, a), gelu_from_parts(hi, b));
-  d = pack2bf(gelu_grad_from_parts(lo, a), gelu_grad_from_parts(hi, b));
+  const vl_f32x2 x = unpack2bf(w);
+  const GeluParts2 g = gelu_parts2(x);
+  y = pack2bf(gelu_from_parts2(x, g));
+  d = pack2bf(gelu_grad_from_parts2(x, g));
 }
 __device__ __forceinline__ unsigned int mul_pk_bf16(unsigned int a, unsigned int b) {
   return pack2bf(bf2f((bf16_t)(a & 0xffff)) * bf2f((bf16_t)(b & 0xffff)), bf2f((bf16_t)(a >> 16)) * bf2f((bf16_t)(b >> 16)));

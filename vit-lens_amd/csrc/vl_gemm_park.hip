@@ -467,7 +467,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
             if constexpr (EPI == EPI_BF16 && ACTB == 1) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+              for (int e = 0; e < 4; e += 2) {
+                const vl_f32x2 y = gelu_erf2(vl_f32x2{v[e], v[e + 1]});
+                v[e] = y[0]; v[e + 1] = y[1];
+              }
             } else if constexpr (EPI == EPI_BF16 && ACTB == 2) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -494,24 +497,26 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
               __builtin_nontemporal_store(w, (u32x4*)((unsigned char*)pe.out2 + (rowoff * 2 * pe.ldo + ncol0) * 2 + lo_pre));
             u32x2 o;
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
-              o[e] = pack2bf(bf2f((bf16_t)(w[2 * e] & 0xffff)) * gelu_erf(bf2f((bf16_t)(w[2 * e] >> 16))),
-                             bf2f((bf16_t)(w[2 * e + 1] & 0xffff)) * gelu_erf(bf2f((bf16_t)(w[2 * e + 1] >> 16))));
+            for (int e = 0; e < 2; ++e) {       // (a, gate) of two neighbouring hidden columns: the two gates as one packed pair
+              const vl_f32x2 a = {bf2f((bf16_t)(w[2 * e] & 0xffff)), bf2f((bf16_t)(w[2 * e + 1] & 0xffff))};
+              const vl_f32x2 gt = {bf2f((bf16_t)(w[2 * e] >> 16)), bf2f((bf16_t)(w[2 * e + 1] >> 16))};
+              o[e] = pack2bf(a * gelu_erf2(gt));
+            }
             __builtin_nontemporal_store(o, (u32x2*)((unsigned char*)pe.out + (rowoff * pe.ldo + (ncol0 >> 1)) * 2 + lo_half));
             continue;
           } else if constexpr (IS_DGEGLU) {
             // w = dy of 8 hidden columns (bf16); hx = their 8 (a, gate) pairs -> 8 (d a, d gate) pairs
             u32x4 o2[2];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-              const unsigned hv = hx[i & 1][pass * 2 + (c >> 2)][c & 3];
-              const float dy = bf2f((bf16_t)((c & 1) ? (w[c >> 1] >> 16) : (w[c >> 1] & 0xffff)));
-              const float a = bf2f((bf16_t)(hv & 0xffff)), g = bf2f((bf16_t)(hv >> 16));
-              const GeluParts gp = gelu_parts(g);
-              const float ge = fmaf(-(fabsf(g) * gp.q), gp.e, fmaxf(g, 0.0f));
-              const float step = (__builtin_bit_cast(int, g) >= 0) ? 1.0f : 0.0f;
-              const float gd = fmaf(gp.e, fmaf(0.3989422804014327f, g, -copysignf(gp.q, g)), step);
-              o2[c >> 2][c & 3] = pack2bf(dy * ge, dy * a * gd);
+            for (int c = 0; c < 8; c += 2) {      // two hidden columns per iteration: the arithmetic in packed-fp32 pairs
+              const unsigned hv0 = hx[i & 1][pass * 2 + (c >> 2)][c & 3], hv1 = hx[i & 1][pass * 2 + (c >> 2)][(c + 1) & 3];
+              const vl_f32x2 dy = unpack2bf(w[c >> 1]);
+              const vl_f32x2 a = {bf2f((bf16_t)(hv0 & 0xffff)), bf2f((bf16_t)(hv1 & 0xffff))};
+              const vl_f32x2 g = {bf2f((bf16_t)(hv0 >> 16)), bf2f((bf16_t)(hv1 >> 16))};
+              const GeluParts2 gp = gelu_parts2(g);
+              const vl_f32x2 da = dy * gelu_from_parts2(g, gp), dg = dy * a * gelu_grad_from_parts2(g, gp);
+              o2[c >> 2][c & 3] = pack2bf(da[0], dg[0]);
+              o2[c >> 2][(c + 1) & 3] = pack2bf(da[1], dg[1]);
             }
             unsigned char* dst = (unsigned char*)pe.out + ((size_t)(mrow0 + i * 32 + pass * 8) * pe.ldo + 2 * ncol0) * 2 + lo_h;
             __builtin_nontemporal_store(o2[0], (u32x4*)dst);
@@ -520,8 +525,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
           } else if constexpr (EPI == EPI_BF16 && ACTB == 3) {
             __builtin_nontemporal_store(w, (u32x4*)((unsigned char*)pe.out2 + ((size_t)(mrow0 + i * 32 + pass * 8) * pe.ldo + ncol0) * 2 + lo_out));
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              w[e] = pack2bf(gelu_erf(bf2f((bf16_t)(w[e] & 0xffff))), gelu_erf(bf2f((bf16_t)(w[e] >> 16))));
+            for (int e = 0; e < 4; ++e) w[e] = pack2bf(gelu_erf2(unpack2bf(w[e])));
           } else if constexpr (EPI == EPI_BF16 && ACTB == 4) {
             u32x4 d;                                              // out2 = gelu'(pre) for the dX GEMM of the backward
 #pragma unroll
@@ -555,8 +559,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
           } else if constexpr (EPI == EPI_DGELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              w[e] = pack2bf(bf2f((bf16_t)(w[e] & 0xffff)) * gelu_erf_grad(bf2f((bf16_t)(rr[e] & 0xffff))),
-                             bf2f((bf16_t)(w[e] >> 16)) * gelu_erf_grad(bf2f((bf16_t)(rr[e] >> 16))));
+              w[e] = pack2bf(unpack2bf(w[e]) * gelu_erf_grad2(unpack2bf(rr[e])));
           }
           __builtin_nontemporal_store(w, (u32x4*)(out_base + (size_t)((i * 32 + pass * 8) * ldo2)));
         }

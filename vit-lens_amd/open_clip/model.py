@@ -671,7 +671,8 @@ class TriCLIP(nn.Module):
                           "the MI355X path has no fp32 backward.  See model.precision_effective.", UserWarning, stacklevel=3)
         elif precision == "amp":
             warnings.warn("precision='amp' (fp16 autocast in the reference) runs as amp_bf16 on the MI355X path: bf16 operands, "
-                          "fp32 accumulation, no loss scaling.", UserWarning, stacklevel=3)
+                          "fp32 accumulation.  bf16 has fp32's range, so no loss scaling is needed; a GradScaler around the loop "
+                          "body works as in the reference (scale / unscale_ / skipped step on overflow).", UserWarning, stacklevel=3)
         return self
 
     # ---- lock recipes (model.py:448-502) -------------------------------------------------------
