@@ -189,16 +189,23 @@ class PointTokenizerTrainer:
         self.ctx = (patches, z1, s1[0], s1[1], h1, f, g, z3, s3[0], s3[1], h2, f2, g2, c3, u, p1, s1[2], s3[2])
         return out
 
+    def _dw_into(self, dy, x, g):
+        """g += dy^T x (bf16 [rows, *] operands): token-major operands for the dW kernel (narrow channel counts zero-padded to
+        whole tiles, ops.gemm_dw_tn_any) - the rows are B * groups * points, two transposed copies of them per weight were
+        3 % of the C5 step; the transposing NT path where the row count is not a multiple of 64."""
+        if ops.gemm_dw_tn_any(dy, x, g):
+            return
+        rp = (dy.shape[0] + 63) // 64 * 64
+        ops.gemm_dw(ops.transpose_to_bf16(dy, ldo=rp), ops.transpose_to_bf16(x, ldo=rp), g, cfg=self.cfg)
+
     def _dw(self, name, dy, x, cols=None):
         """grads[name] += dy^T x (both bf16 [rows, *])."""
-        rows = dy.shape[0]
-        rp = (rows + 63) // 64 * 64
         g = self.grad_buffer(name)
         if cols is None:
-            ops.gemm_dw(ops.transpose_to_bf16(dy, ldo=rp), ops.transpose_to_bf16(x, ldo=rp), g, cfg=self.cfg)
+            self._dw_into(dy, x, g)
         else:       # zero-padded input channels: compute the padded product, accumulate the real columns
             full = torch.zeros(dy.shape[1], x.shape[1], device=self.device, dtype=torch.float32)
-            ops.gemm_dw(ops.transpose_to_bf16(dy, ldo=rp), ops.transpose_to_bf16(x, ldo=rp), full, cfg=self.cfg)
+            self._dw_into(dy, x, full)
             ops.axpy(g, full[:, :cols].contiguous(), 1.0)
 
     def _db(self, name, dy):
@@ -225,10 +232,8 @@ class PointTokenizerTrainer:
         dt = ops.group_sum(dz3, M)
         gw = self.grad_buffer(a + "encoder.second_conv.0.weight")
         half = gw.shape[1] // 2
-        rp = (dz3.shape[0] + 63) // 64 * 64
-        ops.gemm_dw(ops.transpose_to_bf16(dz3, ldo=rp), ops.transpose_to_bf16(f, ldo=rp), gw[:, half:], cfg=c)
-        rg = (dt.shape[0] + 63) // 64 * 64
-        ops.gemm_dw(ops.transpose_to_bf16(dt, ldo=rg), ops.transpose_to_bf16(g, ldo=rg), gw[:, :half], cfg=c)
+        self._dw_into(dz3, f, gw[:, half:])
+        self._dw_into(dt, g, gw[:, :half])
         self._db(a + "encoder.second_conv.0.bias", dt)
         dg = ops.gemm(dt, o["w3gT"], None, cfg=c)
         dfl = ops.gemm(dz3, o["w3lT"], None, cfg=c)
