@@ -1,6 +1,7 @@
 """Tensor-level wrappers over the C ABI.  Every function enqueues HIP kernels on the current
 torch stream and returns immediately.  Inputs must live on a GPU: there is no CPU fallback."""
 import ctypes as C
+import threading
 
 import torch
 
@@ -320,8 +321,9 @@ _pad_cache = {}
 
 def _zero_padded(t, cols, tag):
     """t [R, c] bf16 -> a [R, cols] bf16 buffer (cached per shape and role) whose first c columns are t and the rest zero."""
-    # (the source width is part of the key: the pad columns must stay zero; the stream too: two backwards run side by side)
-    key = (tag, t.device, torch.cuda.current_stream(t.device).cuda_stream, t.shape[0], t.shape[1], cols)
+    # (the source width is part of the key: the pad columns must stay zero; the stream too: two backwards run side by side;
+    #  the host thread too: a buffer is filled and consumed by two separate enqueues)
+    key = (tag, t.device, torch.cuda.current_stream(t.device).cuda_stream, threading.get_ident(), t.shape[0], t.shape[1], cols)
     buf = _pad_cache.get(key)
     if buf is None:
         buf = torch.zeros(t.shape[0], cols, device=t.device, dtype=torch.bfloat16)      # the pad columns are written once: zeros
@@ -559,7 +561,8 @@ def _ws_for(device, rows, cols, planes):
     """Workspace of the deterministic two-stage column reductions (cached per device, grown on demand)."""
     need = int(_lib.vl_colreduce_ws_floats(rows, cols, planes))             # the kernels' own slab geometry, not a copy of it
     # one workspace per device AND stream: two micro-batches' backwards run on two HIP streams (step.py, round 6)
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    # (and per host thread: threads that enqueue on one stream interleave their launches - tests emulate ranks that way)
+    key = (device, torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
     t = _colreduce_ws.get(key)
     if t is None or t.numel() < need:
         t = torch.empty(need, device=device, dtype=torch.float32)

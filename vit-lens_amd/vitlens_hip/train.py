@@ -563,27 +563,30 @@ class PerceiverTrainer:
         f32 = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         bf = lambda *s: torch.empty(*s, device=dev, dtype=BF)
         nres = c.depth * (2 + 2 * c.self_per_cross) + 1
-        st = {"X": [f32(R, D) for _ in range(nres)], "h": bf(R, D), "ctx": bf(B * Tc, c.input_chan), "hid": bf(R, 4 * D),
+        st = {"X": [f32(R, D) for _ in range(nres)],
               "dx": f32(R, D), "dxb": bf(R, D), "dh8": bf(R, 8 * D), "dhn": bf(R, D), "dqkv": bf(R, 3 * c.latent_heads * c.latent_dim_head),
               "dq": bf(R, c.cross_heads * c.cross_dim_head), "dkv": bf(B * Tc, 2 * c.cross_heads * c.cross_dim_head),
               "dctx": bf(B * Tc, c.input_chan), "ddata": f32(B * Tc, c.input_chan), "layers": []}
         for _ in range(c.depth):
-            lay = {"x_stats": [f32(R), f32(R)], "c_stats": [f32(B * Tc), f32(B * Tc)],
+            # (kept per sub-layer for the backward's weight gradients: every LayerNorm output `*_hn` / `c_n` and every GEGLU
+            #  output `*_hid` - recomputing them was 2 % of the C4 step's kernel time for 2-7 GB of a 288 GB card)
+            lay = {"x_stats": [f32(R), f32(R)], "c_stats": [f32(B * Tc), f32(B * Tc)], "x_hn": bf(R, D), "c_n": bf(B * Tc, c.input_chan),
                    "x_attn": _AttnSaved(B, c.cross_heads, n, Tc, c.cross_dim_head, dev, packed=False),
-                   "xff_stats": [f32(R), f32(R)], "xff_h": bf(R, 8 * D), "selfs": []}
+                   "xff_stats": [f32(R), f32(R)], "xff_h": bf(R, 8 * D), "xff_hn": bf(R, D), "xff_hid": bf(R, 4 * D), "selfs": []}
             for _ in range(c.self_per_cross):
                 lay["selfs"].append({"stats": [f32(R), f32(R)], "attn": _AttnSaved(B, c.latent_heads, n, n, c.latent_dim_head, dev, packed=True),
-                                     "ff_stats": [f32(R), f32(R)], "ff_h": bf(R, 8 * D)})
+                                     "hn": bf(R, D), "ff_stats": [f32(R), f32(R)], "ff_h": bf(R, 8 * D), "ff_hn": bf(R, D),
+                                     "ff_hid": bf(R, 4 * D)})
             st["layers"].append(lay)
         self._st[key] = st
         return st
 
     # ---- forward ----------------------------------------------------------------------------------
-    def _ff_fwd(self, st, xi, norm, ff, stats, hsave, rows, D):
+    def _ff_fwd(self, st, xi, norm, ff, stats, hsave, hn, hid, rows, D):
         X, cfg = st["X"], self.pe.gemm_cfg
-        ops.layernorm(X[xi], norm[0], norm[1], st["h"], rows, D, mean=stats[0], rstd=stats[1])
-        ops.gemm(st["h"], ff["w0"], ff["b0"], out=st["hid"], epi=ops.EPI_GEGLU, cfg=cfg, out2=hsave)
-        ops.gemm(st["hid"], ff["w2"], ff["b2"], out=X[xi + 1], res=X[xi], epi=ops.EPI_RES_F32, cfg=cfg)
+        ops.layernorm(X[xi], norm[0], norm[1], hn, rows, D, mean=stats[0], rstd=stats[1])
+        ops.gemm(hn, ff["w0"], ff["b0"], out=hid, epi=ops.EPI_GEGLU, cfg=cfg, out2=hsave)
+        ops.gemm(hid, ff["w2"], ff["b2"], out=X[xi + 1], res=X[xi], epi=ops.EPI_RES_F32, cfg=cfg)
 
     def forward(self, data: torch.Tensor, B: int) -> torch.Tensor:
         pe, c = self.pe, self.pe.cfg
@@ -595,25 +598,25 @@ class PerceiverTrainer:
         for li, lay in enumerate(pe.layers):
             S = st["layers"][li]
             a, A = lay["x_attn"], S["x_attn"]
-            ops.layernorm(X[xi], lay["x_norm"][0], lay["x_norm"][1], st["h"], rows, D, mean=S["x_stats"][0], rstd=S["x_stats"][1])
-            ops.layernorm(data, lay["x_norm_ctx"][0], lay["x_norm_ctx"][1], st["ctx"], B * Tc, c.input_chan,
+            ops.layernorm(X[xi], lay["x_norm"][0], lay["x_norm"][1], S["x_hn"], rows, D, mean=S["x_stats"][0], rstd=S["x_stats"][1])
+            ops.layernorm(data, lay["x_norm_ctx"][0], lay["x_norm_ctx"][1], S["c_n"], B * Tc, c.input_chan,
                           mean=S["c_stats"][0], rstd=S["c_stats"][1])
-            ops.gemm(st["h"], a["q_w"], None, out=A.q2, epi=ops.EPI_BF16, cfg=cfg)
-            ops.gemm(st["ctx"], a["kv_w"], None, out=A.kv2, epi=ops.EPI_BF16, cfg=cfg)
+            ops.gemm(S["x_hn"], a["q_w"], None, out=A.q2, epi=ops.EPI_BF16, cfg=cfg)
+            ops.gemm(S["c_n"], a["kv_w"], None, out=A.kv2, epi=ops.EPI_BF16, cfg=cfg)
             ops.attn_fwd(A.q, A.k, A.v, A.a, lse=A.lse, qscale=c.cross_dim_head ** -0.5 * ops.LOG2E)
             ops.gemm(A.a, a["to_out_w"], a["to_out_b"], out=X[xi + 1], res=X[xi], epi=ops.EPI_RES_F32, cfg=cfg)
             xi += 1
-            self._ff_fwd(st, xi, lay["x_ff_norm"], lay["x_ff"], S["xff_stats"], S["xff_h"], rows, D)
+            self._ff_fwd(st, xi, lay["x_ff_norm"], lay["x_ff"], S["xff_stats"], S["xff_h"], S["xff_hn"], S["xff_hid"], rows, D)
             xi += 1
             for sj, sl in enumerate(lay["selfs"]):
                 T = S["selfs"][sj]
                 a, A = sl["attn"], T["attn"]
-                ops.layernorm(X[xi], sl["norm"][0], sl["norm"][1], st["h"], rows, D, mean=T["stats"][0], rstd=T["stats"][1])
-                ops.gemm(st["h"], a["qkv_w"], None, out=A.qkv2, epi=ops.EPI_BF16, cfg=cfg)
+                ops.layernorm(X[xi], sl["norm"][0], sl["norm"][1], T["hn"], rows, D, mean=T["stats"][0], rstd=T["stats"][1])
+                ops.gemm(T["hn"], a["qkv_w"], None, out=A.qkv2, epi=ops.EPI_BF16, cfg=cfg)
                 ops.attn_fwd(A.q, A.k, A.v, A.a, lse=A.lse, qscale=c.latent_dim_head ** -0.5 * ops.LOG2E)
                 ops.gemm(A.a, a["to_out_w"], a["to_out_b"], out=X[xi + 1], res=X[xi], epi=ops.EPI_RES_F32, cfg=cfg)
                 xi += 1
-                self._ff_fwd(st, xi, sl["ff_norm"], sl["ff"], T["ff_stats"], T["ff_h"], rows, D)
+                self._ff_fwd(st, xi, sl["ff_norm"], sl["ff"], T["ff_stats"], T["ff_h"], T["ff_hn"], T["ff_hid"], rows, D)
                 xi += 1
         self.ctx = (B, Tc, data)
         return X[xi]
@@ -631,17 +634,16 @@ class PerceiverTrainer:
         ops.layernorm_bwd_params(dy, x, stats[0], stats[1], self.grad_buffer(name + ".weight", (D,)),
                                  self.grad_buffer(name + ".bias", (D,)), rows, D)
 
-    def _ff_bwd(self, st, xi, norm, ff, wT, stats, hsave, rows, D, pname):
-        """x_{xi+1} = x_xi + W2 geglu(W0 LN(x_xi) + b0) + b2 ; st['dx'] holds dL/dx_{xi+1} on entry, dL/dx_xi on exit."""
+    def _ff_bwd(self, st, xi, norm, ff, wT, stats, hsave, hn, hid, rows, D, pname):
+        """x_{xi+1} = x_xi + W2 geglu(W0 LN(x_xi) + b0) + b2 ; st['dx'] holds dL/dx_{xi+1} on entry, dL/dx_xi on exit.
+        hn = LN(x_xi), hid = geglu(...) as the forward left them."""
         X, cfg = st["X"], self.pe.gemm_cfg
-        ops.geglu_bf16(hsave, st["hid"])
         # (dy = the bf16 copy of the residual gradient the dX GEMMs read: token-major operands for the dW kernel - the fp32
         #  stream would be rounded to the same bf16 values on its way through a transposed copy)
-        self._dw(pname + "1.fn.net.2.weight", st["dxb"], st["hid"], rows)
+        self._dw(pname + "1.fn.net.2.weight", st["dxb"], hid, rows)
         ops.colsum(st["dx"], self.grad_buffer(pname + "1.fn.net.2.bias", (D,)))
         ops.gemm(st["dxb"], wT["w2"], None, out=st["dh8"], res=hsave, epi=ops.EPI_DGEGLU, cfg=cfg)     # d(pre-activation), interleaved
-        ops.layernorm(X[xi], norm[0], norm[1], st["h"], rows, D)
-        self._dw(pname + "1.fn.net.0.weight_il", st["dh8"], st["h"], rows)
+        self._dw(pname + "1.fn.net.0.weight_il", st["dh8"], hn, rows)
         ops.colsum(st["dh8"], self.grad_buffer(pname + "1.fn.net.0.bias_il", (8 * D,)))
         ops.gemm(st["dh8"], wT["w0"], None, out=st["dhn"], epi=ops.EPI_BF16, cfg=cfg)
         self._ln_params(pname + "1.norm", st["dhn"], X[xi], stats, rows, D)
@@ -665,7 +667,7 @@ class PerceiverTrainer:
                 sl, T, w = lay["selfs"][sj], S["selfs"][sj], wT["selfs"][sj]
                 pn = f"{P}layers.{self.layer_name(li)}.2.{sj}."
                 xi -= 1
-                self._ff_bwd(st, xi, sl["ff_norm"], sl["ff"], w, T["ff_stats"], T["ff_h"], rows, D, pn)
+                self._ff_bwd(st, xi, sl["ff_norm"], sl["ff"], w, T["ff_stats"], T["ff_h"], T["ff_hn"], T["ff_hid"], rows, D, pn)
                 xi -= 1
                 a, A = sl["attn"], T["attn"]
                 H, dh = c.latent_heads, c.latent_dim_head
@@ -676,15 +678,14 @@ class PerceiverTrainer:
                 dqkv = st["dqkv"]
                 ops.attn_bwd(A.q, A.k, A.v, A.dO, A.av, A.lse, A.delta, dqkv, dqkv[:, inner:], dqkv[:, 2 * inner:],
                              3 * inner, 3 * inner)
-                ops.layernorm(X[xi], sl["norm"][0], sl["norm"][1], st["h"], rows, D)
-                self._dw(pn + "0.fn.to_qkv.weight", dqkv, st["h"], rows)            # rows [to_q ; to_kv]
+                self._dw(pn + "0.fn.to_qkv.weight", dqkv, T["hn"], rows)            # rows [to_q ; to_kv]
                 ops.gemm(dqkv, w["qkv"], None, out=st["dhn"], epi=ops.EPI_BF16, cfg=cfg)
                 self._ln_params(pn + "0.norm", st["dhn"], X[xi], T["stats"], rows, D)
                 ops.layernorm_bwd(st["dhn"], X[xi], T["stats"][0], T["stats"][1], sl["norm"][0], rows, D, dres=st["dx"],
                                   dx=st["dx"], dx_bf16=st["dxb"])
             pn = f"{P}layers.{self.layer_name(li)}."
             xi -= 1
-            self._ff_bwd(st, xi, lay["x_ff_norm"], lay["x_ff"], wT["xff"], S["xff_stats"], S["xff_h"], rows, D, pn)
+            self._ff_bwd(st, xi, lay["x_ff_norm"], lay["x_ff"], wT["xff"], S["xff_stats"], S["xff_h"], S["xff_hn"], S["xff_hid"], rows, D, pn)
             xi -= 1
             a, A, w = lay["x_attn"], S["x_attn"], wT["x"]
             H, dh = c.cross_heads, c.cross_dim_head
@@ -695,16 +696,14 @@ class PerceiverTrainer:
             dkv = st["dkv"]
             ops.attn_bwd(A.q, A.k, A.v, A.dO, A.av, A.lse, A.delta, st["dq"], dkv, dkv[:, inner:], inner, 2 * inner)
             # query side: LN(x) -> to_q
-            ops.layernorm(X[xi], lay["x_norm"][0], lay["x_norm"][1], st["h"], rows, D)
-            self._dw(pn + "0.fn.to_q.weight", st["dq"], st["h"], rows)
+            self._dw(pn + "0.fn.to_q.weight", st["dq"], S["x_hn"], rows)
             ops.gemm(st["dq"], w["q"], None, out=st["dhn"], epi=ops.EPI_BF16, cfg=cfg)
             self._ln_params(pn + "0.norm", st["dhn"], X[xi], S["x_stats"], rows, D)
             ops.layernorm_bwd(st["dhn"], X[xi], S["x_stats"][0], S["x_stats"][1], lay["x_norm"][0], rows, D, dres=st["dx"],
                               dx=st["dx"], dx_bf16=st["dxb"])
             # context side: LN_ctx(data) -> to_kv ; every cross layer reads the same data -> accumulate
             C = c.input_chan
-            ops.layernorm(data, lay["x_norm_ctx"][0], lay["x_norm_ctx"][1], st["ctx"], B * Tc, C)
-            self._dw(pn + "0.fn.to_kv.weight", dkv, st["ctx"], B * Tc)
+            self._dw(pn + "0.fn.to_kv.weight", dkv, S["c_n"], B * Tc)
             ops.gemm(dkv, w["kv"], None, out=st["dctx"], epi=ops.EPI_BF16, cfg=cfg)
             self._ln_params(pn + "0.norm_context", st["dctx"], data, S["c_stats"], B * Tc, C)
             ops.layernorm_bwd(st["dctx"], data, S["c_stats"][0], S["c_stats"][1], lay["x_norm_ctx"][0], B * Tc, C,
