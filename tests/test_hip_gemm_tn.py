@@ -83,6 +83,16 @@ def test_bias_gradient_column_sum(R, C, stride):
     ops.colsum(a, out, 0.25)
     ref = 3.0 + 0.25 * a.double().sum(0)
     assert relerr(out, ref) < 1e-5
+    # the same columns as fp32 (the Perceiver's residual-gradient stream): the 16-byte kernel for C % 4 == 0 on aligned rows,
+    # the one-column-per-thread kernel for the view shifted by one column
+    af = torch.randn(R, stride + 4, generator=g).cuda()
+    for view in (af[:, :C], af[:, 1:1 + C]):
+        outf = torch.full((C,), -2.0, device="cuda")
+        ops.colsum(view, outf, 0.5)
+        assert relerr(outf, -2.0 + 0.5 * view.double().sum(0)) < 1e-5
+        again = torch.full((C,), -2.0, device="cuda")
+        ops.colsum(view, again, 0.5)
+        assert torch.equal(outf, again)                       # deterministic two-stage reduction
 
 
 @pytest.mark.parametrize("R,M,N", [(256 * 64, 64, 1024),      # Perceiver to_q / to_k gradient: 64 output columns

@@ -251,6 +251,28 @@ def test_layernorm_param_gradients_bf16_streams(rows, D):
     assert relerr(db, -1.0 + dy.double().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("rows,D", [(50, 1024), (777, 1024), (1030, 768), (263, 72), (41, 102)])
+def test_layernorm_param_gradients_bf16_dy_fp32_x(rows, D):
+    """dgamma / dbeta from a bf16 dy and an fp32 x (the Perceiver's LayerNorms on its fp32 residual stream): the 4-column kernel
+    (D % 4 == 0) and the per-column one (D = 102), row counts that are no multiple of the row lanes or of the 256-row slabs,
+    a strided x (a column window of a wider tensor), accumulation into existing values, deterministic."""
+    from vitlens_hip import ops
+    g = torch.Generator().manual_seed(rows * 3 + D)
+    wide = (torch.randn(rows, D + 8, generator=g) * 2 + 0.5).cuda()
+    x = wide[:, 4:4 + D] if D % 4 == 0 else wide[:, :D].contiguous()
+    dy = torch.randn(rows, D, generator=g).bfloat16().cuda()
+    xd = x.double()
+    mean = xd.mean(1); rstd = (xd.var(1, unbiased=False) + 1e-5).rsqrt()
+    dw = torch.full((D,), 2.0, device="cuda"); db = torch.full((D,), -1.0, device="cuda")
+    ops.layernorm_bwd_params(dy, x, mean.float(), rstd.float(), dw, db, rows, D, x_row_stride=x.stride(0))
+    xh = (xd - mean.float().double()[:, None]) * rstd.float().double()[:, None]
+    assert relerr(dw, 2.0 + (dy.double() * xh).sum(0)) < 1e-5
+    assert relerr(db, -1.0 + dy.double().sum(0)) < 1e-5
+    dw2 = torch.full((D,), 2.0, device="cuda"); db2 = torch.full((D,), -1.0, device="cuda")
+    ops.layernorm_bwd_params(dy, x, mean.float(), rstd.float(), dw2, db2, rows, D, x_row_stride=x.stride(0))
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
 def test_adamw_matches_torch():
     from vitlens_hip import train as TR
     g = torch.Generator().manual_seed(7)
