@@ -109,7 +109,11 @@ __global__ void __launch_bounds__(NWMAX * 64, DH == 128 ? 2 : 4) attn_fwd_kernel
   }
   [[maybe_unused]] u32x4 tailraw = {0u, 0u, 0u, 0u};
   if constexpr (TAILQ) {
-    if (tid < nch) tailraw = *(const u32x4*)(Qb + (long)(p.Lq - 1) * p.q.sr + tid * 8);
+    // (!PAD: EVERY thread loads one of the row's CH chunks and stores it below - duplicates write identical bytes.  A load under
+    //  a lane condition makes hipcc close the block with s_waitcnt vmcnt(0): a memory round trip of its own in front of the
+    //  K / V requests.)
+    if constexpr (!PAD) tailraw = *(const u32x4*)(Qb + (long)(p.Lq - 1) * p.q.sr + (tid & (CH - 1)) * 8);
+    else if (tid < nch) tailraw = *(const u32x4*)(Qb + (long)(p.Lq - 1) * p.q.sr + tid * 8);
   }
   unsigned char* const sVr = (unsigned char*)sV;       // DMA: V as a row image [KC][128 B], chunks swizzled by vswz(row)
   auto vswz = [](int row) { const int x = (row >> 1) & 7; return ((x & 1) << 2) | (x >> 1); };      // (= the fused backward's fb_swz)
@@ -140,7 +144,8 @@ __global__ void __launch_bounds__(NWMAX * 64, DH == 128 ? 2 : 4) attn_fwd_kernel
                                            0, p.Lk, tid, nthr);
   }
   if constexpr (TAILQ) {
-    if (tid < CH) *(u32x4*)(sTailQ + tid * 8) = tailraw;
+    if constexpr (!PAD) *(u32x4*)(sTailQ + (tid & (CH - 1)) * 8) = tailraw;
+    else if (tid < CH) *(u32x4*)(sTailQ + tid * 8) = tailraw;
   }
   VL_PROF_STAMP(p, 1);
   // V^T fragment in accumulator order out of the row image (DMA): this lane's column d = t*32 + (lane & 31), the 8 keys

@@ -144,7 +144,9 @@ __device__ __forceinline__ FusedBwdP fb_reload_params() {
 #if defined(__HIP_DEVICE_COMPILE__)
   FbKernargP kp = (FbKernargP)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(kp));
-  __builtin_memcpy(&r, (const void*)kp, sizeof(FusedBwdP));
+  // (copied THROUGH the constant address space: cast to a generic pointer the copy became 14 vector loads whose
+  //  s_waitcnt vmcnt(0) drained the previous item's stores - and the q / k prefetch - at the top of every item)
+  __builtin_memcpy(&r, kp, sizeof(FusedBwdP));
 #endif
   return r;
 }
@@ -167,6 +169,11 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_fused_kernel(const FusedBwdP 
   // (Round 6: every workgroup's item takes the same time, so all 256 CUs stage at the same instant; starting every second
   //  workgroup 8-32 k cycles late to spread that demand changed nothing - 0.439-0.447 ms with and without at L = 257,
   //  profiles/r06_attn_bwd_stagger.log - and was removed.)
+  // (Round 6, late: the staging phase had FIVE serial memory round trips per item - the kernel arguments re-read through vector
+  //  loads, then four blocks of loads under lane conditions that hipcc closed with s_waitcnt vmcnt(0) each.  Now: arguments by
+  //  scalar loads, every staging load branch-free in one batch.  Fetching the next item's q / k rows into registers under the
+  //  tile loop - 32 more live VGPRs - shortened the staging by 2.4 k cycles and lengthened the tiles by 3.2 k: removed;
+  //  profiles/r06_v23_attn_bwd_fused_variants.log.)
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
   if (item != (int)blockIdx.x) __syncthreads();      // the previous item's last LDS reads (lone-row finish) are done
   const FusedBwdP p = fb_reload_params();
@@ -191,20 +198,19 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_fused_kernel(const FusedBwdP 
 
   FB_STAMP(p, 0);
   // ---------------------------------------------------------------- staging: one memory round trip for the workgroup
-  // K / V rows of this lane as MFMA column operands
+  // V rows of this lane as MFMA column operands (the K rows come out of the staged image behind the barrier: 32 KB less
+  // to fetch per item)
   bf16x8 kf[4], vf[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    kf[ks] = fb_load_frag(Kb + (long)krow * p.k.sr, ks, fg);
-    vf[ks] = fb_load_frag(Vb + (long)krow * p.v.sr, ks, fg);
-  }
+  for (int ks = 0; ks < 4; ++ks) vf[ks] = fb_load_frag(Vb + (long)krow * p.v.sr, ks, fg);
   // the lone row: lane d of wave 0 fetches element d of q, dO, o, k, v
-  [[maybe_unused]] float tq = 0.f, tg = 0.f, to = 0.f, tk = 0.f, tv = 0.f, tlse = 0.f;
-  if (p.tail && wid == 0) {
-    tq = bf2f(Qb[(long)lm * p.q.sr + lane]); tg = bf2f(Gb[(long)lm * p.dO.sr + lane]); to = bf2f(Ob[(long)lm * p.o.sr + lane]);
-    tk = bf2f(Kb[(long)lm * p.k.sr + lane]); tv = bf2f(Vb[(long)lm * p.v.sr + lane]);
-    tlse = p.lse[bh * p.L + lm];
-  }
+  // (EVERY wave loads it, from a row that exists with or without a lone row, and uses only wave 0's copy: loads whose
+  //  results are consumed under a condition leave hipcc's wait-count analysis with "pending" registers on the other path,
+  //  and the first later write to one of them becomes an s_waitcnt that also drains the next item's q / k prefetch)
+  const long trow = p.tail ? lm : lm - 1;
+  const float tq = bf2f(Qb[trow * p.q.sr + lane]), tg = bf2f(Gb[trow * p.dO.sr + lane]), to = bf2f(Ob[trow * p.o.sr + lane]);
+  const float tk = bf2f(Kb[trow * p.k.sr + lane]), tv = bf2f(Vb[trow * p.v.sr + lane]);
+  const float tlse = p.lse[bh * p.L + trow];
   {
     // item = 16-byte chunk c of the row pair rp: rows 2rp, 2rp+1 of q, dO, k, o.  nt*128 items, two per thread.
     u32x4 qa[2], qb[2], ga[2], gb[2], ka[2], kb[2], oa[2], ob[2];
@@ -215,22 +221,18 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_fused_kernel(const FusedBwdP 
       const int rp = it >> 3, c = it & 7;
       const int row = 2 * rp;
       const u32x4 z = {0u, 0u, 0u, 0u};
-      qa[u] = z; qb[u] = z; ga[u] = z; gb[u] = z; ka[u] = z; kb[u] = z; oa[u] = z; ob[u] = z;
-      la[u] = INFINITY; lb[u] = INFINITY;
-      if (row < lm) {
-        qa[u] = *(const u32x4*)(Qb + (long)row * p.q.sr + c * 8);
-        ga[u] = *(const u32x4*)(Gb + (long)row * p.dO.sr + c * 8);
-        ka[u] = *(const u32x4*)(Kb + (long)row * p.k.sr + c * 8);
-        oa[u] = *(const u32x4*)(Ob + (long)row * p.o.sr + c * 8);
-        if (c == 0) la[u] = p.lse[bh * p.L + row];
-      }
-      if (row + 1 < lm) {
-        qb[u] = *(const u32x4*)(Qb + (long)(row + 1) * p.q.sr + c * 8);
-        gb[u] = *(const u32x4*)(Gb + (long)(row + 1) * p.dO.sr + c * 8);
-        kb[u] = *(const u32x4*)(Kb + (long)(row + 1) * p.k.sr + c * 8);
-        ob[u] = *(const u32x4*)(Ob + (long)(row + 1) * p.o.sr + c * 8);
-        if (c == 0) lb[u] = p.lse[bh * p.L + row + 1];
-      }
+      // branch-free (every lane loads a row that exists, rows past l_main are zeroed by selects): a load under a lane
+      // condition makes hipcc close the block with s_waitcnt vmcnt(0) - the four conditional blocks this replaces were
+      // four SERIAL memory round trips
+      const bool ok0 = row < lm, ok1 = row + 1 < lm;
+      const long ra = ok0 ? row : 0, rb = ok1 ? row + 1 : 0;
+      const u32x4 g0 = *(const u32x4*)(Gb + ra * p.dO.sr + c * 8), o0 = *(const u32x4*)(Ob + ra * p.o.sr + c * 8);
+      const u32x4 g1 = *(const u32x4*)(Gb + rb * p.dO.sr + c * 8), o1 = *(const u32x4*)(Ob + rb * p.o.sr + c * 8);
+      const float l0 = p.lse[bh * p.L + ra], l1 = p.lse[bh * p.L + rb];
+      const u32x4 q0 = *(const u32x4*)(Qb + ra * p.q.sr + c * 8), k0 = *(const u32x4*)(Kb + ra * p.k.sr + c * 8);
+      const u32x4 q1 = *(const u32x4*)(Qb + rb * p.q.sr + c * 8), k1 = *(const u32x4*)(Kb + rb * p.k.sr + c * 8);
+      ga[u] = ok0 ? g0 : z; oa[u] = ok0 ? o0 : z; la[u] = ok0 ? l0 : INFINITY; qa[u] = ok0 ? q0 : z; ka[u] = ok0 ? k0 : z;
+      gb[u] = ok1 ? g1 : z; ob[u] = ok1 ? o1 : z; lb[u] = ok1 ? l1 : INFINITY; qb[u] = ok1 ? q1 : z; kb[u] = ok1 ? k1 : z;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -244,8 +246,10 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_fused_kernel(const FusedBwdP 
       *(u32x4*)(sK + o0) = ka[u]; *(u32x4*)(sK + o1) = kb[u];
       const float d0 = fb_sum8(dot8(__builtin_bit_cast(bf16x8, ga[u]), __builtin_bit_cast(bf16x8, oa[u]), 0.f));
       const float d1 = fb_sum8(dot8(__builtin_bit_cast(bf16x8, gb[u]), __builtin_bit_cast(bf16x8, ob[u]), 0.f));
+      float nl0 = -la[u] * FB_LOG2E, nl1 = -lb[u] * FB_LOG2E;             // by every lane, outside the lane condition (see above)
+      asm volatile("" : "+v"(nl0), "+v"(nl1));
       if (c == 0) {
-        sNegL[r0] = -la[u] * FB_LOG2E; sNegL[r1] = -lb[u] * FB_LOG2E;      // padded rows: -inf
+        sNegL[r0] = nl0; sNegL[r1] = nl1;                                    // padded rows: -inf
         sNegD[r0] = -d0; sNegD[r1] = -d1;                                    // padded rows: 0 (zero-filled operands)
       }
     }
@@ -261,6 +265,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_fused_kernel(const FusedBwdP 
   FB_STAMP(p, 1);
   __syncthreads();
   FB_STAMP(p, 2);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kf[ks] = fb_rows(sK, krow, ks, fg);
   if (item + (int)gridDim.x < nitems && tid < p.L) {
     // touch the next item's lines (fire and forget: the values are never read; the loads retire under the tile loop)
     const int nb = (item + gridDim.x) / p.H, nh = (item + gridDim.x) - nb * p.H;
