@@ -79,6 +79,15 @@ for WL in c2 c4 c5; do
   tail -1 gpurun_out/r06_bench_$WL.log > gpurun_out/r06_bench_${WL}_train_step.json
   cut -c1-1200 gpurun_out/r06_bench_${WL}_train_step.json
 done
+for WL in c4 c5; do
+  stamp "rocprof stats $WL (one stream)"
+  rm -rf gpurun_out/r06_prof_$WL
+  cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r06_prof_$WL -o r06 -- python $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-overlap-frozen > $R/gpurun_out/r06_rocprof_$WL.log 2>&1
+  cd $R
+  find gpurun_out/r06_prof_$WL -name "*kernel_trace*" -delete
+  f=$(find gpurun_out/r06_prof_$WL -name "*kernel_stats*.csv" | head -1)
+  [ -n "$f" ] && cp $f gpurun_out/r06_bench_${WL}_kernel_stats.csv
+done
 fi
 stamp "micro-batch size on the two-stream schedule (128 / 512 against the default 256)"
 for MB in 128 512; do
