@@ -295,6 +295,47 @@ __global__ void __launch_bounds__(256) row_stats_kernel(const float* part, int P
   const int row = m_main + ((int)blockIdx.x - nb_main) * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const bf16_t* xr = x + (size_t)row * xs;
+  if ((D & 511) == 0 && D <= 2048 && (xs & 7) == 0 && (((uintptr_t)x) & 15) == 0) {
+    // the row once, in registers (8 consecutive values per lane and 512-column slab): this kernel is ~350 launches of a C3
+    // step that do nothing but wait for memory, and the three passes below are three round trips
+    u32x4 v[4];
+    const int nc = D >> 9;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) if (c < nc) v[c] = *(const u32x4*)(xr + (c * 64 + lane) * 8);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) if (c < nc)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += bf2f((bf16_t)(v[c][e] & 0xffff)) + bf2f((bf16_t)(v[c][e] >> 16));
+    const float mu = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) if (c < nc)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d0 = bf2f((bf16_t)(v[c][e] & 0xffff)) - mu, d1 = bf2f((bf16_t)(v[c][e] >> 16)) - mu;
+        q = fmaf(d0, d0, q); q = fmaf(d1, d1, q);
+      }
+    const float rs = rsqrtf(wave_sum(q) * invD + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    if (y && row >= y_row0) {
+      bf16_t* yr = y + (size_t)(row - y_row0) * ys;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) if (c < nc) {
+        const int e0 = (c * 64 + lane) * 8;
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = pack2bf(fmaf((bf2f((bf16_t)(v[c][e] & 0xffff)) - mu) * rs, lw[e0 + 2 * e], lb[e0 + 2 * e]),
+                         fmaf((bf2f((bf16_t)(v[c][e] >> 16)) - mu) * rs, lw[e0 + 2 * e + 1], lb[e0 + 2 * e + 1]));
+        if ((ys & 7) == 0 && (((uintptr_t)y) & 15) == 0) *(u32x4*)(yr + e0) = o;
+        else
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { yr[e0 + 2 * e] = (bf16_t)(o[e] & 0xffff); yr[e0 + 2 * e + 1] = (bf16_t)(o[e] >> 16); }
+      }
+    }
+    return;
+  }
   float s = 0.f;
   for (int e = lane; e < D; e += 64) s += bf2f(xr[e]);
   const float mu = wave_sum(s) * invD;
