@@ -119,6 +119,25 @@ def test_gelu_erf_accuracy():
     assert bool(((out - ref).abs() <= ulp).all())
 
 
+def test_standalone_geglu_equals_the_gemm_epilogue():
+    """`vl_geglu_bf16` (h [rows, 2n] of interleaved (a, gate) pairs -> a * gelu(gate)): what the GEGLU epilogue of the
+    Perceiver's first feed-forward GEMM computes, as a kernel of its own for hosts that keep only the pre-activation.  Same
+    arithmetic on the same bf16 pairs: bit-equal to the epilogue's output, and within bf16 rounding of torch."""
+    ops = _ops()
+    M, N, K = 512, 1024, 512
+    a = rnd(M, K, scale=0.5, seed=1).bfloat16().cuda()
+    w = rnd(N, K, scale=0.2, seed=2).bfloat16().cuda()
+    bias = rnd(N, seed=3).cuda()
+    h = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    # cfg 8 = the persistent kernel, whose epilogue multiplies the bf16-ROUNDED pairs as autocast does (the small-tile kernels
+    # that `cfg=-1` picks for a problem this small apply gelu to the fp32 accumulators: up to one bf16 ulp apart)
+    fused = ops.gemm(a, w, bias, epi=ops.EPI_GEGLU, out2=h, cfg=8)         # out2 = the bf16 pre-activation pairs
+    alone = ops.geglu_bf16(h, torch.empty(M, N // 2, device="cuda", dtype=torch.bfloat16))
+    assert torch.equal(fused, alone)
+    ref = h.float()[:, 0::2] * torch.nn.functional.gelu(h.float()[:, 1::2])
+    assert relerr(alone, ref) < 4e-3
+
+
 def _attn_reference(qf, kf, vf, causal):
     s = qf @ kf.transpose(-1, -2)
     if causal:
