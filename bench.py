@@ -427,6 +427,33 @@ def synth_text(n, gen, ctx=77, vocab=49408):
     return t
 
 
+def emit_result_line(out, rank, use_dist):
+    """Rank 0's ONE JSON line, as the LAST line of the job's stdout.  Native libraries print through C stdio, which is fully
+    buffered on a pipe and flushed at process exit: RCCL's five-line version banner came out AFTER the JSON line of a
+    `--force-dist` run (round 6, `gpurun_out/fd_stdout.log`) - a driver that reads the last line would not find the result.
+    So: every rank flushes C stdio, the ranks meet, the process group is torn down, ranks other than 0 say nothing more, and
+    rank 0 prints the line and then closes its stdout for whatever an exit handler might still write."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if use_dist:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+    if rank == 0:
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 1)
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: become the launcher.  Re-executes this script with the same
     arguments as N ranks of one node under torch.distributed.run (reference: env-based world discovery of
@@ -441,6 +468,12 @@ def spawn_ranks(n):
     env.setdefault("OMP_NUM_THREADS", "8")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    try:        # nothing this launcher process holds in C stdio may come out behind the ranks' result line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     return subprocess.call(cmd, env=env)
 
 
@@ -495,9 +528,7 @@ def selftest_main(a, rank, world):
             out["per_rank_ms_per_step"] = per_rank_ms
             out["collective_ms_per_step"] = coll
             out["collective_share"] = round(sum(coll.values()) / ms, 4) if coll else 0.0
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    emit_result_line(out if rank == 0 else None, rank, world > 1)
 
 
 def main():
@@ -747,9 +778,7 @@ def main():
             os.makedirs(os.path.dirname(os.path.abspath(a.detail)), exist_ok=True)
             with open(a.detail, "w") as fh:
                 json.dump({"shapes": shapes, "ms_per_step": ms}, fh, indent=1)
-        print(json.dumps(out))
-    if use_dist:
-        dist.destroy_process_group()
+    emit_result_line(out if rank == 0 else None, rank, use_dist)
 
 
 if __name__ == "__main__":

@@ -69,3 +69,21 @@ def test_under_torchrun_is_a_rank():
     assert p.returncode == 0, p.stderr[-2000:]
     (j,) = _json_lines(p.stdout)
     assert j["n_gpus"] == 2
+
+
+@pytest.mark.parametrize("gpus", ["1", "2"])
+def test_result_line_is_the_last_line_of_stdout_even_behind_native_prints(gpus):
+    """RCCL prints a version banner through C stdio; on a pipe that buffer is flushed at process exit - AFTER Python's own
+    prints (round 6: the five banner lines followed the JSON line of `bench.py --force-dist`).  A driver that reads the last
+    line of stdout must still find the result: bench.py flushes C stdio before its line and closes stdout after it.  Here the
+    native print is libc `puts` issued before bench's main() in every rank."""
+    code = ("import ctypes, sys, runpy; ctypes.CDLL(None).puts(b'native banner line (C stdio, buffered on a pipe)'); "
+            f"sys.argv = ['bench.py', '--gpus', '{gpus}', '--steps', '2', '--warmup', '1', '--workload', 'selftest']; "
+            f"runpy.run_path({os.path.join(ROOT, 'bench.py')!r}, run_name='__main__')")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert lines and lines[-1].startswith("{"), lines[-3:]
+    assert json.loads(lines[-1])["n_gpus"] == int(gpus)
+    assert "native banner line" in p.stdout          # (it was printed - in front of the result, not behind it)
