@@ -47,6 +47,8 @@ def test_bench_force_dist_reports_the_collectives():
                         "--batch", "64", "--micro-batch", "32", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    # the result line is the LAST line of stdout: RCCL's version banner (C stdio, flushed at exit) used to follow it
+    assert [l for l in r.stdout.splitlines() if l.strip()][-1].startswith("{"), r.stdout[-600:]
     assert out["n_gpus"] == 1 and out["config"].get("force_dist") is True
     coll = out["collective_ms_per_step"]
     assert "all_gather" in coll and ("all_reduce_wait" in coll or "all_reduce" in coll), coll
